@@ -1,0 +1,177 @@
+/*
+ * orb_oracle.h -- CPU restatement ("oracle") of the ORB-SLAM2 per-frame front end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liborboracle.so.  The product
+ * (liborbfe.so, HIP) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference (sjulier/Refactored_ORB_SLAM2) ships no tests, fixtures or golden
+ * vectors for this path and cannot be compiled in this image (needs OpenCV, which is neither vendored
+ * nor installed).  The OpenCV primitives it calls (cv::FAST, cv::resize, cv::GaussianBlur,
+ * cv::fastAtan2, cvRound) are restated here from the published OpenCV 4.5.x generic (non-IPP) algorithms
+ * and cross-checked by an independent numpy restatement (tests/np_restatement.py), not by the real
+ * reference binary.
+ *
+ * Every function cites the reference file:line it follows.  Abbreviation: L/ =
+ * Source/Libraries/ORB_SLAM2/ of the reference checkout.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout-identical to cv::KeyPoint (7 x 4 bytes) */
+typedef struct oo_keypoint {
+  float x, y;      /* pt */
+  float size;
+  float angle;     /* degrees [0,360) */
+  float response;  /* FAST score */
+  int32_t octave;
+  int32_t class_id;
+} oo_keypoint;
+
+#define OO_MAX_LEVELS 16
+#define OO_GRID_COLS 64 /* L/include/Frame.h:37 */
+#define OO_GRID_ROWS 48 /* L/include/Frame.h:36 */
+#define OO_TH_HIGH 100  /* L/src/ORBmatcher.cc:38 */
+#define OO_TH_LOW 50    /* L/src/ORBmatcher.cc:39 */
+#define OO_HISTO_LENGTH 30 /* L/src/ORBmatcher.cc:40 */
+
+/* ---------------------------------------------------------------- primitives (OpenCV restatements) */
+int oo_cvround(double v);                 /* P1: round half to even */
+int oo_cvroundf(float v);
+float oo_fast_atan2(float y, float x);    /* P5: cv::fastAtan2, degrees */
+float oo_sinf(float x);                   /* restatement of glibc 2.35 sinf for |x| < 120 */
+float oo_cosf(float x);
+void oo_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
+                         int dstride);    /* P2 */
+/* coefficient tables of P2 for one axis: ofs[d], coef[2*d..2*d+1] */
+void oo_resize_tables(int s, int d, int32_t* ofs, int16_t* coef);
+void oo_gauss_taps7(int taps[7]);         /* P3 fixed-point taps for ksize 7, sigma 2 */
+void oo_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride); /* P3 */
+void oo_copy_make_border_reflect101(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride,
+                                    int border); /* P6 */
+/* P4: cv::FAST(roi, th, nonmax=true), TYPE_9_16.  Returns number of keypoints written (x,y,score). */
+int oo_fast9_16(const uint8_t* img, int stride, int cols, int rows, int threshold, int nonmax, int cap,
+                int* out_x, int* out_y, int* out_score);
+int oo_fast_corner_score(const uint8_t* p, int stride, int threshold);
+
+/* ---------------------------------------------------------------- extractor (L/src/ORBextractor.cc) */
+typedef struct oo_extractor oo_extractor;
+
+oo_extractor* oo_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                                  int min_th_fast);            /* ORBextractor.cc:407-464 */
+void oo_extractor_destroy(oo_extractor* e);
+int oo_extractor_levels(const oo_extractor* e);
+const float* oo_extractor_scale_factors(const oo_extractor* e);     /* mvScaleFactor */
+const float* oo_extractor_inv_scale_factors(const oo_extractor* e); /* mvInvScaleFactor */
+const float* oo_extractor_sigma2(const oo_extractor* e);            /* mvLevelSigma2 */
+const float* oo_extractor_inv_sigma2(const oo_extractor* e);        /* mvInvLevelSigma2 */
+const int* oo_extractor_features_per_level(const oo_extractor* e);  /* mnFeaturesPerLevel */
+const int* oo_extractor_umax(const oo_extractor* e);                /* umax[0..15] */
+const int8_t* oo_pattern(void);                                     /* 1024 int8 */
+
+/* operator(): ORBextractor.cc:978-1039.  Returns 0, or <0 on error (cap too small: -2).  Empty image:
+ * returns 0 and leaves outputs untouched with *n_out = -1 (reference: silent return, :981-982). */
+int oo_extract(oo_extractor* e, const uint8_t* img, int w, int h, int stride, oo_keypoint* kps, uint8_t* desc,
+               int cap, int* n_out);
+
+/* intermediate results of the last oo_extract call (for stage-level parity tests) */
+int oo_level_size(const oo_extractor* e, int level, int* w, int* h);
+const uint8_t* oo_level_pixels(const oo_extractor* e, int level, int* stride);     /* mvImagePyramid[level] */
+const uint8_t* oo_level_blurred(const oo_extractor* e, int level, int* stride);    /* workingMat after blur */
+/* FAST candidates handed to DistributeOctTree at this level (coords relative to (16,16)) */
+int oo_level_candidates(const oo_extractor* e, int level, const int** x, const int** y, const int** score);
+/* keypoints chosen by DistributeOctTree at this level, in list order (level coords incl. +16 border) */
+int oo_level_keypoints(const oo_extractor* e, int level, const oo_keypoint** kps);
+
+/* DistributeOctTree: ORBextractor.cc:529-731 (+DivideNode :475-527).  Inputs are candidate coordinates
+ * relative to (minX,minY) and their responses, in vToDistributeKeys order.  Writes selected candidate
+ * indices in list order; returns their count (<= n).  The reference's secondary sort key is a heap
+ * pointer (allocator dependent); this restatement orders equal-size nodes by creation sequence, i.e.
+ * behaves as a bump allocator would. */
+int oo_distribute_octree(const int* x, const int* y, const int* score, int n, int minX, int maxX, int minY,
+                         int maxY, int N, int* out_idx);
+
+float oo_ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax);   /* :76-100 */
+void oo_orb_descriptor(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
+                       uint8_t desc[32]);                                          /* :103-146 */
+
+/* ---------------------------------------------------------------- matcher (L/src/ORBmatcher.cc, Frame.cc) */
+int oo_descriptor_distance(const uint8_t* a, const uint8_t* b); /* ORBmatcher.cc:1542-1556 */
+
+typedef struct oo_frame {
+  int n;                      /* Frame::N */
+  const oo_keypoint* keys_un; /* mvKeysUn */
+  const uint8_t* desc;        /* mDescriptors, n x 32 */
+  const float* u_right;       /* mvuRight (may be NULL = all -1) */
+  float min_x, max_x, min_y, max_y;       /* mnMinX.. */
+  float grid_w_inv, grid_h_inv;           /* mfGridElementWidthInv/HeightInv */
+  int n_levels;
+  const float* scale_factors;             /* mvScaleFactors */
+  /* grid in CSR form, cell = ix * OO_GRID_ROWS + iy (mGrid[ix][iy]); filled by oo_frame_build_grid */
+  int32_t cell_start[OO_GRID_COLS * OO_GRID_ROWS + 1];
+  int32_t* cell_idx;          /* n entries, caller-allocated */
+} oo_frame;
+
+void oo_frame_build_grid(oo_frame* f);  /* Frame.cc:250-263, 399-410 */
+/* Frame.cc:341-397.  Returns count, indices in reference enumeration order. */
+int oo_features_in_area(const oo_frame* f, float x, float y, float r, int min_level, int max_level,
+                        int32_t* out_idx);
+
+/* One projected map point / last-frame point, as the searches consume it */
+typedef struct oo_query {
+  float u, v;          /* projection (mTrackProjX/Y or u,v) */
+  float u_r;           /* mTrackProjXR or u - mbf*invzc */
+  float radius;        /* search radius already scaled (r*scale[level] or th*scale[octave]) */
+  int32_t min_level, max_level;
+  int32_t valid;       /* 0: skipped by the reference before the window query */
+  int32_t blocks;      /* 1 if the map point has Observations()>0 (an assignment of it blocks later queries) */
+  float angle;         /* keypoint angle for the rotation histogram (A12) */
+  uint8_t desc[32];
+} oo_query;
+
+/* SearchByProjection(Frame&, vector<MapPoint*>&, th): ORBmatcher.cc:45-128.
+ * blocked[idx] != 0 <=> F.mvpMapPoints[idx] has Observations()>0 on entry; updated in place.
+ * assigned[idx] = query index written to F.mvpMapPoints[idx] (or left unchanged).  Returns nmatches. */
+int oo_search_by_projection_points(const oo_frame* f, const oo_query* q, int nq, float nnratio, uint8_t* blocked,
+                                   int32_t* assigned);
+/* SearchByProjection(Frame& cur, const Frame& last, th, bMono): ORBmatcher.cc:1247-1383 (window,
+ * argmin, TH_HIGH, rotation histogram).  Queries carry the projection.  Returns nmatches. */
+int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq, int check_orientation,
+                                  uint8_t* blocked, int32_t* assigned);
+/* SearchByBoW(KeyFrame*, Frame&, ...): ORBmatcher.cc:161-273 with feature vectors as sorted node lists.
+ * nodeA/nodeB: n_nodes entries {node_id, start, count} into idxA/idxB.  validA[i]!=0 <=> KF feature i has
+ * a good map point.  matchB[j] = KF index matched to frame feature j, or -1.  Returns nmatches. */
+typedef struct oo_featvec_node { int32_t node_id, start, count; } oo_featvec_node;
+int oo_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* validA,
+                     const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
+                     const float* angleB, int nB, const oo_featvec_node* nodesB, int n_nodesB,
+                     const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchB);
+/* SearchForInitialization: ORBmatcher.cc:388-492 */
+int oo_search_for_initialization(const oo_keypoint* keys1, const uint8_t* desc1, int n1, const oo_frame* f2,
+                                 float* prev_matched_xy, int window, float nnratio, int check_orientation,
+                                 int32_t* matches12);
+void oo_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3); /* :1506-1538 */
+
+/* Frame::ComputeStereoMatches: Frame.cc:477-646.  pyrL/pyrR: per-level plane pointers+strides+sizes of
+ * the two extractors' mvImagePyramid.  Writes u_right[n], depth[n] (-1 when unmatched). */
+typedef struct oo_pyramid_view {
+  int n_levels;
+  const uint8_t* data[OO_MAX_LEVELS];
+  int stride[OO_MAX_LEVELS], w[OO_MAX_LEVELS], h[OO_MAX_LEVELS];
+} oo_pyramid_view;
+int oo_compute_stereo_matches(const oo_keypoint* keysL, const uint8_t* descL, int nL, const oo_keypoint* keysR,
+                              const uint8_t* descR, int nR, const oo_pyramid_view* pyrL,
+                              const oo_pyramid_view* pyrR, const float* scale_factors,
+                              const float* inv_scale_factors, float mbf, float mb, float* u_right,
+                              float* depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

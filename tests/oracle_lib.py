@@ -1,0 +1,348 @@
+"""ctypes binding of oracle/_build/liborboracle.so (the CPU restatement; TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liborboracle.so")
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+assert KP_DTYPE.itemsize == 28
+
+QUERY_DTYPE = np.dtype(
+    [("u", "<f4"), ("v", "<f4"), ("u_r", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
+     ("max_level", "<i4"), ("valid", "<i4"), ("blocks", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))]
+)
+assert QUERY_DTYPE.itemsize == 68
+
+GRID_COLS, GRID_ROWS = 64, 48
+MAX_LEVELS = 16
+
+
+class OOFrame(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("keys_un", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p),
+        ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+        ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float), ("n_levels", C.c_int),
+        ("scale_factors", C.c_void_p), ("cell_start", C.c_int32 * (GRID_COLS * GRID_ROWS + 1)),
+        ("cell_idx", C.c_void_p),
+    ]
+
+
+class OOPyramidView(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("data", C.c_void_p * MAX_LEVELS), ("stride", C.c_int * MAX_LEVELS),
+                ("w", C.c_int * MAX_LEVELS), ("h", C.c_int * MAX_LEVELS)]
+
+
+class FeatVecNode(C.Structure):
+    _fields_ = [("node_id", C.c_int32), ("start", C.c_int32), ("count", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle.c", "orb_oracle.h")]
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src if os.path.exists(s))
+    if stale:
+        subprocess.run(["make", "-C", ORACLE_DIR, "-B"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.oo_cvround.restype = ci; L.oo_cvround.argtypes = [C.c_double]
+    L.oo_cvroundf.restype = ci; L.oo_cvroundf.argtypes = [cf]
+    L.oo_fast_atan2.restype = cf; L.oo_fast_atan2.argtypes = [cf, cf]
+    L.oo_sinf.restype = cf; L.oo_sinf.argtypes = [cf]
+    L.oo_cosf.restype = cf; L.oo_cosf.argtypes = [cf]
+    L.oo_resize_linear_u8.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci]
+    L.oo_resize_tables.argtypes = [ci, ci, vp, vp]
+    L.oo_gauss_taps7.argtypes = [vp]
+    L.oo_gaussian_blur7_u8.argtypes = [vp, ci, ci, ci, vp, ci]
+    L.oo_copy_make_border_reflect101.argtypes = [vp, ci, ci, ci, vp, ci, ci]
+    L.oo_fast9_16.restype = ci; L.oo_fast9_16.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    L.oo_fast_corner_score.restype = ci; L.oo_fast_corner_score.argtypes = [vp, ci, ci]
+    L.oo_extractor_create.restype = vp; L.oo_extractor_create.argtypes = [ci, cf, ci, ci, ci]
+    L.oo_extractor_destroy.argtypes = [vp]
+    L.oo_extractor_levels.restype = ci; L.oo_extractor_levels.argtypes = [vp]
+    for name in ("scale_factors", "inv_scale_factors", "sigma2", "inv_sigma2"):
+        f = getattr(L, "oo_extractor_" + name); f.restype = C.POINTER(cf); f.argtypes = [vp]
+    L.oo_extractor_features_per_level.restype = C.POINTER(ci); L.oo_extractor_features_per_level.argtypes = [vp]
+    L.oo_extractor_umax.restype = C.POINTER(ci); L.oo_extractor_umax.argtypes = [vp]
+    L.oo_pattern.restype = C.POINTER(C.c_int8)
+    L.oo_extract.restype = ci; L.oo_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, C.POINTER(ci)]
+    L.oo_level_size.restype = ci; L.oo_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.oo_level_pixels.restype = vp; L.oo_level_pixels.argtypes = [vp, ci, C.POINTER(ci)]
+    L.oo_level_blurred.restype = vp; L.oo_level_blurred.argtypes = [vp, ci, C.POINTER(ci)]
+    L.oo_level_candidates.restype = ci
+    L.oo_level_candidates.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.oo_level_keypoints.restype = ci; L.oo_level_keypoints.argtypes = [vp, ci, C.POINTER(vp)]
+    L.oo_distribute_octree.restype = ci
+    L.oo_distribute_octree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    L.oo_ic_angle.restype = cf; L.oo_ic_angle.argtypes = [vp, ci, ci, ci, vp]
+    L.oo_orb_descriptor.argtypes = [vp, ci, ci, ci, cf, vp]
+    L.oo_descriptor_distance.restype = ci; L.oo_descriptor_distance.argtypes = [vp, vp]
+    L.oo_frame_build_grid.argtypes = [C.POINTER(OOFrame)]
+    L.oo_features_in_area.restype = ci
+    L.oo_features_in_area.argtypes = [C.POINTER(OOFrame), cf, cf, cf, ci, ci, vp]
+    L.oo_search_by_projection_points.restype = ci
+    L.oo_search_by_projection_points.argtypes = [C.POINTER(OOFrame), vp, ci, cf, vp, vp]
+    L.oo_search_by_projection_frame.restype = ci
+    L.oo_search_by_projection_frame.argtypes = [C.POINTER(OOFrame), vp, ci, ci, vp, vp]
+    L.oo_search_by_bow.restype = ci
+    L.oo_search_by_bow.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp]
+    L.oo_search_for_initialization.restype = ci
+    L.oo_search_for_initialization.argtypes = [vp, vp, ci, C.POINTER(OOFrame), vp, ci, cf, ci, vp]
+    L.oo_three_maxima.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.oo_compute_stereo_matches.restype = ci
+    L.oo_compute_stereo_matches.argtypes = [vp, vp, ci, vp, vp, ci, C.POINTER(OOPyramidView),
+                                            C.POINTER(OOPyramidView), vp, vp, cf, cf, vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """Mirror of ORB_SLAM2::ORBextractor over the C oracle."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.oo_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oo_extractor_destroy(self.h)
+            self.h = None
+
+    def _farr(self, fn, n):
+        return np.array([fn(self.h)[i] for i in range(n)], dtype=np.float32)
+
+    @property
+    def scale_factors(self):
+        return self._farr(self.L.oo_extractor_scale_factors, self.nlevels)
+
+    @property
+    def inv_scale_factors(self):
+        return self._farr(self.L.oo_extractor_inv_scale_factors, self.nlevels)
+
+    @property
+    def sigma2(self):
+        return self._farr(self.L.oo_extractor_sigma2, self.nlevels)
+
+    @property
+    def inv_sigma2(self):
+        return self._farr(self.L.oo_extractor_inv_sigma2, self.nlevels)
+
+    @property
+    def features_per_level(self):
+        p = self.L.oo_extractor_features_per_level(self.h)
+        return [p[i] for i in range(self.nlevels)]
+
+    @property
+    def umax(self):
+        p = self.L.oo_extractor_umax(self.h)
+        return [p[i] for i in range(16)]
+
+    def __call__(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        rc = self.L.oo_extract(self.h, _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"oo_extract rc={rc} n={n.value}")
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        self.L.oo_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def _plane(self, fn, level):
+        w, h = self.level_size(level)
+        s = C.c_int()
+        p = fn(self.h, level, C.byref(s))
+        if not p:
+            return None
+        buf = (C.c_uint8 * (s.value * h)).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h, s.value)[:, :w].copy()
+
+    def level_pixels(self, level):
+        return self._plane(self.L.oo_level_pixels, level)
+
+    def level_blurred(self, level):
+        return self._plane(self.L.oo_level_blurred, level)
+
+    def level_candidates(self, level):
+        x, y, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = self.L.oo_level_candidates(self.h, level, C.byref(x), C.byref(y), C.byref(s))
+        if n == 0:
+            z = np.zeros(0, np.int32)
+            return z, z, z
+        mk = lambda p: np.frombuffer((C.c_int * n).from_address(p.value), dtype=np.int32).copy()
+        return mk(x), mk(y), mk(s)
+
+    def level_keypoints(self, level):
+        p = C.c_void_p()
+        n = self.L.oo_level_keypoints(self.h, level, C.byref(p))
+        if n == 0:
+            return np.zeros(0, KP_DTYPE)
+        return np.frombuffer((C.c_uint8 * (28 * n)).from_address(p.value), dtype=KP_DTYPE).copy()
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oo_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().oo_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast9_16(img: np.ndarray, th: int, nonmax: bool = True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    x = np.zeros(cap, np.int32); y = np.zeros(cap, np.int32); s = np.zeros(cap, np.int32)
+    n = lib().oo_fast9_16(_p(img), img.strides[0], img.shape[1], img.shape[0], th, int(nonmax), cap, _p(x), _p(y), _p(s))
+    return x[:n], y[:n], s[:n]
+
+
+def distribute_octree(x, y, score, minX, maxX, minY, maxY, N):
+    x = np.ascontiguousarray(x, np.int32); y = np.ascontiguousarray(y, np.int32)
+    score = np.ascontiguousarray(score, np.int32)
+    out = np.zeros(max(len(x), 1), np.int32)
+    n = lib().oo_distribute_octree(_p(x), _p(y), _p(score), len(x), minX, maxX, minY, maxY, N, _p(out))
+    return out[:n]
+
+
+def descriptor_distance(a, b) -> int:
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().oo_descriptor_distance(_p(a), _p(b))
+
+
+class OracleFrame:
+    """POD view of the Frame members the matcher reads (mvKeysUn, mDescriptors, mvuRight, grid)."""
+
+    def __init__(self, kps, desc, scale_factors, min_x, max_x, min_y, max_y, u_right=None):
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        self.cell_idx = np.zeros(max(len(self.kps), 1), np.int32)
+        f = OOFrame()
+        f.n = len(self.kps)
+        f.keys_un = self.kps.ctypes.data
+        f.desc = self.desc.ctypes.data
+        f.u_right = None if self.u_right is None else self.u_right.ctypes.data
+        f.min_x, f.max_x, f.min_y, f.max_y = min_x, max_x, min_y, max_y
+        f.grid_w_inv = np.float32(GRID_COLS) / (np.float32(max_x) - np.float32(min_x))
+        f.grid_h_inv = np.float32(GRID_ROWS) / (np.float32(max_y) - np.float32(min_y))
+        f.n_levels = len(self.sf)
+        f.scale_factors = self.sf.ctypes.data
+        f.cell_idx = self.cell_idx.ctypes.data
+        self.f = f
+        lib().oo_frame_build_grid(C.byref(f))
+
+    @property
+    def cell_start(self):
+        return np.array(self.f.cell_start[:], dtype=np.int32)
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(self.f.n, 1), np.int32)
+        n = lib().oo_features_in_area(C.byref(self.f), x, y, r, min_level, max_level, _p(out))
+        return out[:n]
+
+    def search_by_projection_points(self, queries, nnratio, blocked=None):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        blocked = np.zeros(self.f.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        assigned = np.full(self.f.n, -1, np.int32)
+        nm = lib().oo_search_by_projection_points(C.byref(self.f), _p(q), len(q), nnratio, _p(blocked), _p(assigned))
+        return nm, assigned, blocked
+
+    def search_by_projection_frame(self, queries, check_orientation=True, blocked=None):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        blocked = np.zeros(self.f.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        assigned = np.full(self.f.n, -1, np.int32)
+        nm = lib().oo_search_by_projection_frame(C.byref(self.f), _p(q), len(q), int(check_orientation), _p(blocked), _p(assigned))
+        return nm, assigned, blocked
+
+
+def featvec_arrays(groups: dict):
+    """{node_id: [indices]} -> (nodes array of FeatVecNode, idx int32 array), nodes sorted by id."""
+    ids = sorted(groups)
+    nodes = (FeatVecNode * max(len(ids), 1))()
+    idx = []
+    for k, nid in enumerate(ids):
+        nodes[k].node_id = nid; nodes[k].start = len(idx); nodes[k].count = len(groups[nid])
+        idx.extend(groups[nid])
+    return nodes, len(ids), np.asarray(idx if idx else [0], np.int32)
+
+
+def search_by_bow(descA, angleA, validA, groupsA, descB, angleB, groupsB, nnratio=0.7, check_orientation=True):
+    descA = np.ascontiguousarray(descA, np.uint8); descB = np.ascontiguousarray(descB, np.uint8)
+    angleA = np.ascontiguousarray(angleA, np.float32); angleB = np.ascontiguousarray(angleB, np.float32)
+    validA = np.ascontiguousarray(validA, np.uint8)
+    nA, nnA, iA = featvec_arrays(groupsA)
+    nB, nnB, iB = featvec_arrays(groupsB)
+    matchB = np.full(len(descB), -1, np.int32)
+    nm = lib().oo_search_by_bow(_p(descA), _p(angleA), _p(validA), C.cast(nA, C.c_void_p), nnA, _p(iA),
+                                _p(descB), _p(angleB), len(descB), C.cast(nB, C.c_void_p), nnB, _p(iB),
+                                nnratio, int(check_orientation), _p(matchB))
+    return nm, matchB
+
+
+def pyramid_view(planes):
+    v = OOPyramidView()
+    v.n_levels = len(planes)
+    keep = []
+    for i, p in enumerate(planes):
+        p = np.ascontiguousarray(p, np.uint8)
+        keep.append(p)
+        v.data[i] = p.ctypes.data
+        v.stride[i] = p.strides[0]
+        v.w[i] = p.shape[1]
+        v.h[i] = p.shape[0]
+    return v, keep
+
+
+def compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, mbf, mb):
+    kL = np.ascontiguousarray(kL, KP_DTYPE); kR = np.ascontiguousarray(kR, KP_DTYPE)
+    dL = np.ascontiguousarray(dL, np.uint8); dR = np.ascontiguousarray(dR, np.uint8)
+    sf = np.ascontiguousarray(sf, np.float32); isf = np.ascontiguousarray(isf, np.float32)
+    vL, keepL = pyramid_view(planesL)
+    vR, keepR = pyramid_view(planesR)
+    ur = np.zeros(len(kL), np.float32); depth = np.zeros(len(kL), np.float32)
+    n = lib().oo_compute_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), C.byref(vL), C.byref(vR),
+                                        _p(sf), _p(isf), mbf, mb, _p(ur), _p(depth))
+    return n, ur, depth
