@@ -1,0 +1,218 @@
+/*
+ * orbfe.h -- C ABI of liborbfe.so: the MI355X (gfx950) ORB front end.
+ *
+ * This is the drop-in boundary for ORB-SLAM2's per-frame feature front end.  The reference
+ * (sjulier/Refactored_ORB_SLAM2) has no FFI for this path: the boundary there is two C++ classes,
+ *   ORB_SLAM2::ORBextractor  (Source/Libraries/ORB_SLAM2/include/ORBextractor.h:43-104)
+ *   ORB_SLAM2::ORBmatcher    (Source/Libraries/ORB_SLAM2/include/ORBmatcher.h:34-114)
+ * and Frame's window query / stereo association (Source/Libraries/ORB_SLAM2/src/Frame.cc:250-263,
+ * 341-410, 477-646).  The C++ classes shipped in refactored_orb_slam2_amd/csrc/host/ keep those exact
+ * signatures and forward to the entry points below, so Tracking.cc / Frame.cc link unchanged
+ * (INTEGRATION.md).  Everything here is plain C: opaque handles, POD structs, pointers and sizes; every
+ * function returns ORBFE_OK (0) or a negative error code and never throws.  There is NO CPU fallback:
+ * without a HIP device every compute entry point returns ORBFE_ERR_NO_DEVICE.
+ *
+ * L/ = Source/Libraries/ORB_SLAM2/ of the reference checkout.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_VERSION 100
+
+enum {
+  ORBFE_OK = 0,
+  ORBFE_ERR_INVALID = -1,    /* bad argument (null pointer, unsupported size, bad parameter) */
+  ORBFE_ERR_CAPACITY = -2,   /* an output buffer or an internal fixed-size table is too small */
+  ORBFE_ERR_NO_DEVICE = -3,  /* no usable HIP device / HIP runtime failure at start-up */
+  ORBFE_ERR_HIP = -4,        /* a HIP call failed; orbfe_last_error() has the text */
+  ORBFE_ERR_EMPTY = -5       /* empty input image: outputs untouched (L/src/ORBextractor.cc:981-982) */
+};
+
+#define ORBFE_MAX_LEVELS 16
+#define ORBFE_GRID_COLS 64   /* FRAME_GRID_COLS, L/include/Frame.h:37 */
+#define ORBFE_GRID_ROWS 48   /* FRAME_GRID_ROWS, L/include/Frame.h:36 */
+#define ORBFE_TH_HIGH 100    /* ORBmatcher::TH_HIGH, L/src/ORBmatcher.cc:38 */
+#define ORBFE_TH_LOW 50      /* ORBmatcher::TH_LOW,  L/src/ORBmatcher.cc:39 */
+#define ORBFE_HISTO_LENGTH 30
+
+/* Constructor arguments of ORBextractor (L/src/ORBextractor.cc:407-410) */
+typedef struct orbfe_params {
+  int32_t n_features;
+  float scale_factor;
+  int32_t n_levels;
+  int32_t ini_th_fast;
+  int32_t min_th_fast;
+} orbfe_params;
+
+/* Layout-identical to cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id; 28 bytes) */
+typedef struct orbfe_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} orbfe_keypoint;
+
+typedef struct orbfe_extractor orbfe_extractor;
+
+const char* orbfe_last_error(void);   /* thread-local text of the last failure on this thread */
+int orbfe_device_count(int* count);   /* number of visible HIP devices */
+
+/* ------------------------------------------------------------------------------------- ORBextractor */
+/* ORBextractor::ORBextractor (L/src/ORBextractor.cc:407-464).  device < 0 selects the current device. */
+int orbfe_extractor_create(const orbfe_params* params, int device, orbfe_extractor** out);
+int orbfe_extractor_destroy(orbfe_extractor* e);
+
+/* Getters of L/include/ORBextractor.h:60-74; each writes n_levels floats. */
+int orbfe_extractor_levels(const orbfe_extractor* e, int* n_levels);
+int orbfe_extractor_scale_factors(const orbfe_extractor* e, float* out);
+int orbfe_extractor_inv_scale_factors(const orbfe_extractor* e, float* out);
+int orbfe_extractor_sigma2(const orbfe_extractor* e, float* out);
+int orbfe_extractor_inv_sigma2(const orbfe_extractor* e, float* out);
+int orbfe_extractor_features_per_level(const orbfe_extractor* e, int32_t* out);
+/* Upper bound on keypoints per image: sum over levels of max(N_level + 3, 4 * nIni). */
+int orbfe_extractor_max_keypoints(const orbfe_extractor* e, int w, int h, int* cap);
+
+/* ORBextractor::operator() (L/src/ORBextractor.cc:978-1039) on ONE host image, synchronous.
+ * img: CV_8UC1, h rows of w bytes, `stride` bytes between rows.  kps/desc: caller-owned host buffers of
+ * `cap` entries (desc: cap x 32 bytes).  *n_out = number of keypoints.  Keypoints are in level order,
+ * inside a level in DistributeOctTree list order, coordinates in level-0 pixels. */
+int orbfe_extract(orbfe_extractor* e, const uint8_t* img, int w, int h, int stride, orbfe_keypoint* kps,
+                  uint8_t* desc, int cap, int* n_out);
+
+/* mvImagePyramid[level] of the last orbfe_extract call (L/include/ORBextractor.h:76; read by
+ * Frame::ComputeStereoMatches, L/src/Frame.cc:483,567-589).  Copies the level (no border) to host. */
+int orbfe_pyramid_level(orbfe_extractor* e, int level, uint8_t* dst, int dst_stride, int* w, int* h);
+int orbfe_pyramid_level_size(const orbfe_extractor* e, int w0, int h0, int level, int* w, int* h);
+
+/* Batched operator(): n_images host images of identical geometry, synchronous.  imgs[i] points to image i.
+ * kps: n_images x cap, desc: n_images x cap x 32, n_out: n_images. */
+int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* imgs, int n_images, int w, int h, int stride,
+                        orbfe_keypoint* kps, uint8_t* desc, int cap, int32_t* n_out);
+
+/* Device-resident batch: all pointers are DEVICE pointers; asynchronous on `stream` (a hipStream_t, or
+ * NULL for the handle's own stream).  d_imgs: image i at d_imgs + i*image_pitch, rows `stride` bytes
+ * apart.  d_kps: n_images x cap, d_desc: n_images x cap x 32, d_n_out: n_images int32.  Work space is
+ * (re)allocated when the geometry or batch size grows -- call once untimed before timing. */
+int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_imgs, int n_images, int w, int h, int stride,
+                               size_t image_pitch, orbfe_keypoint* d_kps, uint8_t* d_desc, int cap,
+                               int32_t* d_n_out, void* stream);
+/* Device pointer + geometry of pyramid level `level` of image `image` of the last device batch. */
+int orbfe_device_pyramid(const orbfe_extractor* e, int image, int level, const uint8_t** d_ptr, int* pitch,
+                         int* w, int* h);
+int orbfe_sync(orbfe_extractor* e);   /* wait for the handle's stream(s) */
+/* Waits for the handle's stream and returns ORBFE_ERR_CAPACITY if a kernel of an earlier (asynchronous)
+ * batch flagged an internal table overflow; ORBFE_OK otherwise. */
+int orbfe_device_status(orbfe_extractor* e);
+
+/* Stage-level outputs of the last batch, for parity tests (host copies; synchronous).
+ * candidates: FAST keypoints handed to DistributeOctTree (x, y relative to (16,16), score) in
+ * vToDistributeKeys order; blurred: workingMat after GaussianBlur; level_keypoints: octree selection
+ * before scaling (x, y in level coords, response). */
+int orbfe_debug_candidates(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y, int32_t* score,
+                           int cap, int* n);
+int orbfe_debug_blurred(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride);
+int orbfe_debug_pyramid(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride);
+int orbfe_debug_level_keypoints(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y,
+                                int32_t* score, int cap, int* n);
+
+/* Per-stage HIP-event timing of the handle's stream.  enable != 0 records events around every kernel
+ * stage of subsequent batches; orbfe_stage_times returns the accumulated milliseconds and launch counts
+ * since the last reset.  Stage ids: */
+enum {
+  ORBFE_STAGE_PYRAMID = 0,
+  ORBFE_STAGE_FAST = 1,
+  ORBFE_STAGE_OCTREE = 2,
+  ORBFE_STAGE_BLUR = 3,
+  ORBFE_STAGE_DESCRIBE = 4,
+  ORBFE_STAGE_COUNT = 5
+};
+int orbfe_profile_enable(orbfe_extractor* e, int enable);
+int orbfe_stage_times(orbfe_extractor* e, float* ms /*[ORBFE_STAGE_COUNT]*/, int32_t* launches, int reset);
+
+/* --------------------------------------------------------------------------------------- ORBmatcher */
+/* ORBmatcher::DescriptorDistance (L/src/ORBmatcher.cc:1542-1556) for all pairs: dist[i*nB + j] =
+ * Hamming(A[i], B[j]) as uint16.  DEVICE pointers, asynchronous on stream. */
+int orbfe_hamming_matrix_device(const uint8_t* d_A, int nA, const uint8_t* d_B, int nB, uint16_t* d_dist,
+                                void* stream);
+
+/* Brute-force best / second-best (the inner loops of SearchByBoW, L/src/ORBmatcher.cc:201-222): for
+ * every row i of A the first-minimum over j of B (strict <, index order) and the second-smallest
+ * distance.  groupA/groupB (nullable): compare only where groupA[i] == groupB[j] (vocabulary node id);
+ * maskB (nullable): skip j with maskB[j] != 0.  n_sets independent problems: set s uses rows
+ * [s*strideA, s*strideA + nA[s]) of A etc.  All pointers DEVICE pointers. */
+typedef struct orbfe_bf_match {
+  int32_t best_idx;    /* -1 when no candidate */
+  int32_t best_dist;   /* 256 when none */
+  int32_t second_dist; /* 256 when none */
+} orbfe_bf_match;
+int orbfe_hamming_bf_device(const uint8_t* d_A, const int32_t* d_nA, int strideA, const uint8_t* d_B,
+                            const int32_t* d_nB, int strideB, const int32_t* d_groupA, const int32_t* d_groupB,
+                            const uint8_t* d_maskB, int n_sets, orbfe_bf_match* d_out, void* stream);
+
+/* View of the Frame members the projection searches read (L/include/Frame.h): mvKeysUn, mDescriptors,
+ * mvuRight and the 64x48 grid (mGrid, filled as Frame::AssignFeaturesToGrid does). */
+typedef struct orbfe_frame_view {
+  int32_t n;                        /* Frame::N */
+  const orbfe_keypoint* keys_un;    /* mvKeysUn */
+  const uint8_t* desc;              /* mDescriptors (n x 32) */
+  const float* u_right;             /* mvuRight, nullable */
+  float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+} orbfe_frame_view;
+
+/* One projected map point (A11: L/src/ORBmatcher.cc:52-71; A12: :1270-1308) */
+typedef struct orbfe_query {
+  float u, v;       /* projection */
+  float u_r;        /* right-image coordinate of the projection */
+  float radius;     /* window half-size, already multiplied by the level scale */
+  int32_t min_level, max_level; /* GetFeaturesInArea level filter */
+  int32_t valid;    /* 0 = the reference skips this point before the window query */
+  int32_t blocks;   /* map point has Observations() > 0 */
+  float angle;      /* keypoint angle (rotation histogram of A12) */
+  uint8_t desc[32];
+} orbfe_query;
+
+typedef struct orbfe_cand {
+  int32_t idx;   /* frame keypoint index */
+  int32_t dist;  /* Hamming distance to the query descriptor */
+} orbfe_cand;
+
+/* Window query + distances, the data-parallel part of every SearchByProjection
+ * (Frame::GetFeaturesInArea L/src/Frame.cc:341-397 + DescriptorDistance).  HOST pointers in, HOST
+ * results out; synchronous.  For query q writes up to max_cand candidates in the reference's
+ * enumeration order to cand[q*max_cand ..] and their number to n_cand[q] (a count > max_cand signals
+ * truncation).  The stereo gate |u_r - mvuRight| <= radius is applied on the device. */
+int orbfe_proj_candidates(const orbfe_frame_view* frame, const orbfe_query* q, int nq, orbfe_cand* cand,
+                          int32_t* n_cand, int max_cand);
+
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th) (L/src/ORBmatcher.cc:45-128): device window
+ * query + distances, host replay of the order-dependent assignment.  blocked[idx] != 0 <=>
+ * F.mvpMapPoints[idx] has Observations() > 0 on entry (updated).  assigned[idx] = query index written to
+ * F.mvpMapPoints[idx], untouched otherwise.  *n_matches = return value of the reference. */
+int orbfe_search_by_projection_points(const orbfe_frame_view* frame, const orbfe_query* q, int nq, float nnratio,
+                                      uint8_t* blocked, int32_t* assigned, int* n_matches);
+/* SearchByProjection(Frame& cur, const Frame& last, th, bMono) (L/src/ORBmatcher.cc:1247-1383). */
+int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_query* q, int nq,
+                                     int check_orientation, uint8_t* blocked, int32_t* assigned, int* n_matches);
+
+/* Frame::ComputeStereoMatches (L/src/Frame.cc:477-646) for n_pairs stereo frames, DEVICE pointers,
+ * asynchronous.  Left/right keypoints+descriptors as produced by orbfe_extract_batch_device with the
+ * two extractor handles (whose device pyramids are read for the 11x11 SAD refinement).
+ * d_u_right / d_depth: n_pairs x cap floats (-1 = no match). */
+int orbfe_stereo_match_device(orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
+                              const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                              const orbfe_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r,
+                              int cap, float mbf, float mb, float* d_u_right, float* d_depth, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H */

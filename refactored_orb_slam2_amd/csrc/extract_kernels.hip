@@ -1,0 +1,838 @@
+// extract_kernels.hip -- HIP kernels of the ORB extractor for gfx950 (MI355X, wave64).
+//
+// Kernel            replaces (reference file:line, L/ = Source/Libraries/ORB_SLAM2/)
+// copy_level0       copyMakeBorder of the input into mvImagePyramid[0]  L/src/ORBextractor.cc:1061
+// pyr_resize        cv::resize(INTER_LINEAR) chained level to level      L/src/ORBextractor.cc:1054
+// fast_cells        per-cell cv::FAST(th=ini, else th=min) + NMS         L/src/ORBextractor.cc:756-791
+// octree_select     DistributeOctTree + DivideNode                       L/src/ORBextractor.cc:475-731
+// gauss_blur7       GaussianBlur(7x7, sigma 2, REFLECT_101)              L/src/ORBextractor.cc:1017-1019
+// orient_describe   IC_Angle + computeOrbDescriptor + pt*=scale          L/src/ORBextractor.cc:76-146,1028-1035
+//
+// All arithmetic that decides an output bit is integer, or float/double evaluated exactly as the x86-64
+// reference build does (no FMA contraction: this file is compiled with -ffp-contract=off; IEEE divide).
+#include "orbfe_internal.h"
+#include "../../include/orb_pattern_data.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    int t = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Inclusive scan over the 256 threads of a block (thread order = threadIdx.x).  tmp: >= 5 ints of LDS.
+// Returns the inclusive prefix; *total receives the block sum.  Contains two __syncthreads().
+__device__ __forceinline__ int block_incl_scan256(int v, int* tmp, int* total) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1), wid = tid >> 6;
+  int s = wave_incl_scan(v);
+  __syncthreads();  // protect tmp from a previous use
+  if (lane == WAVE - 1) tmp[wid] = s;
+  __syncthreads();
+  int off = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int t = tmp[i];
+    if (i < wid) off += t;
+  }
+  *total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  return s + off;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------ level 0
+// Copies the caller's images (arbitrary stride/alignment) into the pitched, 256-byte aligned level-0 planes.
+__global__ __launch_bounds__(256) void copy_level0_kernel(const uint8_t* __restrict__ src, int sstride,
+                                                           unsigned long long simg, uint8_t* __restrict__ dst,
+                                                           int dpitch, unsigned long long dimg, int w, int h) {
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (x4 >= w || y >= h) return;
+  const uint8_t* S = src + (size_t)blockIdx.z * simg + (size_t)y * sstride;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int x = x4 + i < w ? x4 + i : w - 1;
+    out |= (uint32_t)S[x] << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------ resize
+// cv::resize INTER_LINEAR 8UC1, fixed point: horizontal taps sum 2048 (int32 row), vertical
+// ((b*(T>>4))>>16 summed, +2, >>2).  4 destination pixels per thread, one dword store.
+__global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restrict__ src, int spitch,
+                                                          unsigned long long simg, uint8_t* __restrict__ dst,
+                                                          int dpitch, unsigned long long dimg, int dw, int dh,
+                                                          const ResizeTap* __restrict__ xt,
+                                                          const ResizeTap* __restrict__ yt) {
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (x4 >= dw || y >= dh) return;
+  const uint8_t* S = src + (size_t)blockIdx.z * simg;
+  const ResizeTap ty = yt[y];
+  const uint8_t* S0 = S + (size_t)ty.s0 * spitch;
+  const uint8_t* S1 = S + (size_t)ty.s1 * spitch;
+  const int b0 = ty.c0, b1 = ty.c1;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int dx = x4 + i < dw ? x4 + i : dw - 1;
+    const ResizeTap tx = xt[dx];
+    const int t0 = S0[tx.s0] * tx.c0 + S0[tx.s1] * tx.c1;
+    const int t1 = S1[tx.s0] * tx.c0 + S1[tx.s1] * tx.c1;
+    const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+    out |= (uint32_t)(v & 0xff) << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------ FAST
+// ring offsets of FAST-9/16 (OpenCV makeOffsets, patternSize 16)
+__device__ constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__device__ constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// true iff the 16-bit circular mask holds >= 9 contiguous ones
+__device__ __forceinline__ bool ring_has9(uint32_t m) {
+  m |= m << 16;
+  uint32_t a = m & (m >> 1);
+  uint32_t b = a & (a >> 2);
+  uint32_t c = b & (b >> 4);
+  uint32_t d = c & (m >> 8);
+  return (d & 0xffffu) != 0;
+}
+
+// cornerScore<16>: (largest t at which the pixel is still a corner) = max over the sixteen 9-arcs of the arc
+// minimum of (v-p), and of (p-v), larger of the two, minus 1.
+__device__ __forceinline__ int corner_score16(const int d[16]) {
+  int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo2[i] = min(d[i], d[(i + 1) & 15]);
+    hi2[i] = max(d[i], d[(i + 1) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
+    hi4[i] = max(hi2[i], hi2[(i + 2) & 15]);
+  }
+  int A = -1000, B = 1000;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+    int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+    A = max(A, lo9);   // dark arc:   all (v - p) >= lo9
+    B = min(B, hi9);   // bright arc: all (p - v) >= -hi9
+  }
+  return max(A, -B) - 1;
+}
+
+// One workgroup per (cell, image).  Stages the cell ROI in LDS, finds FAST corners at min_th, scores them,
+// applies 3x3 strict NMS inside the cell's tested region, then emits the th=ini survivors if there are any,
+// else all survivors, in row-major order (== cv::FAST(ini) else cv::FAST(min) of the reference).
+__global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
+                                                          int total_cells, int32_t* __restrict__ cell_cnt,
+                                                          uint32_t* __restrict__ slots,
+                                                          unsigned long long slots_per_image, int ini_th,
+                                                          int min_th) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[ORBFE_CELL_MAX * ORBFE_TILE_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sc[ORBFE_CELL_MAX * ORBFE_TILE_PITCH];
+  __shared__ uint16_t clist[(ORBFE_CELL_MAX - 6) * (ORBFE_CELL_MAX - 6)];
+  __shared__ int nlist;
+  __shared__ int scan_tmp[8];
+
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y;
+  const CellDesc cd = cells[blockIdx.x];
+  const int lvl = cd.level;
+  const int pitch = pyr.pitch[lvl];
+  const uint8_t* plane = pyr.base[lvl] + (size_t)img * pyr.img_stride[lvl];
+  const int cols = cd.cols, rows = cd.rows;
+  const int ax = cd.x0 & ~3, xo = cd.x0 & 3;
+  const int ndw = (xo + cols + 3) >> 2;
+
+  if (tid == 0) nlist = 0;
+  // stage ROI (aligned dwords) and clear the score plane
+  {
+    uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
+    uint32_t* s32 = reinterpret_cast<uint32_t*>(sc);
+    const int total = rows * ndw;
+    for (int i = tid; i < total; i += 256) {
+      int r = (int)((i + 0.5f) / (float)ndw);
+      int c = i - r * ndw;
+      t32[r * (ORBFE_TILE_PITCH / 4) + c] =
+          *reinterpret_cast<const uint32_t*>(plane + (size_t)(cd.y0 + r) * pitch + ax + 4 * c);
+    }
+    for (int i = tid; i < rows * (ORBFE_TILE_PITCH / 4); i += 256) s32[i] = 0;
+  }
+  __syncthreads();
+
+  const int tw = cols - 6, th = rows - 6;  // tested region [3, cols-3) x [3, rows-3)
+  const int npix = (tw > 0 && th > 0) ? tw * th : 0;
+  const uint8_t* T = tile + xo;
+
+  // pass A1: corner test at min_th, compact corner pixels into clist
+  for (int p = tid; p < npix; p += 256) {
+    const int ty = (int)((p + 0.5f) / (float)tw);
+    const int tx = p - ty * tw;
+    const int x = tx + 3, y = ty + 3;
+    const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
+    const int v = c[0];
+    const int lo = v - min_th, hi = v + min_th;
+    uint32_t dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int q = c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
+      dark |= (uint32_t)(q < lo) << k;
+      bright |= (uint32_t)(q > hi) << k;
+    }
+    if (ring_has9(dark) || ring_has9(bright)) {
+      int idx = atomicAdd(&nlist, 1);
+      clist[idx] = (uint16_t)((y << 8) | x);
+    }
+  }
+  __syncthreads();
+
+  // pass A2: score the corners (dense over the compacted list)
+  const int nl = nlist;
+  for (int i = tid; i < nl; i += 256) {
+    const int e = clist[i];
+    const int x = e & 0xff, y = e >> 8;
+    const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
+    const int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - (int)c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
+    sc[y * ORBFE_TILE_PITCH + x] = (uint8_t)corner_score16(d);
+  }
+  __syncthreads();
+
+  // pass B: NMS + ordered compaction.  Thread t owns the row-major pixel range [t*K, (t+1)*K).
+  const int K = (npix + 255) >> 8;
+  uint32_t surv = 0, survhi = 0;
+  const int p0 = tid * K;
+  int ty0 = 0, tx0 = 0;
+  if (p0 < npix) {
+    ty0 = (int)((p0 + 0.5f) / (float)tw);
+    tx0 = p0 - ty0 * tw;
+  }
+  {
+    int tx = tx0, ty = ty0;
+    for (int i = 0; i < K && p0 + i < npix; i++) {
+      const uint8_t* s = sc + (ty + 3) * ORBFE_TILE_PITCH + (tx + 3);
+      const int v = s[0];
+      if (v > 0) {
+        const bool keep = v > s[-1] && v > s[1] && v > s[-ORBFE_TILE_PITCH - 1] && v > s[-ORBFE_TILE_PITCH] &&
+                          v > s[-ORBFE_TILE_PITCH + 1] && v > s[ORBFE_TILE_PITCH - 1] && v > s[ORBFE_TILE_PITCH] &&
+                          v > s[ORBFE_TILE_PITCH + 1];
+        if (keep) {
+          surv |= 1u << i;
+          if (v >= ini_th) survhi |= 1u << i;
+        }
+      }
+      if (++tx == tw) { tx = 0; ty++; }
+    }
+  }
+  int total;
+  const int packed = (__popc(survhi) << 16) | __popc(surv);
+  const int incl = block_incl_scan256(packed, scan_tmp, &total);
+  const int excl = incl - packed;
+  const bool use_hi = (total >> 16) != 0;
+  const uint32_t mask = use_hi ? survhi : surv;
+  int off = use_hi ? (excl >> 16) : (excl & 0xffff);
+  const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
+  uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
+  if (mask) {
+    int tx = tx0, ty = ty0;
+    for (int i = 0; i < K; i++) {
+      if (mask & (1u << i)) {
+        const int x = tx + 3, y = ty + 3;
+        const uint32_t s = sc[y * ORBFE_TILE_PITCH + x];
+        const uint32_t rx = (uint32_t)(x + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(y + cd.y0 - ORBFE_EDGE);
+        if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (s << 24);
+        off++;
+      }
+      if (++tx == tw) { tx = 0; ty++; }
+    }
+  }
+  if (tid == 0) cell_cnt[(size_t)img * total_cells + blockIdx.x] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
+}
+
+// ------------------------------------------------------------------------------------------------ octree
+// DistributeOctTree as an array algorithm.  The leaves of the quadtree are kept in an array in std::list
+// order (index 0 = list head); because every insertion in the reference is a push_front and the initial
+// nodes are push_back'ed, list order == descending creation order, so "sort by (size, node address)" with
+// a bump allocator == sort by (size, -position).  One iteration = count keys per (leaf, quadrant), prefix
+// sums over leaves, rebuild the array, relabel keys.  Keys never move.
+//
+// key record (8 bytes): x:int16 | y:int16 | node:uint16 | score:uint8 | quadrant:uint8
+__device__ __forceinline__ unsigned long long key_pack(int x, int y, int node, int score, int q) {
+  return (unsigned long long)(uint16_t)x | ((unsigned long long)(uint16_t)y << 16) |
+         ((unsigned long long)(uint16_t)node << 32) | ((unsigned long long)(uint8_t)score << 48) |
+         ((unsigned long long)(uint8_t)q << 56);
+}
+#define KEY_X(k) ((int)(int16_t)((k) & 0xffff))
+#define KEY_Y(k) ((int)(int16_t)(((k) >> 16) & 0xffff))
+#define KEY_NODE(k) ((int)(((k) >> 32) & 0xffff))
+#define KEY_SCORE(k) ((int)(((k) >> 48) & 0xff))
+#define KEY_Q(k) ((int)(((k) >> 56) & 0xff))
+
+struct OctNode {
+  int16_t x0, x1, y0, y1;
+  int32_t cnt;
+};
+
+size_t orbfe_octree_lds_bytes(int M, int lds_keys) {
+  // nodeA, nodeB (12 B), cnt4 (16 B), childpos (8 B: 4 x uint16), aux (4 B), aux2 (4 B), sortkey (8 B), sorted (8 B)
+  return (size_t)M * (12 + 12 + 16 + 8 + 4 + 4 + 8 + 8) + (size_t)lds_keys * 8 + 64 * 4 + ORBFE_MAX_INI * 8 + 256;
+}
+
+__global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int level = blockIdx.x, img = blockIdx.y;
+  const OctLevel L = P.lv[level];
+  const int M = P.max_nodes;
+
+  // carve dynamic LDS
+  uint8_t* sp = smem;
+  unsigned long long* sortkey = reinterpret_cast<unsigned long long*>(sp); sp += (size_t)M * 8;
+  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(sp);  sp += (size_t)M * 8;
+  unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(sp);   sp += (size_t)P.lds_keys * 8;
+  OctNode* nodeA = reinterpret_cast<OctNode*>(sp); sp += (size_t)M * 12;
+  OctNode* nodeB = reinterpret_cast<OctNode*>(sp); sp += (size_t)M * 12;
+  int* cnt4 = reinterpret_cast<int*>(sp);          sp += (size_t)M * 16;
+  uint16_t* childpos = reinterpret_cast<uint16_t*>(sp); sp += (size_t)M * 8;
+  int* aux = reinterpret_cast<int*>(sp);           sp += (size_t)M * 4;   // childbase / flags
+  int* aux2 = reinterpret_cast<int*>(sp);          sp += (size_t)M * 4;   // staypos
+  int* ini_cnt = reinterpret_cast<int*>(sp);       sp += ORBFE_MAX_INI * 4;
+  int* ini_map = reinterpret_cast<int*>(sp);       sp += ORBFE_MAX_INI * 4;
+  int* scan_tmp = reinterpret_cast<int*>(sp);      sp += 16 * 4;
+  int* sh = reinterpret_cast<int*>(sp);            // small shared scalars
+
+  const int32_t* cnt = P.cell_cnt + (size_t)img * P.total_cells + L.cell_begin;
+  int32_t* coff = P.cell_off + (size_t)img * P.total_cells + L.cell_begin;
+  const CellDesc* cells = P.cells + L.cell_begin;
+  const uint32_t* slots = P.slots + (size_t)img * P.slots_per_image;
+  uint32_t* out_kp = P.lvl_kp + (size_t)img * P.kp_per_image + L.kp_off;
+
+  // 1. exclusive offsets of the cells' candidate lists (cell raster order == vToDistributeKeys order)
+  int running = 0;
+  for (int base = 0; base < L.n_cells; base += 256) {
+    const int c = base + tid;
+    const int v = c < L.n_cells ? cnt[c] : 0;
+    int tot;
+    const int incl = block_incl_scan256(v, scan_tmp, &tot);
+    if (c < L.n_cells) coff[c] = running + incl - v;
+    running += tot;
+  }
+  const int C = running;
+  if (C > L.key_cap || C > 0xFFFFFF) {  // cannot happen: key_cap = sum of slot caps
+    if (tid == 0) { atomicOr(P.err, 1); P.lvl_n[(size_t)img * P.n_levels + level] = 0; }
+    return;
+  }
+  unsigned long long* keys = (C <= P.lds_keys) ? lkeys : (P.gkeys + (size_t)img * P.gkeys_per_image + L.key_off);
+
+  for (int i = tid; i < L.n_ini; i += 256) ini_cnt[i] = 0;
+  __syncthreads();
+
+  // 2. gather keys, assign to the root nodes: vpIniNodes[kp.pt.x / hX] (L/src/ORBextractor.cc:559)
+  for (int c = tid; c < L.n_cells; c += 256) {
+    const int n = cnt[c];
+    const int o = coff[c];
+    const uint32_t* src = slots + cells[c].slot_off;
+    for (int j = 0; j < n; j++) {
+      const uint32_t e = src[j];
+      const int x = e & 0xfff, y = (e >> 12) & 0xfff, s = e >> 24;
+      int node = (int)((float)x / L.hX);
+      if (node >= L.n_ini) node = L.n_ini - 1;
+      keys[o + j] = key_pack(x, y, node, s, 0);
+      atomicAdd(&ini_cnt[node], 1);
+    }
+  }
+  __syncthreads();
+
+  // 3. root nodes that hold keys, in order (empty ones are erased, :564-572)
+  int size;
+  {
+    const int has = (tid < L.n_ini && ini_cnt[tid] > 0) ? 1 : 0;
+    int tot;
+    const int incl = block_incl_scan256(has, scan_tmp, &tot);
+    if (tid < L.n_ini) {
+      ini_map[tid] = incl - has;
+      if (has) {
+        OctNode nd;
+        nd.x0 = (int16_t)(int)(L.hX * (float)tid);
+        nd.x1 = (int16_t)(int)(L.hX * (float)(tid + 1));
+        nd.y0 = 0;
+        nd.y1 = (int16_t)L.height;
+        nd.cnt = ini_cnt[tid];
+        nodeA[incl - 1] = nd;
+      }
+    }
+    size = tot;
+  }
+  __syncthreads();
+  for (int k = tid; k < C; k += 256) {
+    unsigned long long kk = keys[k];
+    const int nn = ini_map[KEY_NODE(kk)];
+    keys[k] = (kk & ~(0xffffULL << 32)) | ((unsigned long long)(uint16_t)nn << 32);
+  }
+  __syncthreads();
+
+  // 4. subdivision loop (:581-709)
+  int phase = 1;
+  bool finish = (size == 0);
+  const int N = L.N;
+  while (!finish) {
+    const int prev = size;
+    for (int i = tid; i < size * 4; i += 256) cnt4[i] = 0;
+    __syncthreads();
+    // keys -> quadrant counts of their leaf (DivideNode :505-517)
+    for (int k = tid; k < C; k += 256) {
+      unsigned long long kk = keys[k];
+      const int p = KEY_NODE(kk);
+      const OctNode nd = nodeA[p];
+      if (nd.cnt > 1) {
+        const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);  // UL.x + ceil(w/2)
+        const int my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+        const int q = (KEY_X(kk) >= mx ? 1 : 0) + (KEY_Y(kk) >= my ? 2 : 0);  // 0:n1 1:n2 2:n3 3:n4
+        atomicAdd(&cnt4[p * 4 + q], 1);
+        keys[k] = (kk & ~(0xffULL << 56)) | ((unsigned long long)q << 56);
+      }
+    }
+    __syncthreads();
+
+    // which leaves split, and in which order their children are created
+    int K = 0;        // number of children created
+    int nsplit = 0;
+    if (phase == 1) {
+      // every multi-key leaf splits, in list order (:592-643)
+      int run = 0;
+      for (int base = 0; base < size; base += 256) {
+        const int p = base + tid;
+        int c = 0;
+        if (p < size && nodeA[p].cnt > 1)
+          c = (cnt4[p * 4] > 0) + (cnt4[p * 4 + 1] > 0) + (cnt4[p * 4 + 2] > 0) + (cnt4[p * 4 + 3] > 0);
+        int tot;
+        const int incl = block_incl_scan256(c, scan_tmp, &tot);
+        if (p < size) aux[p] = c > 0 ? run + incl - c : -1;  // childbase, -1 = stays
+        run += tot;
+      }
+      K = run;
+    } else {
+      // phase 2 (:651-707): expandable leaves sorted by (size, address) ascending, walked from the back:
+      // larger first, among equal sizes the later-created (= smaller list position) first; stop as soon as
+      // the list holds >= N nodes.
+      int nE = 0;
+      for (int base = 0; base < size; base += 256) {
+        const int p = base + tid;
+        const int e = (p < size && nodeA[p].cnt > 1) ? 1 : 0;
+        int tot;
+        const int incl = block_incl_scan256(e, scan_tmp, &tot);
+        if (e) sortkey[nE + incl - 1] = ((unsigned long long)(0xFFFFFFFFu - (uint32_t)nodeA[p].cnt) << 32) | (uint32_t)p;
+        if (p < size) aux[p] = -1;
+        nE += tot;
+      }
+      __syncthreads();
+      // rank sort (keys are unique)
+      for (int i = tid; i < nE; i += 256) {
+        const unsigned long long mine = sortkey[i];
+        int r = 0;
+        for (int j = 0; j < nE; j++) r += (sortkey[j] < mine) ? 1 : 0;
+        sorted[r] = mine;
+      }
+      __syncthreads();
+      // walk in sorted order: running list size after each split; first rank reaching N ends the walk
+      if (tid == 0) sh[0] = nE;  // index of the last split rank + 1
+      int run_inc = 0, run_c = 0;
+      for (int base = 0; base < nE; base += 256) {
+        const int r = base + tid;
+        int c = 0, p = 0;
+        if (r < nE) {
+          p = (int)(sorted[r] & 0xffffffffu);
+          c = (cnt4[p * 4] > 0) + (cnt4[p * 4 + 1] > 0) + (cnt4[p * 4 + 2] > 0) + (cnt4[p * 4 + 3] > 0);
+        }
+        int tot;
+        const int packed = ((c > 0 ? c - 1 : 0) << 16) | c;
+        const int incl = block_incl_scan256(packed, scan_tmp, &tot);
+        if (r < nE) {
+          const int size_after = prev + run_inc + (incl >> 16);
+          aux2[r] = run_c + (incl & 0xffff) - c;  // childbase by rank (temporarily in aux2)
+          if (size_after >= N) atomicMin(&sh[0], r + 1);
+        }
+        run_inc += tot >> 16;
+        run_c += tot & 0xffff;
+        __syncthreads();
+      }
+      __syncthreads();
+      nsplit = sh[0];
+      __syncthreads();
+      if (tid == 0) sh[1] = 0;
+      __syncthreads();
+      for (int r = tid; r < nsplit; r += 256) {
+        const int p = (int)(sorted[r] & 0xffffffffu);
+        aux[p] = aux2[r];
+        if (r == nsplit - 1) {
+          const int c = (cnt4[p * 4] > 0) + (cnt4[p * 4 + 1] > 0) + (cnt4[p * 4 + 2] > 0) + (cnt4[p * 4 + 3] > 0);
+          sh[1] = aux2[r] + c;
+        }
+      }
+      __syncthreads();
+      K = sh[1];
+    }
+    __syncthreads();
+
+    // positions of the leaves that stay: after the K new children, old order preserved
+    int S = 0;
+    for (int base = 0; base < size; base += 256) {
+      const int p = base + tid;
+      const int st = (p < size && aux[p] < 0) ? 1 : 0;
+      int tot;
+      const int incl = block_incl_scan256(st, scan_tmp, &tot);
+      if (st) aux2[p] = K + S + incl - 1;
+      S += tot;
+    }
+    const int newsize = K + S;
+    if (newsize > M) {  // cannot happen: M >= max(N + 3, 4 * nIni)
+      if (tid == 0) { atomicOr(P.err, 2); P.lvl_n[(size_t)img * P.n_levels + level] = 0; }
+      return;
+    }
+    __syncthreads();
+    // build the new leaf array: children pushed to the front in creation order => reversed
+    for (int p = tid; p < size; p += 256) {
+      const OctNode nd = nodeA[p];
+      if (aux[p] >= 0) {
+        const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+        const int my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+        int j = aux[p];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int cq = cnt4[p * 4 + q];
+          if (cq > 0) {
+            OctNode ch;
+            ch.x0 = (q & 1) ? (int16_t)mx : nd.x0;
+            ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
+            ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
+            ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
+            ch.cnt = cq;
+            const int pos = K - 1 - j;
+            nodeB[pos] = ch;
+            childpos[p * 4 + q] = (uint16_t)pos;
+            j++;
+          }
+        }
+      } else {
+        nodeB[aux2[p]] = nd;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < C; k += 256) {
+      unsigned long long kk = keys[k];
+      const int p = KEY_NODE(kk);
+      const int np = aux[p] >= 0 ? (int)childpos[p * 4 + KEY_Q(kk)] : aux2[p];
+      keys[k] = (kk & ~(0xffffULL << 32)) | ((unsigned long long)(uint16_t)np << 32);
+    }
+    { OctNode* t = nodeA; nodeA = nodeB; nodeB = t; }
+    size = newsize;
+    __syncthreads();
+
+    if (phase == 1) {
+      // nToExpand = leaves with more than one key (all of them are new children)
+      int ne = 0;
+      for (int p = tid; p < size; p += 256) ne += nodeA[p].cnt > 1 ? 1 : 0;
+      int tot;
+      block_incl_scan256(ne, scan_tmp, &tot);
+      if (size >= N || size == prev) finish = true;
+      else if (size + 3 * tot > N) phase = 2;
+    } else {
+      if (size >= N || size == prev) finish = true;
+    }
+    __syncthreads();
+  }
+
+  // 5. best key of every leaf: max response, first candidate wins ties (:712-728)
+  uint32_t* best = reinterpret_cast<uint32_t*>(cnt4);
+  for (int p = tid; p < size; p += 256) best[p] = 0;
+  __syncthreads();
+  for (int k = tid; k < C; k += 256) {
+    const unsigned long long kk = keys[k];
+    atomicMax(&best[KEY_NODE(kk)], ((uint32_t)KEY_SCORE(kk) << 24) | (0xFFFFFFu - (uint32_t)k));
+  }
+  __syncthreads();
+  for (int p = tid; p < size; p += 256) {
+    const int k = (int)(0xFFFFFFu - (best[p] & 0xFFFFFFu));
+    const unsigned long long kk = keys[k];
+    if (p < L.kp_cap)
+      out_kp[p] = (uint32_t)KEY_X(kk) | ((uint32_t)KEY_Y(kk) << 12) | ((uint32_t)KEY_SCORE(kk) << 24);
+  }
+  if (tid == 0) {
+    if (size > L.kp_cap) atomicOr(P.err, 4);
+    P.lvl_n[(size_t)img * P.n_levels + level] = size < L.kp_cap ? size : L.kp_cap;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ blur
+// 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps, exact 16.16 accumulation, round half up.
+// One 64x16 output tile per workgroup, separable through LDS; 4 outputs per thread, one dword store.
+__global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles) {
+  __shared__ uint8_t in[22][72];
+  __shared__ uint16_t hb[22][64];
+  const int tid = threadIdx.x;
+  const BlurTile t = tiles[blockIdx.x];
+  const int lvl = t.level;
+  const int w = src.w[lvl], h = src.h[lvl], pitch = src.pitch[lvl];
+  const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
+  uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
+  const int ox = t.tx * 64, oy = t.ty * 16;
+  for (int i = tid; i < 22 * 70; i += 256) {
+    const int r = i / 70, c = i - r * 70;
+    const int gy = reflect101(oy + r - 3, h), gx = reflect101(ox + c - 3, w);
+    in[r][c] = S[(size_t)gy * pitch + gx];
+  }
+  __syncthreads();
+  for (int i = tid; i < 22 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const uint8_t* p = &in[r][c];
+    hb[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const int gy = oy + r, gx = ox + c4;
+    if (gy < h && gx < w) {
+      uint32_t out = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int c = c4 + i;
+        const uint32_t acc = 18u * (hb[r][c] + hb[r + 6][c]) + 34u * (hb[r + 1][c] + hb[r + 5][c]) +
+                             48u * (hb[r + 2][c] + hb[r + 4][c]) + 56u * hb[r + 3][c];
+        out |= ((acc + 32768u) >> 16) << (8 * i);
+      }
+      *reinterpret_cast<uint32_t*>(D + (size_t)gy * dst.pitch[lvl] + gx) = out;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ describe
+__device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {ORB_PATTERN_INT8_1024};
+// umax of ORBextractor's constructor for HALF_PATCH_SIZE 15 (L/src/ORBextractor.cc:449-463)
+__device__ constexpr int UMAX[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// cv::fastAtan2 (degrees), scalar OpenCV path, float, un-fused
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * scale;
+  const float p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale;
+  const float p7 = -0.04432655554792128f * scale;
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// glibc 2.35 sinf/cosf (flt-32/s_sincosf.h) restated: double reduction by pi/2, two double polynomials,
+// one rounding to float.  Valid for |x| < 120 (angles here are in [0, 2*pi]).
+__device__ __forceinline__ float sc_poly(double x, double x2, int n, bool flip) {
+  const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+               C4 = 0x1.99343027bf8c3p-16;
+  const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  if ((n & 1) == 0) {
+    const double x3 = x * x2;
+    const double s1 = S2 + x2 * S3;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * S1;
+    return (float)(s + x7 * s1);
+  } else {
+    const double sg = flip ? -1.0 : 1.0;
+    const double x4 = x2 * x2;
+    const double c2 = sg * C3 + x2 * (sg * C4);
+    const double c1 = sg * C1 + x2 * (sg * C2);
+    const double x6 = x4 * x2;
+    const double c = sg * C0 + x2 * c1;
+    return (float)(c + x6 * c2);
+  }
+}
+__device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
+  double x = (double)y;
+  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+  if (top < 0x3f4) {  // |y| < pi/4  (abstop12(0x1.921FB6p-1f) = 0x3f4)
+    const double x2 = x * x;
+    if (top < 0x398) {  // |y| < 2^-12
+      *sn = y;
+      *cs = 1.0f;
+      return;
+    }
+    *sn = sc_poly(x, x2, 0, false);
+    *cs = sc_poly(x, x2, 1, false);
+    return;
+  }
+  const double r = x * 0x1.45F306DC9C883p+23;
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  x = x - (double)n * 0x1.921FB54442D18p0;
+  const double s = ((n + 1) & 2) ? -1.0 : 1.0;  // sign table {1,-1,-1,1}[n&3]
+  const bool flip = (n & 2) != 0;
+  const double xs = x * s, x2 = x * x;
+  *sn = sc_poly(xs, x2, n, flip);
+  *cs = sc_poly(xs, x2, n ^ 1, flip);
+}
+
+// One wave per keypoint slot.  IC_Angle on the un-blurred level, steered BRIEF on the blurred level,
+// 4 x __ballot -> 256 bits; writes the cv::KeyPoint record (pt scaled to level-0 pixels) and 32 bytes.
+__global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.y;
+  const int32_t* ln = P.lvl_n + (size_t)img * P.n_levels;
+  if (slot == 0 && lane == 0) {
+    int tot = 0;
+    for (int l = 0; l < P.n_levels; l++) tot += ln[l];
+    P.out_n[img] = tot;
+  }
+  if (slot >= P.kp_per_image) return;
+  int level = 0;
+  while (level + 1 < P.n_levels && slot >= P.kp_off[level + 1]) level++;
+  const int idx = slot - P.kp_off[level];
+  if (idx >= ln[level]) return;
+  int out = idx;
+  for (int l = 0; l < level; l++) out += ln[l];
+  if (out >= P.cap) return;
+
+  const uint32_t e = P.lvl_kp[(size_t)img * P.kp_per_image + slot];
+  const int cx = (int)(e & 0xfff) + ORBFE_EDGE, cy = (int)((e >> 12) & 0xfff) + ORBFE_EDGE;
+  const int score = (int)(e >> 24);
+
+  // --- IC_Angle (L/src/ORBextractor.cc:76-100): two rows per step, lanes 0-31 / 32-63
+  const int pitch = P.pyr.pitch[level];
+  const uint8_t* center = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level] + (size_t)cy * pitch + cx;
+  int m10 = 0, m01 = 0;
+  const int u = (lane & 31) - 15;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int v = -15 + 2 * i + (lane >> 5);
+    if (v <= 15 && (lane & 31) < 31) {
+      const int av = v < 0 ? -v : v;
+      const int au = u < 0 ? -u : u;
+      if (au <= UMAX[av]) {
+        const int val = center[v * pitch + u];
+        m10 += u * val;
+        m01 += v * val;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m10 += __shfl_xor(m10, d, WAVE);
+    m01 += __shfl_xor(m01, d, WAVE);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // --- computeOrbDescriptor (L/src/ORBextractor.cc:103-146)
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  const float arad = angle * factorPI;
+  float a, b;
+  glibc_sincosf(arad, &b, &a);
+  const int bpitch = P.blur.pitch[level];
+  const uint8_t* bc = P.blur.base[level] + (size_t)img * P.blur.img_stride[level] + (size_t)cy * bpitch + cx;
+  uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int pi = r * 64 + lane;
+    const int pk = *reinterpret_cast<const int*>(&g_pattern[pi * 4]);
+    const float x0 = (float)(int8_t)(pk & 0xff), y0 = (float)(int8_t)((pk >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pk >> 16) & 0xff), y1 = (float)(int8_t)((pk >> 24) & 0xff);
+    const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
+    const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
+    const int t0 = bc[ry0 * bpitch + rx0];
+    const int t1 = bc[ry1 * bpitch + rx1];
+    const unsigned long long bits = __ballot(t0 < t1);
+    if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = bits;
+  }
+
+  // --- keypoint record
+  if (lane < 7) {
+    float fx = (float)cx, fy = (float)cy;
+    if (level != 0) {
+      fx *= P.scale[level];
+      fy *= P.scale[level];
+    }
+    uint32_t wv;
+    switch (lane) {
+      case 0: wv = __float_as_uint(fx); break;
+      case 1: wv = __float_as_uint(fy); break;
+      case 2: wv = __float_as_uint(P.kp_size[level]); break;
+      case 3: wv = __float_as_uint(angle); break;
+      case 4: wv = __float_as_uint((float)score); break;
+      case 5: wv = (uint32_t)level; break;
+      default: wv = 0xFFFFFFFFu; break;
+    }
+    reinterpret_cast<uint32_t*>(P.out_kps + (size_t)img * P.cap + out)[lane] = wv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
+                        int h, int n_images, hipStream_t s) {
+  dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4, n_images);
+  hipLaunchKernelGGL(copy_level0_kernel, grid, block, 0, s, src, sstride, (unsigned long long)simg, dst, dpitch,
+                     (unsigned long long)dimg, w, h);
+}
+
+void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
+                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, hipStream_t s) {
+  dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
+  hipLaunchKernelGGL(pyr_resize_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
+                     (unsigned long long)dimg, dw, dh, xt, yt);
+}
+
+void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
+                       unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s) {
+  if (total_cells == 0) return;
+  dim3 block(256), grid(total_cells, n_images);
+  hipLaunchKernelGGL(fast_cells_kernel, grid, block, 0, s, pyr, cells, total_cells, cell_cnt, slots, slots_per_image,
+                     ini_th, min_th);
+}
+
+void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s) {
+  dim3 block(ORBFE_OCT_THREADS), grid(p.n_levels, n_images);
+  hipLaunchKernelGGL(octree_select_kernel, grid, block, lds_bytes, s, p);
+}
+
+void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
+                       hipStream_t s) {
+  dim3 block(256), grid(n_tiles, n_images);
+  hipLaunchKernelGGL(gauss_blur7_kernel, grid, block, 0, s, src, dst, tiles);
+}
+
+void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
+  dim3 block(256), grid((p.kp_per_image + 3) / 4 > 0 ? (p.kp_per_image + 3) / 4 : 1, n_images);
+  hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, p);
+}
+
+int orbfe_set_octree_lds(size_t lds_bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(octree_select_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}

@@ -1,0 +1,803 @@
+// extractor.cpp -- host side of liborbfe's ORBextractor path: parameter tables, geometry plan, HBM work
+// space, kernel sequencing, and the C ABI of include/orbfe.h.  No CPU fallback exists: every compute
+// entry point needs a HIP device.
+//
+// Reference behaviour restated here (L/ = Source/Libraries/ORB_SLAM2/):
+//   constructor tables          L/src/ORBextractor.cc:407-464
+//   level sizes                 L/src/ORBextractor.cc:1043-1045
+//   FAST cell geometry          L/src/ORBextractor.cc:740-771
+//   DistributeOctTree set-up    L/src/ORBextractor.cc:535-537
+//   resize coefficient set-up   cv::resize (OpenCV 4.5 imgproc/src/resize.cpp), see SURVEY.md §8(c)-P2
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "orbfe_internal.h"
+
+void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
+                        int h, int n_images, hipStream_t s);
+int orbfe_set_octree_lds(size_t lds_bytes);
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void orbfe_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* orbfe_last_error(void) { return g_err; }
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      orbfe_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return ORBFE_ERR_HIP;                                                                       \
+    }                                                                                             \
+  } while (0)
+
+extern "C" int orbfe_device_count(int* count) {
+  if (!count) return ORBFE_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    orbfe_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return ORBFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ handle
+struct LevelGeom {
+  int w, h, pitch;
+  size_t plane;  // bytes of one image's plane (pitch*h rounded to 256)
+  size_t off;    // offset of this level inside the per-level-major pyramid buffer
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct orbfe_extractor {
+  orbfe_params prm{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // constructor tables
+  float scale[ORBFE_MAX_LEVELS]{}, inv_scale[ORBFE_MAX_LEVELS]{}, sigma2[ORBFE_MAX_LEVELS]{}, inv_sigma2[ORBFE_MAX_LEVELS]{};
+  int feat_per_level[ORBFE_MAX_LEVELS]{};
+  // plan (depends on image geometry)
+  int plan_w = 0, plan_h = 0;
+  LevelGeom lg[ORBFE_MAX_LEVELS]{};
+  std::vector<CellDesc> cells;
+  std::vector<BlurTile> tiles;
+  OctLevel oct[ORBFE_MAX_LEVELS]{};
+  int total_cells = 0;
+  size_t slots_per_image = 0, gkeys_per_image = 0;
+  int kp_per_image = 0;
+  int max_nodes = 0, lds_keys = 0;
+  size_t oct_lds = 0;
+  // device tables
+  DevBuf d_cells, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];
+  // work space for `cap_images`
+  int cap_images = 0;
+  DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_off, d_slots, d_gkeys, d_lvl_kp, d_lvl_n, d_err;
+  // host-API outputs
+  DevBuf d_out_kps, d_out_desc, d_out_n;
+  int out_cap = 0;
+  int last_images = 0;
+  // profiling
+  bool profile = false;
+  float stage_ms[ORBFE_STAGE_COUNT]{};
+  int stage_launches[ORBFE_STAGE_COUNT]{};
+  std::vector<hipEvent_t> ev_pool;
+  struct EvPair { int stage; hipEvent_t a, b; };
+  std::vector<EvPair> ev_pending;
+  std::mutex mu;
+};
+
+static int dev_alloc(DevBuf& b, size_t bytes) {
+  if (bytes <= b.bytes && b.p) return ORBFE_OK;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  if (bytes == 0) bytes = 256;
+  HIPCHK(hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return ORBFE_OK;
+}
+static void dev_free(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int16_t sat_short(float v) {
+  int i = cv_round_f(v);
+  return (int16_t)std::min(32767, std::max(-32768, i));
+}
+
+// cv::resize INTER_LINEAR coefficient set-up for one axis.  clamp_edges: the x axis forces fx=0 at the
+// borders (sx<0, sx>=ssize-1); the y axis only clamps the row index when rows are read.
+static void build_taps(int s, int d, bool x_axis, std::vector<ResizeTap>& out) {
+  out.resize(d);
+  const double scale = 1.0 / ((double)d / (double)s);
+  for (int i = 0; i < d; i++) {
+    float f = (float)((i + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= si;
+    if (x_axis) {
+      if (si < 0) { f = 0; si = 0; }
+      if (si >= s - 1) { f = 0; si = s - 1; }
+    }
+    ResizeTap t;
+    int s0 = si, s1 = si + 1;
+    s0 = std::min(std::max(s0, 0), s - 1);
+    s1 = std::min(std::max(s1, 0), s - 1);
+    t.s0 = (int16_t)s0;
+    t.s1 = (int16_t)s1;
+    t.c0 = sat_short((1.f - f) * 2048);
+    t.c1 = sat_short(f * 2048);
+    out[i] = t;
+  }
+}
+
+static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
+  int rc = dev_alloc(b, bytes);
+  if (rc) return rc;
+  if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+  return ORBFE_OK;
+}
+
+// Builds everything that depends on the image size.
+static int build_plan(orbfe_extractor* e, int w, int h) {
+  if (e->plan_w == w && e->plan_h == h) return ORBFE_OK;
+  if (w < 1 || h < 1 || w > 4095 || h > 4095) {
+    orbfe_set_error("unsupported image size %dx%d (1..4095)", w, h);
+    return ORBFE_ERR_INVALID;
+  }
+  const int nl = e->prm.n_levels;
+  size_t off = 0;
+  for (int l = 0; l < nl; l++) {
+    LevelGeom& g = e->lg[l];
+    g.w = cv_round_f((float)w * e->inv_scale[l]);  // L/src/ORBextractor.cc:1044-1045
+    g.h = cv_round_f((float)h * e->inv_scale[l]);
+    if (g.w < 1 || g.h < 1) {
+      orbfe_set_error("pyramid level %d of a %dx%d image is empty", l, w, h);
+      return ORBFE_ERR_INVALID;
+    }
+    g.pitch = (g.w + 63) & ~63;
+    g.plane = ((size_t)g.pitch * g.h + 255) & ~(size_t)255;
+    g.off = off;  // per-image offsets; the buffer is level-major: level block = plane * cap_images
+    off += g.plane;
+  }
+  // FAST cells and octree levels
+  e->cells.clear();
+  e->tiles.clear();
+  size_t slot_off = 0, key_off = 0;
+  int kp_off = 0, maxM = 0;
+  for (int l = 0; l < nl; l++) {
+    const LevelGeom& g = e->lg[l];
+    OctLevel& o = e->oct[l];
+    memset(&o, 0, sizeof(o));
+    o.cell_begin = (int)e->cells.size();
+    o.N = e->feat_per_level[l];
+    const int minB = ORBFE_EDGE;
+    const int maxBX = g.w - ORBFE_EDGE, maxBY = g.h - ORBFE_EDGE;
+    const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+    const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+    o.n_ini = 1;
+    o.hX = 1.f;
+    o.width = std::max(maxBX - minB, 0);
+    o.height = std::max(maxBY - minB, 0);
+    size_t level_slots = 0;
+    if (nCols >= 1 && nRows >= 1) {  // the reference would divide by zero otherwise (:753-754)
+      const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minB + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBY - 3) continue;
+        if (maxY > maxBY) maxY = (float)maxBY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = (float)(minB + j * wCell);
+          float maxX = iniX + wCell + 6;
+          if (iniX >= maxBX - 6) continue;
+          if (maxX > maxBX) maxX = (float)maxBX;
+          CellDesc c;
+          c.level = (int16_t)l;
+          c.x0 = (int16_t)iniX;
+          c.y0 = (int16_t)iniY;
+          c.cols = (int16_t)((int)maxX - (int)iniX);
+          c.rows = (int16_t)((int)maxY - (int)iniY);
+          c.shift_x = (int16_t)(j * wCell);
+          c.shift_y = (int16_t)(i * hCell);
+          if (c.cols > ORBFE_CELL_MAX || c.rows > ORBFE_CELL_MAX) {
+            orbfe_set_error("FAST cell %dx%d exceeds the staged maximum %d", c.cols, c.rows, ORBFE_CELL_MAX);
+            return ORBFE_ERR_INVALID;
+          }
+          const int tw = std::max(c.cols - 6, 0), th = std::max(c.rows - 6, 0);
+          const int cap = std::max(((tw + 1) / 2) * ((th + 1) / 2), 1);  // NMS survivors are never 8-adjacent
+          c.slot_cap = (int16_t)cap;
+          c.slot_off = (uint32_t)slot_off;
+          slot_off += cap;
+          level_slots += cap;
+          e->cells.push_back(c);
+        }
+      }
+      const int nIni = (int)roundf(width / height);  // :535
+      if (nIni < 1 || nIni > ORBFE_MAX_INI) {
+        orbfe_set_error("level %d aspect ratio gives nIni=%d (supported 1..%d)", l, nIni, ORBFE_MAX_INI);
+        return ORBFE_ERR_INVALID;
+      }
+      o.n_ini = nIni;
+      o.hX = width / nIni;
+    }
+    o.n_cells = (int)e->cells.size() - o.cell_begin;
+    o.kp_cap = std::max(o.N + 3, 4 * o.n_ini) + 1;
+    o.kp_off = kp_off;
+    kp_off += o.kp_cap;
+    maxM = std::max(maxM, o.kp_cap);
+    o.key_off = key_off;
+    o.key_cap = (int)std::min<size_t>(level_slots, 0xFFFFFF);
+    key_off += level_slots;
+    // blur tiles
+    for (int ty = 0; ty < (g.h + 15) / 16; ty++)
+      for (int tx = 0; tx < (g.w + 63) / 64; tx++) e->tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
+  }
+  e->total_cells = (int)e->cells.size();
+  e->slots_per_image = slot_off;
+  e->gkeys_per_image = key_off;
+  e->kp_per_image = kp_off;
+  e->max_nodes = (maxM + 63) & ~63;
+  if (e->max_nodes > 8192) {
+    orbfe_set_error("nFeatures too large for the octree node table (%d nodes)", e->max_nodes);
+    return ORBFE_ERR_INVALID;
+  }
+  // LDS budget: node tables + as many keys as fit in 64 KiB (more keys spill to HBM, same results)
+  {
+    const size_t fixed = orbfe_octree_lds_bytes(e->max_nodes, 0);
+    const size_t budget = 64 * 1024;
+    e->lds_keys = fixed + 8 * 512 <= budget ? (int)((budget - fixed) / 8) : 512;
+    e->oct_lds = orbfe_octree_lds_bytes(e->max_nodes, e->lds_keys);
+    if (e->oct_lds > 160 * 1024) {
+      orbfe_set_error("octree LDS %zu exceeds 160 KiB", e->oct_lds);
+      return ORBFE_ERR_INVALID;
+    }
+    if (e->oct_lds > 64 * 1024) {
+      int rc = orbfe_set_octree_lds(e->oct_lds);
+      if (rc != 0) {
+        orbfe_set_error("hipFuncSetAttribute(max dynamic LDS %zu) failed: %d", e->oct_lds, rc);
+        return ORBFE_ERR_HIP;
+      }
+    }
+  }
+  // device tables
+  int rc;
+  if ((rc = upload(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), e->stream))) return rc;
+  if ((rc = upload(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(BlurTile), e->stream))) return rc;
+  for (int l = 1; l < nl; l++) {
+    std::vector<ResizeTap> xt, yt;
+    build_taps(e->lg[l - 1].w, e->lg[l].w, true, xt);
+    build_taps(e->lg[l - 1].h, e->lg[l].h, false, yt);
+    if ((rc = upload(e->d_xt[l], xt.data(), xt.size() * sizeof(ResizeTap), e->stream))) return rc;
+    if ((rc = upload(e->d_yt[l], yt.data(), yt.size() * sizeof(ResizeTap), e->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));  // xt/yt go out of scope
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->plan_w = w;
+  e->plan_h = h;
+  e->cap_images = 0;  // force work-space re-allocation
+  return ORBFE_OK;
+}
+
+static size_t pyr_bytes_per_image(const orbfe_extractor* e) {
+  size_t s = 0;
+  for (int l = 0; l < e->prm.n_levels; l++) s += e->lg[l].plane;
+  return s;
+}
+
+static int ensure_workspace(orbfe_extractor* e, int n_images) {
+  if (n_images <= e->cap_images) return ORBFE_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const size_t B = (size_t)n_images;
+  int rc;
+  if ((rc = dev_alloc(e->d_pyr, pyr_bytes_per_image(e) * B))) return rc;
+  if ((rc = dev_alloc(e->d_blur, pyr_bytes_per_image(e) * B))) return rc;
+  if ((rc = dev_alloc(e->d_cell_cnt, sizeof(int32_t) * e->total_cells * B))) return rc;
+  if ((rc = dev_alloc(e->d_cell_off, sizeof(int32_t) * e->total_cells * B))) return rc;
+  if ((rc = dev_alloc(e->d_slots, sizeof(uint32_t) * e->slots_per_image * B))) return rc;
+  if ((rc = dev_alloc(e->d_gkeys, sizeof(uint64_t) * e->gkeys_per_image * B))) return rc;
+  if ((rc = dev_alloc(e->d_lvl_kp, sizeof(uint32_t) * e->kp_per_image * B))) return rc;
+  if ((rc = dev_alloc(e->d_lvl_n, sizeof(int32_t) * e->prm.n_levels * B))) return rc;
+  if ((rc = dev_alloc(e->d_err, 256))) return rc;
+  HIPCHK(hipMemsetAsync(e->d_err.p, 0, 256, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->cap_images = n_images;
+  return ORBFE_OK;
+}
+
+// level-major layout: level l of image i at d_pyr + cap_images*off_l + i*plane_l
+static uint8_t* level_ptr(const orbfe_extractor* e, const DevBuf& buf, int level, int image) {
+  return (uint8_t*)buf.p + (size_t)e->cap_images * e->lg[level].off + (size_t)image * e->lg[level].plane;
+}
+
+static void make_view(const orbfe_extractor* e, const DevBuf& buf, PyrView& v) {
+  memset(&v, 0, sizeof(v));
+  v.n_levels = e->prm.n_levels;
+  for (int l = 0; l < v.n_levels; l++) {
+    v.base[l] = level_ptr(e, buf, l, 0);
+    v.img_stride[l] = e->lg[l].plane;
+    v.pitch[l] = e->lg[l].pitch;
+    v.w[l] = e->lg[l].w;
+    v.h[l] = e->lg[l].h;
+  }
+}
+
+struct StageTimer {
+  orbfe_extractor* e;
+  hipStream_t s;
+  int stage;
+  hipEvent_t a = nullptr, b = nullptr;
+  StageTimer(orbfe_extractor* e_, hipStream_t s_, int st) : e(e_), s(s_), stage(st) {
+    if (!e->profile) return;
+    auto get = [&]() {
+      hipEvent_t ev = nullptr;
+      if (!e->ev_pool.empty()) { ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
+      else (void)hipEventCreate(&ev);
+      return ev;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, s);
+  }
+  ~StageTimer() {
+    if (!e->profile) return;
+    (void)hipEventRecord(b, s);
+    e->ev_pending.push_back({stage, a, b});
+  }
+};
+
+static void drain_events(orbfe_extractor* e) {
+  for (auto& p : e->ev_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      e->stage_ms[p.stage] += ms;
+      e->stage_launches[p.stage] += 1;
+    }
+    e->ev_pool.push_back(p.a);
+    e->ev_pool.push_back(p.b);
+  }
+  e->ev_pending.clear();
+}
+
+// Enqueues the whole extractor pipeline for n_images whose level-0 planes are already in d_pyr.
+static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_kps, uint8_t* d_desc, int cap,
+                            int32_t* d_n_out, hipStream_t s) {
+  const int nl = e->prm.n_levels;
+  PyrView pv, bv;
+  make_view(e, e->d_pyr, pv);
+  make_view(e, e->d_blur, bv);
+  {
+    StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
+    for (int l = 1; l < nl; l++)
+      orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], e->lg[l - 1].plane, const_cast<uint8_t*>(pv.base[l]),
+                          pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
+                          (const ResizeTap*)e->d_yt[l].p, n_images, s);
+  }
+  {
+    StageTimer t(e, s, ORBFE_STAGE_FAST);
+    orbfe_launch_fast(pv, (const CellDesc*)e->d_cells.p, e->total_cells, (int32_t*)e->d_cell_cnt.p,
+                      (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast, n_images, s);
+  }
+  {
+    StageTimer t(e, s, ORBFE_STAGE_OCTREE);
+    OctParams op;
+    memset(&op, 0, sizeof(op));
+    for (int l = 0; l < nl; l++) op.lv[l] = e->oct[l];
+    op.cells = (const CellDesc*)e->d_cells.p;
+    op.cell_cnt = (const int32_t*)e->d_cell_cnt.p;
+    op.slots = (const uint32_t*)e->d_slots.p;
+    op.cell_off = (int32_t*)e->d_cell_off.p;
+    op.gkeys = (unsigned long long*)e->d_gkeys.p;
+    op.lvl_kp = (uint32_t*)e->d_lvl_kp.p;
+    op.lvl_n = (int32_t*)e->d_lvl_n.p;
+    op.err = (int32_t*)e->d_err.p;
+    op.total_cells = e->total_cells;
+    op.slots_per_image = e->slots_per_image;
+    op.gkeys_per_image = e->gkeys_per_image;
+    op.kp_per_image = e->kp_per_image;
+    op.n_levels = nl;
+    op.max_nodes = e->max_nodes;
+    op.lds_keys = e->lds_keys;
+    orbfe_launch_octree(op, n_images, e->oct_lds, s);
+  }
+  {
+    StageTimer t(e, s, ORBFE_STAGE_BLUR);
+    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), n_images, s);
+  }
+  {
+    StageTimer t(e, s, ORBFE_STAGE_DESCRIBE);
+    DescribeParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.pyr = pv;
+    dp.blur = bv;
+    dp.lvl_kp = (const uint32_t*)e->d_lvl_kp.p;
+    dp.lvl_n = (const int32_t*)e->d_lvl_n.p;
+    for (int l = 0; l < nl; l++) {
+      dp.kp_off[l] = e->oct[l].kp_off;
+      dp.kp_cap[l] = e->oct[l].kp_cap;
+      dp.scale[l] = e->scale[l];
+      dp.kp_size[l] = (float)(int)(31 * e->scale[l]);  // scaledPatchSize, :800
+    }
+    dp.kp_per_image = e->kp_per_image;
+    dp.n_levels = nl;
+    dp.out_kps = d_kps;
+    dp.out_desc = d_desc;
+    dp.out_n = d_n_out;
+    dp.cap = cap;
+    orbfe_launch_describe(dp, n_images, s);
+  }
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    orbfe_set_error("kernel launch failed: %s", hipGetErrorString(le));
+    return ORBFE_ERR_HIP;
+  }
+  e->last_images = n_images;
+  return ORBFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int orbfe_extractor_create(const orbfe_params* p, int device, orbfe_extractor** out) {
+  if (!p || !out) return ORBFE_ERR_INVALID;
+  *out = nullptr;
+  if (p->n_levels < 1 || p->n_levels > ORBFE_MAX_LEVELS || p->n_features < 1 || !(p->scale_factor > 1.0f) ||
+      p->ini_th_fast < 1 || p->ini_th_fast > 255 || p->min_th_fast < 1 || p->min_th_fast > p->ini_th_fast) {
+    orbfe_set_error("invalid extractor parameters");
+    return ORBFE_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    orbfe_set_error("no HIP device available (liborbfe has no CPU fallback)");
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= ndev) {
+    orbfe_set_error("device %d out of range (%d visible)", device, ndev);
+    return ORBFE_ERR_INVALID;
+  }
+  HIPCHK(hipSetDevice(device));
+  orbfe_extractor* e = new orbfe_extractor();
+  e->prm = *p;
+  e->device = device;
+  // L/src/ORBextractor.cc:411-441; scaleFactor is stored as double (L/include/ORBextractor.h:91)
+  const double sf = (double)p->scale_factor;
+  e->scale[0] = 1.0f;
+  e->sigma2[0] = 1.0f;
+  for (int i = 1; i < p->n_levels; i++) {
+    e->scale[i] = (float)(e->scale[i - 1] * sf);
+    e->sigma2[i] = e->scale[i] * e->scale[i];
+  }
+  for (int i = 0; i < p->n_levels; i++) {
+    e->inv_scale[i] = 1.0f / e->scale[i];
+    e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+  }
+  const float factor = (float)(1.0f / sf);
+  float nDesired = p->n_features * (1 - factor) / (1 - (float)pow((double)factor, (double)p->n_levels));
+  int sum = 0;
+  for (int l = 0; l < p->n_levels - 1; l++) {
+    e->feat_per_level[l] = cv_round_f(nDesired);
+    sum += e->feat_per_level[l];
+    nDesired *= factor;
+  }
+  e->feat_per_level[p->n_levels - 1] = std::max(p->n_features - sum, 0);
+  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he != hipSuccess) {
+    orbfe_set_error("hipStreamCreate: %s", hipGetErrorString(he));
+    delete e;
+    return ORBFE_ERR_HIP;
+  }
+  *out = e;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
+  if (!e) return ORBFE_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  drain_events(e);
+  for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  DevBuf* bufs[] = {&e->d_cells, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
+                    &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
+  for (auto b : bufs) dev_free(*b);
+  for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { dev_free(e->d_xt[l]); dev_free(e->d_yt[l]); }
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return ORBFE_OK;
+}
+
+#define GETTER(name, field, type)                                                  \
+  extern "C" int name(const orbfe_extractor* e, type* out) {                       \
+    if (!e || !out) return ORBFE_ERR_INVALID;                                      \
+    for (int i = 0; i < e->prm.n_levels; i++) out[i] = e->field[i];                \
+    return ORBFE_OK;                                                               \
+  }
+GETTER(orbfe_extractor_scale_factors, scale, float)
+GETTER(orbfe_extractor_inv_scale_factors, inv_scale, float)
+GETTER(orbfe_extractor_sigma2, sigma2, float)
+GETTER(orbfe_extractor_inv_sigma2, inv_sigma2, float)
+GETTER(orbfe_extractor_features_per_level, feat_per_level, int32_t)
+
+extern "C" int orbfe_extractor_levels(const orbfe_extractor* e, int* n) {
+  if (!e || !n) return ORBFE_ERR_INVALID;
+  *n = e->prm.n_levels;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_pyramid_level_size(const orbfe_extractor* e, int w0, int h0, int level, int* w, int* h) {
+  if (!e || !w || !h || level < 0 || level >= e->prm.n_levels) return ORBFE_ERR_INVALID;
+  *w = cv_round_f((float)w0 * e->inv_scale[level]);
+  *h = cv_round_f((float)h0 * e->inv_scale[level]);
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extractor_max_keypoints(const orbfe_extractor* e, int w, int h, int* cap) {
+  if (!e || !cap) return ORBFE_ERR_INVALID;
+  int total = 0;
+  for (int l = 0; l < e->prm.n_levels; l++) {
+    const int lw = cv_round_f((float)w * e->inv_scale[l]), lh = cv_round_f((float)h * e->inv_scale[l]);
+    const float width = (float)(lw - 2 * ORBFE_EDGE), height = (float)(lh - 2 * ORBFE_EDGE);
+    int nIni = 1;
+    if (width >= 30.f && height >= 30.f) nIni = std::max(1, (int)roundf(width / height));
+    total += std::max(e->feat_per_level[l] + 3, 4 * nIni);
+  }
+  *cap = total;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_sync(orbfe_extractor* e) {
+  if (!e) return ORBFE_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return ORBFE_OK;
+}
+
+static int check_device_error(orbfe_extractor* e, hipStream_t s) {
+  int32_t err = 0;
+  HIPCHK(hipMemcpyAsync(&err, e->d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (err) {
+    orbfe_set_error("device-side capacity error word 0x%x", err);
+    (void)hipMemsetAsync(e->d_err.p, 0, 4, s);
+    return ORBFE_ERR_CAPACITY;
+  }
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_device_status(orbfe_extractor* e) {
+  if (!e) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->d_err.p) return ORBFE_OK;
+  return check_device_error(e, e->stream);
+}
+
+extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_imgs, int n_images, int w, int h,
+                                          int stride, size_t image_pitch, orbfe_keypoint* d_kps, uint8_t* d_desc,
+                                          int cap, int32_t* d_n_out, void* stream) {
+  if (!e || !d_imgs || !d_kps || !d_desc || !d_n_out || n_images < 1 || stride < w || cap < 1) return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_desc & 7) || ((uintptr_t)d_kps & 3)) {
+    orbfe_set_error("d_desc must be 8-byte aligned, d_kps 4-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = build_plan(e, w, h))) return rc;
+  if ((rc = ensure_workspace(e, n_images))) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+  {
+    StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
+    orbfe_launch_copy0(d_imgs, stride, image_pitch, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w, h,
+                       n_images, s);
+  }
+  return enqueue_pipeline(e, n_images, d_kps, d_desc, cap, d_n_out, s);
+}
+
+extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* imgs, int n_images, int w, int h,
+                                   int stride, orbfe_keypoint* kps, uint8_t* desc, int cap, int32_t* n_out) {
+  if (!e || !imgs || !kps || !desc || !n_out || n_images < 1 || cap < 1) return ORBFE_ERR_INVALID;
+  if (w < 1 || h < 1) return ORBFE_ERR_EMPTY;
+  if (stride < w) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = build_plan(e, w, h))) return rc;
+  if ((rc = ensure_workspace(e, n_images))) return rc;
+  hipStream_t s = e->stream;
+  if (cap > e->out_cap || (size_t)cap * n_images * sizeof(orbfe_keypoint) > e->d_out_kps.bytes) {
+    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = dev_alloc(e->d_out_kps, sizeof(orbfe_keypoint) * (size_t)cap * n_images))) return rc;
+    if ((rc = dev_alloc(e->d_out_desc, (size_t)32 * cap * n_images))) return rc;
+    e->out_cap = cap;
+  }
+  if ((rc = dev_alloc(e->d_out_n, sizeof(int32_t) * (size_t)std::max(n_images, e->cap_images)))) return rc;
+  for (int i = 0; i < n_images; i++) {
+    if (!imgs[i]) return ORBFE_ERR_INVALID;
+    HIPCHK(hipMemcpy2DAsync(level_ptr(e, e->d_pyr, 0, i), e->lg[0].pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, s));
+  }
+  if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap,
+                             (int32_t*)e->d_out_n.p, s)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(n_out, e->d_out_n.p, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, s));
+  if ((rc = check_device_error(e, s))) return rc;
+  for (int i = 0; i < n_images; i++) {
+    if (n_out[i] > cap) {
+      orbfe_set_error("image %d produced %d keypoints, capacity %d", i, n_out[i], cap);
+      return ORBFE_ERR_CAPACITY;
+    }
+    if (n_out[i] > 0) {
+      HIPCHK(hipMemcpyAsync(kps + (size_t)i * cap, (orbfe_keypoint*)e->d_out_kps.p + (size_t)i * cap,
+                            sizeof(orbfe_keypoint) * n_out[i], hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(desc + (size_t)i * cap * 32, (uint8_t*)e->d_out_desc.p + (size_t)i * cap * 32,
+                            (size_t)32 * n_out[i], hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (e->profile) drain_events(e);
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extract(orbfe_extractor* e, const uint8_t* img, int w, int h, int stride, orbfe_keypoint* kps,
+                             uint8_t* desc, int cap, int* n_out) {
+  if (!e || !kps || !desc || !n_out) return ORBFE_ERR_INVALID;
+  if (!img || w < 1 || h < 1) return ORBFE_ERR_EMPTY;
+  int32_t n = 0;
+  const uint8_t* one[1] = {img};
+  int rc = orbfe_extract_batch(e, one, 1, w, h, stride, kps, desc, cap, &n);
+  *n_out = n;
+  return rc;
+}
+
+extern "C" int orbfe_pyramid_level(orbfe_extractor* e, int level, uint8_t* dst, int dst_stride, int* w, int* h) {
+  if (!e || level < 0 || level >= e->prm.n_levels || e->plan_w == 0 || e->last_images < 1) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  const LevelGeom& g = e->lg[level];
+  if (w) *w = g.w;
+  if (h) *h = g.h;
+  if (dst) {
+    if (dst_stride < g.w) return ORBFE_ERR_INVALID;
+    HIPCHK(hipMemcpy2DAsync(dst, dst_stride, level_ptr(e, e->d_pyr, level, 0), g.pitch, g.w, g.h, hipMemcpyDeviceToHost,
+                            e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_device_pyramid(const orbfe_extractor* e, int image, int level, const uint8_t** d_ptr, int* pitch,
+                                    int* w, int* h) {
+  if (!e || level < 0 || level >= e->prm.n_levels || image < 0 || image >= e->cap_images || e->plan_w == 0)
+    return ORBFE_ERR_INVALID;
+  if (d_ptr) *d_ptr = level_ptr(e, e->d_pyr, level, image);
+  if (pitch) *pitch = e->lg[level].pitch;
+  if (w) *w = e->lg[level].w;
+  if (h) *h = e->lg[level].h;
+  return ORBFE_OK;
+}
+
+// internal accessor for the stereo matcher (match side lives in matcher.cpp)
+int orbfe_internal_pyr_view(const orbfe_extractor* e, PyrView* v, int* n_images) {
+  if (!e || e->plan_w == 0 || e->cap_images < 1) return ORBFE_ERR_INVALID;
+  make_view(e, e->d_pyr, *v);
+  if (n_images) *n_images = e->last_images;
+  return ORBFE_OK;
+}
+int orbfe_internal_tables(const orbfe_extractor* e, float* scale, float* inv_scale, int* n_levels, int* device) {
+  for (int l = 0; l < e->prm.n_levels; l++) { scale[l] = e->scale[l]; inv_scale[l] = e->inv_scale[l]; }
+  *n_levels = e->prm.n_levels;
+  *device = e->device;
+  return ORBFE_OK;
+}
+hipStream_t orbfe_internal_stream(const orbfe_extractor* e) { return e->stream; }
+
+// ---- debug / parity accessors
+extern "C" int orbfe_debug_candidates(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y, int32_t* score,
+                                      int cap, int* n) {
+  if (!e || !n || level < 0 || level >= e->prm.n_levels || image < 0 || image >= e->last_images) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  const OctLevel& o = e->oct[level];
+  std::vector<int32_t> cnt(std::max(o.n_cells, 1));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(cnt.data(), (int32_t*)e->d_cell_cnt.p + (size_t)image * e->total_cells + o.cell_begin,
+                   sizeof(int32_t) * o.n_cells, hipMemcpyDeviceToHost));
+  int total = 0;
+  std::vector<uint32_t> tmp;
+  for (int c = 0; c < o.n_cells; c++) {
+    const CellDesc& cd = e->cells[o.cell_begin + c];
+    tmp.resize(std::max(cnt[c], 1));
+    if (cnt[c] > 0)
+      HIPCHK(hipMemcpy(tmp.data(), (uint32_t*)e->d_slots.p + (size_t)image * e->slots_per_image + cd.slot_off,
+                       sizeof(uint32_t) * cnt[c], hipMemcpyDeviceToHost));
+    for (int j = 0; j < cnt[c]; j++) {
+      if (total < cap) {
+        x[total] = tmp[j] & 0xfff;
+        y[total] = (tmp[j] >> 12) & 0xfff;
+        score[total] = tmp[j] >> 24;
+      }
+      total++;
+    }
+  }
+  *n = total;
+  return total > cap ? ORBFE_ERR_CAPACITY : ORBFE_OK;
+}
+
+extern "C" int orbfe_debug_blurred(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride) {
+  if (!e || !dst || level < 0 || level >= e->prm.n_levels || image < 0 || image >= e->last_images) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  const LevelGeom& g = e->lg[level];
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy2D(dst, dst_stride, level_ptr(e, e->d_blur, level, image), g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_debug_pyramid(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride) {
+  if (!e || !dst || level < 0 || level >= e->prm.n_levels || image < 0 || image >= e->last_images) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  const LevelGeom& g = e->lg[level];
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy2D(dst, dst_stride, level_ptr(e, e->d_pyr, level, image), g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_debug_level_keypoints(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y,
+                                           int32_t* score, int cap, int* n) {
+  if (!e || !n || level < 0 || level >= e->prm.n_levels || image < 0 || image >= e->last_images) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int32_t cnt = 0;
+  HIPCHK(hipMemcpy(&cnt, (int32_t*)e->d_lvl_n.p + (size_t)image * e->prm.n_levels + level, 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> tmp(std::max(cnt, 1));
+  if (cnt > 0)
+    HIPCHK(hipMemcpy(tmp.data(), (uint32_t*)e->d_lvl_kp.p + (size_t)image * e->kp_per_image + e->oct[level].kp_off,
+                     sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+  for (int i = 0; i < cnt && i < cap; i++) {
+    x[i] = (tmp[i] & 0xfff) + ORBFE_EDGE;
+    y[i] = ((tmp[i] >> 12) & 0xfff) + ORBFE_EDGE;
+    score[i] = tmp[i] >> 24;
+  }
+  *n = cnt;
+  return cnt > cap ? ORBFE_ERR_CAPACITY : ORBFE_OK;
+}
+
+extern "C" int orbfe_profile_enable(orbfe_extractor* e, int enable) {
+  if (!e) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->profile = enable != 0;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_stage_times(orbfe_extractor* e, float* ms, int32_t* launches, int reset) {
+  if (!e) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  drain_events(e);
+  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
+    if (ms) ms[i] = e->stage_ms[i];
+    if (launches) launches[i] = e->stage_launches[i];
+    if (reset) { e->stage_ms[i] = 0; e->stage_launches[i] = 0; }
+  }
+  return ORBFE_OK;
+}

@@ -1,0 +1,99 @@
+// orbfe_internal.h -- structs shared by the host side of liborbfe and its HIP kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbfe.h"
+
+#define ORBFE_EDGE 16            // minBorder = EDGE_THRESHOLD - 3 (L/src/ORBextractor.cc:740)
+#define ORBFE_CELL_MAX 66        // largest FAST cell ROI side the cell kernel stages in LDS
+#define ORBFE_TILE_PITCH 72      // LDS row pitch of the staged ROI (ROI side + 3 bytes alignment slack)
+#define ORBFE_MAX_INI 256        // largest nIni (root nodes of DistributeOctTree) supported
+#define ORBFE_OCT_THREADS 256
+
+// Per-level geometry of one image pyramid, passed to kernels by value.
+struct PyrView {
+  const uint8_t* base[ORBFE_MAX_LEVELS];  // level plane of image 0
+  unsigned long long img_stride[ORBFE_MAX_LEVELS];  // bytes between consecutive images at this level
+  int pitch[ORBFE_MAX_LEVELS];
+  int w[ORBFE_MAX_LEVELS], h[ORBFE_MAX_LEVELS];
+  int n_levels;
+};
+
+// Horizontal / vertical coefficient tables of cv::resize INTER_LINEAR (8 bytes per destination index)
+struct ResizeTap {
+  int16_t s0, s1;  // source indices (clamped)
+  int16_t c0, c1;  // fixed-point weights, sum 2048
+};
+
+// One FAST cell of ComputeKeyPointsOctTree (L/src/ORBextractor.cc:756-771)
+struct CellDesc {
+  int16_t level;
+  int16_t x0, y0;      // ROI origin (iniX, iniY) in level pixels
+  int16_t cols, rows;  // ROI size handed to cv::FAST
+  int16_t shift_x, shift_y;  // j*wCell, i*hCell added to FAST's local coordinates
+  int16_t slot_cap;    // capacity of this cell's output slot
+  uint32_t slot_off;   // offset (entries) of this cell's slot inside one image's slot block
+};
+
+// Per-level parameters of DistributeOctTree
+struct OctLevel {
+  int cell_begin, n_cells;  // range in the cell table
+  int N;                    // mnFeaturesPerLevel[level]
+  int n_ini;
+  float hX;
+  int width, height;        // maxX-minX, maxY-minY
+  int kp_off, kp_cap;       // slice of the per-image level-keypoint array
+  unsigned long long key_off;  // offset (entries) of this level's global key fallback inside one image's block
+  int key_cap;
+};
+
+struct OctParams {
+  OctLevel lv[ORBFE_MAX_LEVELS];
+  const CellDesc* cells;
+  const int32_t* cell_cnt;   // [image][total_cells]
+  const uint32_t* slots;     // [image][slots_per_image] packed x | y<<12 | score<<24
+  int32_t* cell_off;         // [image][total_cells] scratch
+  unsigned long long* gkeys; // [image][gkeys_per_image] fallback key storage
+  uint32_t* lvl_kp;          // [image][kp_per_image] selected keypoints packed like slots (level coords - 16)
+  int32_t* lvl_n;            // [image][n_levels]
+  int32_t* err;              // device error word
+  int total_cells;
+  unsigned long long slots_per_image, gkeys_per_image;
+  int kp_per_image;
+  int n_levels;
+  int max_nodes;             // M: node table capacity (dynamic LDS sized from it)
+  int lds_keys;              // CAP: keys that fit the LDS key array
+};
+
+struct DescribeParams {
+  PyrView pyr;      // un-blurred pyramid (orientation)
+  PyrView blur;     // blurred pyramid (descriptor)
+  const uint32_t* lvl_kp;
+  const int32_t* lvl_n;
+  int kp_off[ORBFE_MAX_LEVELS], kp_cap[ORBFE_MAX_LEVELS];
+  float scale[ORBFE_MAX_LEVELS];
+  float kp_size[ORBFE_MAX_LEVELS];
+  int kp_per_image;
+  int n_levels;
+  orbfe_keypoint* out_kps;
+  uint8_t* out_desc;
+  int32_t* out_n;
+  int cap;
+};
+
+struct BlurTile {
+  int16_t level, tx, ty;  // tile origin = (tx*64, ty*16)
+  int16_t pad;
+};
+
+// launchers (extract_kernels.hip)
+void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
+                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, hipStream_t s);
+void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
+                       unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
+void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
+void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
+                       hipStream_t s);
+void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s);
+size_t orbfe_octree_lds_bytes(int max_nodes, int lds_keys);
