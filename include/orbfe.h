@@ -139,27 +139,38 @@ int orbfe_profile_enable(orbfe_extractor* e, int enable);
 int orbfe_stage_times(orbfe_extractor* e, float* ms /*[ORBFE_STAGE_COUNT]*/, int32_t* launches, int reset);
 
 /* --------------------------------------------------------------------------------------- ORBmatcher */
+/* Work-space handle of the matcher kernels (scratch HBM + a HIP stream).  One handle serves one thread at
+ * a time; the host-pointer entry points below that take no handle use a thread-local one, so they may be
+ * called concurrently from Tracking / LocalMapping / LoopClosing threads (ORBmatcher objects are
+ * stack-constructed per call site in the reference, L/src/Tracking.cc:781,1070). */
+typedef struct orbfe_matcher orbfe_matcher;
+int orbfe_matcher_create(int device, orbfe_matcher** out);
+int orbfe_matcher_destroy(orbfe_matcher* m);
+int orbfe_matcher_sync(orbfe_matcher* m);
+
 /* ORBmatcher::DescriptorDistance (L/src/ORBmatcher.cc:1542-1556) for all pairs: dist[i*nB + j] =
- * Hamming(A[i], B[j]) as uint16.  DEVICE pointers, asynchronous on stream. */
+ * Hamming(A[i], B[j]) as uint16.  DEVICE pointers (32-byte rows, 16-byte aligned), asynchronous on stream. */
 int orbfe_hamming_matrix_device(const uint8_t* d_A, int nA, const uint8_t* d_B, int nB, uint16_t* d_dist,
                                 void* stream);
 
 /* Brute-force best / second-best (the inner loops of SearchByBoW, L/src/ORBmatcher.cc:201-222): for
  * every row i of A the first-minimum over j of B (strict <, index order) and the second-smallest
- * distance.  groupA/groupB (nullable): compare only where groupA[i] == groupB[j] (vocabulary node id);
- * maskB (nullable): skip j with maskB[j] != 0.  n_sets independent problems: set s uses rows
- * [s*strideA, s*strideA + nA[s]) of A etc.  All pointers DEVICE pointers. */
+ * distance.  groupA/groupB (nullable, both or neither): compare only where groupA[i] == groupB[j]
+ * (vocabulary node id); maskB (nullable): skip j with maskB[j] != 0 (already matched).  n_sets independent
+ * problems: set s uses rows [s*strideA, s*strideA + nA[s]) of A and of out, [s*strideB, ..+nB[s]) of B;
+ * max_nA >= every nA[s]; nB[s] < 65536.  All pointers DEVICE pointers; asynchronous on stream. */
 typedef struct orbfe_bf_match {
   int32_t best_idx;    /* -1 when no candidate */
   int32_t best_dist;   /* 256 when none */
   int32_t second_dist; /* 256 when none */
 } orbfe_bf_match;
-int orbfe_hamming_bf_device(const uint8_t* d_A, const int32_t* d_nA, int strideA, const uint8_t* d_B,
+int orbfe_hamming_bf_device(const uint8_t* d_A, const int32_t* d_nA, int strideA, int max_nA, const uint8_t* d_B,
                             const int32_t* d_nB, int strideB, const int32_t* d_groupA, const int32_t* d_groupB,
                             const uint8_t* d_maskB, int n_sets, orbfe_bf_match* d_out, void* stream);
 
 /* View of the Frame members the projection searches read (L/include/Frame.h): mvKeysUn, mDescriptors,
- * mvuRight and the 64x48 grid (mGrid, filled as Frame::AssignFeaturesToGrid does). */
+ * mvuRight and the image bounds; the 64x48 grid (mGrid) is rebuilt on the device from them exactly as
+ * Frame::AssignFeaturesToGrid / PosInGrid do (L/src/Frame.cc:250-263,399-410). */
 typedef struct orbfe_frame_view {
   int32_t n;                        /* Frame::N */
   const orbfe_keypoint* keys_un;    /* mvKeysUn */
@@ -168,7 +179,7 @@ typedef struct orbfe_frame_view {
   float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
 } orbfe_frame_view;
 
-/* One projected map point (A11: L/src/ORBmatcher.cc:52-71; A12: :1270-1308) */
+/* One projected map point (A11: L/src/ORBmatcher.cc:52-71; A12: :1270-1308); 68 bytes */
 typedef struct orbfe_query {
   float u, v;       /* projection */
   float u_r;        /* right-image coordinate of the projection */
@@ -188,29 +199,41 @@ typedef struct orbfe_cand {
 /* Window query + distances, the data-parallel part of every SearchByProjection
  * (Frame::GetFeaturesInArea L/src/Frame.cc:341-397 + DescriptorDistance).  HOST pointers in, HOST
  * results out; synchronous.  For query q writes up to max_cand candidates in the reference's
- * enumeration order to cand[q*max_cand ..] and their number to n_cand[q] (a count > max_cand signals
- * truncation).  The stereo gate |u_r - mvuRight| <= radius is applied on the device. */
+ * enumeration order to cand[q*max_cand ..] and their total number to n_cand[q] (a count > max_cand
+ * signals truncation).  The stereo gate |u_r - mvuRight| <= radius is applied on the device. */
 int orbfe_proj_candidates(const orbfe_frame_view* frame, const orbfe_query* q, int nq, orbfe_cand* cand,
                           int32_t* n_cand, int max_cand);
 
-/* SearchByProjection(Frame&, const vector<MapPoint*>&, th) (L/src/ORBmatcher.cc:45-128): device window
- * query + distances, host replay of the order-dependent assignment.  blocked[idx] != 0 <=>
- * F.mvpMapPoints[idx] has Observations() > 0 on entry (updated).  assigned[idx] = query index written to
- * F.mvpMapPoints[idx], untouched otherwise.  *n_matches = return value of the reference. */
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th) (L/src/ORBmatcher.cc:45-128) on the device:
+ * window query + distances in parallel, then the order-dependent assignment by one wave per frame.
+ * blocked[idx] != 0 <=> F.mvpMapPoints[idx] has Observations() > 0 on entry (updated in place).
+ * assigned[idx] = query index written to F.mvpMapPoints[idx]; entries not written keep their value.
+ * *n_matches = return value of the reference.  HOST pointers, synchronous. */
 int orbfe_search_by_projection_points(const orbfe_frame_view* frame, const orbfe_query* q, int nq, float nnratio,
                                       uint8_t* blocked, int32_t* assigned, int* n_matches);
 /* SearchByProjection(Frame& cur, const Frame& last, th, bMono) (L/src/ORBmatcher.cc:1247-1383). */
 int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_query* q, int nq,
                                      int check_orientation, uint8_t* blocked, int32_t* assigned, int* n_matches);
 
+/* Both searches for n_frames frames at once, DEVICE pointers, asynchronous on stream (NULL: the handle's).
+ * Frame f: keypoints/descriptors/u_right rows [f*cap, f*cap + d_n[f]); queries [f*q_cap, f*q_cap + d_nq[f]).
+ * mode 0 = A11 (points, ratio test nnratio), mode 1 = A12 (frame, rotation histogram if check_orientation).
+ * d_blocked / d_assigned: n_frames x cap (in/out as above); d_n_matches: n_frames. */
+int orbfe_proj_match_batch_device(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                                  const int32_t* d_n, const float* d_u_right, int cap, float min_x, float max_x,
+                                  float min_y, float max_y, const orbfe_query* d_q, const int32_t* d_nq, int q_cap,
+                                  int mode, float nnratio, int check_orientation, uint8_t* d_blocked,
+                                  int32_t* d_assigned, int32_t* d_n_matches, void* stream);
+
 /* Frame::ComputeStereoMatches (L/src/Frame.cc:477-646) for n_pairs stereo frames, DEVICE pointers,
  * asynchronous.  Left/right keypoints+descriptors as produced by orbfe_extract_batch_device with the
- * two extractor handles (whose device pyramids are read for the 11x11 SAD refinement).
- * d_u_right / d_depth: n_pairs x cap floats (-1 = no match). */
-int orbfe_stereo_match_device(orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
+ * two extractor handles, whose device pyramids (image p of each) are read for the 11x11 SAD refinement.
+ * d_u_right / d_depth: n_pairs x cap floats (-1 = no match); d_n_matched: n_pairs (matches kept). */
+int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
                               const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
                               const orbfe_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r,
-                              int cap, float mbf, float mb, float* d_u_right, float* d_depth, void* stream);
+                              int cap, float mbf, float mb, float* d_u_right, float* d_depth, int32_t* d_n_matched,
+                              void* stream);
 
 #ifdef __cplusplus
 }

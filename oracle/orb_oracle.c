@@ -1145,6 +1145,11 @@ int oo_compute_stereo_matches(const oo_keypoint* keysL, const uint8_t* descL, in
       const float endu = scaleduR0 + L + w + 1;
       if (iniu < 0 || endu >= pyrR->w[oct]) continue;
       const int yL0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w);
+      /* the reference takes these windows with rowRange/colRange, which throw when out of range; both this
+       * restatement and the device kernel treat that as "no match" */
+      if (yL0 < 0 || yL0 + 2 * w >= pyrL->h[oct] || xL0 < 0 || xL0 + 2 * w >= pyrL->w[oct] ||
+          (int)scaleduR0 - L - w < 0 || (int)scaleduR0 + L + w >= pyrR->w[oct] || yL0 + 2 * w >= pyrR->h[oct])
+        continue;
       const float cL = (float)imL[(size_t)(yL0 + w) * sL + xL0 + w];
       for (int incR = -L; incR <= +L; incR++) {
         const int xR0 = (int)(scaleduR0 + incR - w);

@@ -52,6 +52,7 @@ EXPORTS = [
     "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_device_pyramid", "orbfe_sync",
     "orbfe_device_status", "orbfe_debug_candidates", "orbfe_debug_blurred", "orbfe_debug_pyramid",
     "orbfe_debug_level_keypoints", "orbfe_profile_enable", "orbfe_stage_times",
+    "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
 ]
@@ -105,18 +106,17 @@ def lib():
     L.orbfe_debug_level_keypoints.argtypes = [vp, ci, ci, vp, vp, vp, ci, pi]
     L.orbfe_profile_enable.argtypes = [vp, ci]
     L.orbfe_stage_times.argtypes = [vp, vp, vp, ci]
-    if not hasattr(L, "orbfe_hamming_matrix_device"):  # TEMP while the matcher is being written
-        for name in EXPORTS[:25]:
-            if name != "orbfe_last_error":
-                getattr(L, name).restype = ci
-        _lib = L
-        return L
     L.orbfe_hamming_matrix_device.argtypes = [vp, ci, vp, ci, vp, vp]
-    L.orbfe_hamming_bf_device.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp]
+    L.orbfe_hamming_bf_device.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp]
+    L.orbfe_matcher_create.argtypes = [ci, C.POINTER(vp)]
+    L.orbfe_matcher_destroy.argtypes = [vp]
+    L.orbfe_matcher_sync.argtypes = [vp]
+    L.orbfe_proj_match_batch_device.argtypes = [vp, ci, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, ci, ci, cf, ci,
+                                                vp, vp, vp, vp]
     L.orbfe_proj_candidates.argtypes = [C.POINTER(FrameView), vp, ci, vp, vp, ci]
     L.orbfe_search_by_projection_points.argtypes = [C.POINTER(FrameView), vp, ci, cf, vp, vp, pi]
     L.orbfe_search_by_projection_frame.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, pi]
-    L.orbfe_stereo_match_device.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp]
+    L.orbfe_stereo_match_device.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
     for name in EXPORTS:
         if name != "orbfe_last_error":
             getattr(L, name).restype = ci

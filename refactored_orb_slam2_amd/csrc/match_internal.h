@@ -1,0 +1,63 @@
+// match_internal.h -- structs shared by matcher.cpp and match_kernels.hip
+#pragma once
+#include "orbfe_internal.h"
+
+#define GRID_CELLS (ORBFE_GRID_COLS * ORBFE_GRID_ROWS)
+
+// A batch of frames with identical capacity: frame f uses rows [f*cap, f*cap + n[f])
+struct FrameBatch {
+  const orbfe_keypoint* keys;
+  const uint8_t* desc;
+  const float* u_right;      // nullable
+  const int32_t* n;          // [n_frames]
+  int32_t* cell_start;       // [n_frames][GRID_CELLS + 1]
+  int32_t* cell_idx;         // [n_frames][cap]
+  int cap;
+  float min_x, min_y, gw_inv, gh_inv;
+};
+
+struct QueryBatch {
+  const orbfe_query* q;      // [n_frames][cap]
+  const int32_t* n;          // [n_frames]
+  int cap;
+};
+
+struct HammingBfParams {
+  const uint8_t* A;
+  const int32_t* nA;
+  int strideA;
+  const uint8_t* B;
+  const int32_t* nB;
+  int strideB;
+  const int32_t* groupA;
+  const int32_t* groupB;
+  const uint8_t* maskB;
+  orbfe_bf_match* out;
+};
+
+struct StereoParams {
+  PyrView pyrL, pyrR;
+  const orbfe_keypoint* kpsL;
+  const uint8_t* descL;
+  const int32_t* nL;
+  const orbfe_keypoint* kpsR;
+  const uint8_t* descR;
+  const int32_t* nR;
+  int cap;
+  float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS];
+  float mbf, maxD;
+  float* u_right;
+  float* depth;
+  int32_t* sad;        // scratch [n_pairs][cap]
+  int32_t* n_matched;  // [n_pairs]
+};
+
+void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s);
+void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s);
+void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s);
+void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
+                                  int max_cand, int n_frames, hipStream_t s);
+void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
+                               int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
+                               int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s);
+void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s);

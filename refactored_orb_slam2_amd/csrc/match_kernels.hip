@@ -1,0 +1,612 @@
+// match_kernels.hip -- HIP kernels of the ORB matcher path for gfx950 (MI355X, wave64).
+//
+// Kernel              replaces (reference file:line, L/ = Source/Libraries/ORB_SLAM2/)
+// hamming_matrix      ORBmatcher::DescriptorDistance for all pairs            L/src/ORBmatcher.cc:1542-1556
+// hamming_bf          best / second-best loops of SearchByBoW                 L/src/ORBmatcher.cc:201-222
+// grid_build          Frame::AssignFeaturesToGrid + PosInGrid                 L/src/Frame.cc:250-263,399-410
+// proj_candidates     Frame::GetFeaturesInArea + DescriptorDistance           L/src/Frame.cc:341-397
+// proj_resolve        order-dependent assignment of SearchByProjection        L/src/ORBmatcher.cc:45-128,1247-1383
+// stereo_match        Frame::ComputeStereoMatches (Hamming + 11x11 SAD)        L/src/Frame.cc:477-632
+// stereo_median       median-based outlier cut                                 L/src/Frame.cc:634-645
+//
+// Compiled with -ffp-contract=off: every float expression is evaluated un-fused, as the reference does.
+#include "match_internal.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+__device__ __forceinline__ void load_desc(const uint8_t* p, uint4& d0, uint4& d1) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  d0 = q[0];
+  d1 = q[1];
+}
+// descriptors that are only 4-byte aligned (queries embedded in 68-byte records)
+__device__ __forceinline__ void load_desc4(const uint8_t* p, uint4& d0, uint4& d1) {
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  d0 = make_uint4(q[0], q[1], q[2], q[3]);
+  d1 = make_uint4(q[4], q[5], q[6], q[7]);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, d, WAVE));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ all pairs
+// Thread = one B column (descriptor in registers); a block stages 64 A rows in LDS; stores are coalesced
+// along j.  grid = (ceil(nB/256), ceil(nA/64)).
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t* __restrict__ A, int nA,
+                                                              const uint8_t* __restrict__ B, int nB,
+                                                              uint16_t* __restrict__ out) {
+  __shared__ uint4 sa[64 * 2];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i0 = blockIdx.y * 64;
+  if (threadIdx.x < 128) {
+    const int r = i0 + (threadIdx.x >> 1);
+    sa[threadIdx.x] = r < nA ? reinterpret_cast<const uint4*>(A)[(size_t)r * 2 + (threadIdx.x & 1)] : make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  if (j >= nB) return;
+  uint4 b0, b1;
+  load_desc(B + (size_t)j * 32, b0, b1);
+  const int rows = min(64, nA - i0);
+  for (int r = 0; r < rows; r++) out[(size_t)(i0 + r) * nB + j] = (uint16_t)hamming256(sa[2 * r], sa[2 * r + 1], b0, b1);
+}
+
+// ------------------------------------------------------------------------------------------------ brute force
+// Block = 32 A rows x 8 partitions of B.  B is staged through LDS in tiles of 256 descriptors.  Every
+// thread keeps (best dist, best j, second dist) over its partition in index order; partitions are merged with
+// the (dist, j) lexicographic minimum == the reference's strict-< first-wins scan over vIndicesF.
+__global__ __launch_bounds__(256) void hamming_bf_kernel(HammingBfParams P) {
+  __shared__ uint4 sb[256 * 2];
+  __shared__ int sg[256];
+  __shared__ uint8_t sm[256];
+  __shared__ unsigned mkey[8][32];
+  __shared__ int msec[8][32];
+  const int set = blockIdx.y;
+  const int nA = P.nA[set], nB = P.nB[set];
+  const int a = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int part = threadIdx.x >> 5;
+  if (blockIdx.x * 32 >= nA) return;
+  const uint8_t* A = P.A + (size_t)set * P.strideA * 32;
+  const uint8_t* B = P.B + (size_t)set * P.strideB * 32;
+  uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+  int ga = 0;
+  if (a < nA) {
+    load_desc(A + (size_t)a * 32, a0, a1);
+    if (P.groupA) ga = P.groupA[(size_t)set * P.strideA + a];
+  }
+  int bestd = 256, bestj = -1, second = 256;  // sequential best / second-best of this thread's j subsequence
+  for (int t0 = 0; t0 < nB; t0 += 256) {
+    __syncthreads();
+    {
+      const int j = t0 + threadIdx.x;
+      if (j < nB) {
+        const uint4* q = reinterpret_cast<const uint4*>(B + (size_t)j * 32);
+        sb[2 * threadIdx.x] = q[0];
+        sb[2 * threadIdx.x + 1] = q[1];
+        sg[threadIdx.x] = P.groupB ? P.groupB[(size_t)set * P.strideB + j] : 0;
+        sm[threadIdx.x] = P.maskB ? P.maskB[(size_t)set * P.strideB + j] : 0;
+      }
+    }
+    __syncthreads();
+    const int cnt = min(256, nB - t0);
+    // partition p scans tile entries p*32 .. p*32+31: a thread's j sequence is increasing
+    for (int k = 0; k < 32; k++) {
+      const int jj = part * 32 + k;
+      if (jj >= cnt) break;
+      if (sm[jj]) continue;
+      if (P.groupA && sg[jj] != ga) continue;
+      const int d = hamming256(a0, a1, sb[2 * jj], sb[2 * jj + 1]);
+      if (d < bestd) { second = bestd; bestd = d; bestj = t0 + jj; }
+      else if (d < second) second = d;
+    }
+  }
+  const unsigned best = bestj >= 0 ? (((unsigned)bestd << 16) | (unsigned)bestj) : 0xFFFFFFFFu;
+  mkey[part][threadIdx.x & 31] = best;
+  msec[part][threadIdx.x & 31] = second;
+  __syncthreads();
+  if (part == 0 && a < nA) {
+    // global best = lexicographic min of (dist, j); second = min over every partition's second and every
+    // partition's best except the winner's
+    unsigned b = 0xFFFFFFFFu;
+    for (int p = 0; p < 8; p++) b = min(b, mkey[p][threadIdx.x]);
+    int s = 256;
+    for (int p = 0; p < 8; p++) {
+      const unsigned k = mkey[p][threadIdx.x];
+      if (k != b && k != 0xFFFFFFFFu) s = min(s, (int)(k >> 16));
+      s = min(s, msec[p][threadIdx.x]);
+    }
+    orbfe_bf_match m;
+    if (b == 0xFFFFFFFFu) { m.best_idx = -1; m.best_dist = 256; m.second_dist = 256; }
+    else { m.best_idx = (int)(b & 0xffff); m.best_dist = (int)(b >> 16); m.second_dist = s; }
+    P.out[(size_t)set * P.strideA + a] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ grid
+// One block per frame: 64x48 grid in CSR form (cell = ix*48 + iy), lists in ascending keypoint index.
+__global__ __launch_bounds__(256) void grid_build_kernel(FrameBatch F) {
+  __shared__ int cnt[GRID_CELLS];
+  __shared__ int start[GRID_CELLS + 1];
+  __shared__ int tmp[8];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = F.n[f];
+  const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
+  int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
+  int32_t* ci = F.cell_idx + (size_t)f * F.cap;
+  for (int c = tid; c < GRID_CELLS; c += 256) cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int px = (int)roundf((keys[i].x - F.min_x) * F.gw_inv);
+    const int py = (int)roundf((keys[i].y - F.min_y) * F.gh_inv);
+    if (px >= 0 && px < ORBFE_GRID_COLS && py >= 0 && py < ORBFE_GRID_ROWS) atomicAdd(&cnt[px * ORBFE_GRID_ROWS + py], 1);
+  }
+  __syncthreads();
+  // exclusive scan: 12 consecutive cells per thread
+  {
+    int local = 0;
+    for (int k = 0; k < 12; k++) local += cnt[tid * 12 + k];
+    int v = local;
+    const int lane = tid & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(v, d, WAVE);
+      if (lane >= d) v += t;
+    }
+    if (lane == 63) tmp[tid >> 6] = v;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < (tid >> 6); w++) off += tmp[w];
+    int run = off + v - local;
+    for (int k = 0; k < 12; k++) {
+      start[tid * 12 + k] = run;
+      run += cnt[tid * 12 + k];
+    }
+    if (tid == 255) start[GRID_CELLS] = run;
+  }
+  __syncthreads();
+  for (int c = tid; c <= GRID_CELLS; c += 256) cs[c] = start[c];
+  for (int c = tid; c < GRID_CELLS; c += 256) cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int px = (int)roundf((keys[i].x - F.min_x) * F.gw_inv);
+    const int py = (int)roundf((keys[i].y - F.min_y) * F.gh_inv);
+    if (px >= 0 && px < ORBFE_GRID_COLS && py >= 0 && py < ORBFE_GRID_ROWS) {
+      const int c = px * ORBFE_GRID_ROWS + py;
+      ci[start[c] + atomicAdd(&cnt[c], 1)] = i;
+    }
+  }
+  __syncthreads();
+  // insertion order of the reference = ascending index: sort each (tiny) cell list
+  for (int c = tid; c < GRID_CELLS; c += 256) {
+    const int s = start[c], e = start[c + 1];
+    for (int i = s + 1; i < e; i++) {
+      const int v = ci[i];
+      int j = i - 1;
+      while (j >= s && ci[j] > v) { ci[j + 1] = ci[j]; j--; }
+      ci[j + 1] = v;
+    }
+  }
+}
+
+// Enumerates, in the reference's order, the keypoints GetFeaturesInArea returns for query q that also pass the
+// matcher's stereo gate, and calls fn(rank, idx, dist) for each, wave-cooperatively: a chunk of up to 64
+// consecutive grid entries is tested per step, survivors get consecutive ranks.  Returns the survivor count.
+template <typename Fn>
+__device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, const orbfe_query& q, const uint4 q0,
+                                                const uint4 q1, Fn fn) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const float x = q.u, y = q.v, r = q.radius;
+  const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.gw_inv));
+  if (nMinCellX >= ORBFE_GRID_COLS) return 0;
+  const int nMaxCellX = min(ORBFE_GRID_COLS - 1, (int)ceilf((x - F.min_x + r) * F.gw_inv));
+  if (nMaxCellX < 0) return 0;
+  const int nMinCellY = max(0, (int)floorf((y - F.min_y - r) * F.gh_inv));
+  if (nMinCellY >= ORBFE_GRID_ROWS) return 0;
+  const int nMaxCellY = min(ORBFE_GRID_ROWS - 1, (int)ceilf((y - F.min_y + r) * F.gh_inv));
+  if (nMaxCellY < 0) return 0;
+  const bool bCheckLevels = (q.min_level > 0) || (q.max_level >= 0);
+  const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
+  const uint8_t* desc = F.desc + (size_t)f * F.cap * 32;
+  const float* ur = F.u_right ? F.u_right + (size_t)f * F.cap : nullptr;
+  const int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
+  const int32_t* ci = F.cell_idx + (size_t)f * F.cap;
+  int rank0 = 0;
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+    // cells (ix, nMinCellY..nMaxCellY) are adjacent in CSR order
+    const int e0 = cs[ix * ORBFE_GRID_ROWS + nMinCellY], e1 = cs[ix * ORBFE_GRID_ROWS + nMaxCellY + 1];
+    for (int base = e0; base < e1; base += WAVE) {
+      const int ent = base + lane;
+      bool ok = false;
+      int idx = 0;
+      if (ent < e1) {
+        idx = ci[ent];
+        const orbfe_keypoint kp = keys[idx];
+        ok = true;
+        if (bCheckLevels) {
+          if (kp.octave < q.min_level) ok = false;
+          if (q.max_level >= 0 && kp.octave > q.max_level) ok = false;
+        }
+        const float distx = kp.x - x, disty = kp.y - y;
+        if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+        if (ok && ur) {
+          const float u = ur[idx];
+          if (u > 0) {
+            const float er = fabsf(q.u_r - u);
+            if (er > r) ok = false;
+          }
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) {
+        uint4 d0, d1;
+        load_desc(desc + (size_t)idx * 32, d0, d1);
+        const int rank = rank0 + __popcll(m & ((1ull << lane) - 1ull));
+        fn(rank, idx, hamming256(q0, q1, d0, d1));
+      }
+      rank0 += __popcll(m);
+    }
+  }
+  return rank0;
+}
+
+// One wave per query: candidate lists in enumeration order.
+__global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, QueryBatch Q, orbfe_cand* __restrict__ cand,
+                                                               int32_t* __restrict__ n_cand, int max_cand) {
+  const int f = blockIdx.y;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= Q.n[f]) return;
+  const orbfe_query* qp = Q.q + (size_t)f * Q.cap + qi;
+  const orbfe_query q = *qp;
+  orbfe_cand* out = cand + ((size_t)f * Q.cap + qi) * max_cand;
+  int total = 0;
+  if (q.valid) {
+    uint4 q0, q1;
+    load_desc4(qp->desc, q0, q1);
+    total = enumerate_window(F, f, q, q0, q1, [&](int rank, int idx, int dist) {
+      if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist; }
+    });
+  }
+  if ((threadIdx.x & 63) == 0) n_cand[(size_t)f * Q.cap + qi] = total;
+}
+
+// ComputeThreeMaxima (L/src/ORBmatcher.cc:1506-1538)
+__device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = ind2 = ind3 = -1;
+  for (int i = 0; i < L; i++) {
+    const int s = hs[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// One wave per frame walks the queries IN ORDER (assignments of earlier queries block candidates of later
+// ones).  Per query the lanes take its stored candidates (or, when the list was truncated, re-enumerate the
+// window), drop blocked ones and min-reduce the key (dist << 16 | rank).
+// mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)  -- best/second with the same-level ratio test
+// mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, TH_HIGH, rotation histogram
+__global__ __launch_bounds__(64) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
+                                                           const int32_t* __restrict__ n_cand, int max_cand, int mode,
+                                                           float nnratio, int check_ori, uint8_t* __restrict__ blocked_all,
+                                                           int32_t* __restrict__ assigned_all, int32_t* __restrict__ n_matches,
+                                                           int32_t* __restrict__ push_idx_all, uint8_t* __restrict__ push_bin_all) {
+  __shared__ int hist[ORBFE_HISTO_LENGTH];
+  extern __shared__ uint8_t blocked[];  // F.cap bytes: F.mvpMapPoints[idx]->Observations() > 0
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int nq = Q.n[f];
+  uint8_t* blocked_g = blocked_all + (size_t)f * F.cap;
+  for (int i = lane; i < F.cap; i += WAVE) blocked[i] = blocked_g[i];
+  int32_t* assigned = assigned_all + (size_t)f * F.cap;
+  int32_t* push_idx = push_idx_all + (size_t)f * Q.cap;
+  uint8_t* push_bin = push_bin_all + (size_t)f * Q.cap;
+  const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
+  if (lane < ORBFE_HISTO_LENGTH) hist[lane] = 0;
+  __syncthreads();
+  int nmatches = 0, npush = 0;
+  for (int qi = 0; qi < nq; qi++) {
+    const orbfe_query* qp = Q.q + (size_t)f * Q.cap + qi;
+    if (!qp->valid) continue;
+    const int total = n_cand[(size_t)f * Q.cap + qi];
+    if (total == 0) continue;
+    // lane-local best / second keys; key = dist<<16 | rank, payload = idx
+    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    int i1 = -1, i2 = -1;
+    auto consider = [&](int rank, int idx, int dist) {
+      if (blocked[idx]) return;
+      const unsigned key = ((unsigned)dist << 16) | (unsigned)rank;
+      if (key < k1) { k2 = k1; i2 = i1; k1 = key; i1 = idx; }
+      else if (key < k2) { k2 = key; i2 = idx; }
+    };
+    if (total <= max_cand) {
+      const orbfe_cand* cl = cand + ((size_t)f * Q.cap + qi) * max_cand;
+      for (int c = lane; c < total; c += WAVE) consider(c, cl[c].idx, cl[c].dist);
+    } else {
+      const orbfe_query q = *qp;
+      uint4 q0, q1;
+      load_desc4(qp->desc, q0, q1);
+      enumerate_window(F, f, q, q0, q1, consider);
+    }
+    const unsigned b = wave_min_u32(k1);
+    if (b == 0xFFFFFFFFu) continue;  // every candidate blocked: bestDist stays 256
+    const unsigned long long wm = __ballot(k1 == b);
+    const int wl = __ffsll((long long)wm) - 1;
+    const int bestIdx = __shfl(i1, wl, WAVE);
+    const int bestDist = (int)(b >> 16);
+    bool accept = false;
+    if (mode == 0) {
+      // second = minimum key over everything but the winner
+      const unsigned mine = (lane == wl) ? k2 : k1;
+      const int mine_i = (lane == wl) ? i2 : i1;
+      const unsigned s = wave_min_u32(mine);
+      int bestDist2 = 256, bestLevel2 = -1;
+      if (s != 0xFFFFFFFFu) {
+        const unsigned long long sm = __ballot(mine == s);
+        const int sl = __ffsll((long long)sm) - 1;
+        const int secIdx = __shfl(mine_i, sl, WAVE);
+        bestDist2 = (int)(s >> 16);
+        bestLevel2 = keys[secIdx].octave;
+      }
+      const int bestLevel = keys[bestIdx].octave;
+      if (bestDist <= ORBFE_TH_HIGH) {
+        if (!(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) accept = true;
+      }
+    } else {
+      accept = bestDist <= ORBFE_TH_HIGH;
+    }
+    if (accept) {
+      if (lane == 0) {
+        assigned[bestIdx] = qi;
+        blocked[bestIdx] = (uint8_t)(qp->blocks != 0);
+        if (mode == 1 && check_ori) {
+          float rot = qp->angle - keys[bestIdx].angle;
+          if (rot < 0.0f) rot += 360.0f;
+          int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));  // the reference's factor (sic), :1255
+          if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+          push_idx[npush] = bestIdx;
+          push_bin[npush] = (uint8_t)bin;
+          hist[bin]++;
+        }
+      }
+      nmatches++;
+      npush++;
+    }
+    __syncthreads();  // single wave: lane 0's LDS store to blocked[] is ordered before the next query's reads
+  }
+  for (int i = lane; i < F.cap; i += WAVE) blocked_g[i] = blocked[i];
+  if (mode == 1 && check_ori) {
+    __syncthreads();
+    if (lane == 0) {
+      int i1, i2, i3;
+      three_maxima(hist, ORBFE_HISTO_LENGTH, i1, i2, i3);
+      for (int k = 0; k < npush; k++) {
+        const int bin = push_bin[k];
+        if (bin != i1 && bin != i2 && bin != i3) { assigned[push_idx[k]] = -1; nmatches--; }
+      }
+    }
+  }
+  if (lane == 0) n_matches[f] = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------ stereo
+// One wave per left keypoint.  Candidates = right keypoints whose row band [floor(y-r), ceil(y+r)],
+// r = 2*scale[octave], contains row (int)vL -- in ascending right index, which is the order the reference's
+// row table yields them (L/src/Frame.cc:493-502).
+__global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
+  const int pair = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (iL >= P.cap) return;
+  float* out_ur = P.u_right + (size_t)pair * P.cap;
+  float* out_depth = P.depth + (size_t)pair * P.cap;
+  int32_t* out_sad = P.sad + (size_t)pair * P.cap;
+  const int nL = P.nL[pair], nR = P.nR[pair];
+  if (lane == 0) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
+  if (iL >= nL) return;
+  const orbfe_keypoint* kl = P.kpsL + (size_t)pair * P.cap;
+  const orbfe_keypoint* kr = P.kpsR + (size_t)pair * P.cap;
+  const uint8_t* dl = P.descL + (size_t)pair * P.cap * 32;
+  const uint8_t* dr = P.descR + (size_t)pair * P.cap * 32;
+  const orbfe_keypoint kpL = kl[iL];
+  const int levelL = kpL.octave;
+  const float vL = kpL.y, uL = kpL.x;
+  const int nRows = P.pyrL.h[0];
+  const int row = (int)vL;
+  if (row < 0 || row >= nRows) return;
+  const float minD = 0, maxD = P.maxD;
+  const float minU = uL - maxD, maxU = uL - minD;
+  if (maxU < 0) return;
+  uint4 a0, a1;
+  load_desc(dl + (size_t)iL * 32, a0, a1);
+  unsigned best = ((unsigned)ORBFE_TH_HIGH << 16);  // bestDist starts at TH_HIGH; strict <
+  for (int iR = lane; iR < nR; iR += WAVE) {
+    const orbfe_keypoint kpR = kr[iR];
+    const float r = 2.0f * P.scale[kpR.octave];
+    const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+    if (row < minr || row > maxr) continue;
+    if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+    if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
+    uint4 b0, b1;
+    load_desc(dr + (size_t)iR * 32, b0, b1);
+    const unsigned key = ((unsigned)hamming256(a0, a1, b0, b1) << 16) | (unsigned)iR;
+    if ((key >> 16) < (best >> 16)) best = key;
+  }
+  // first minimum in index order
+  {
+    unsigned k = ((best >> 16) < (unsigned)ORBFE_TH_HIGH) ? best : 0xFFFFFFFFu;
+    best = wave_min_u32(k);
+  }
+  if (best == 0xFFFFFFFFu) return;
+  const int bestDist = (int)(best >> 16);
+  const int bestIdxR = (int)(best & 0xffff);
+  const int thOrbDist = (ORBFE_TH_HIGH + ORBFE_TH_LOW) / 2;
+  if (!(bestDist < thOrbDist)) return;
+
+  // sub-pixel refinement by 11x11 SAD over 11 shifts (L/src/Frame.cc:557-631)
+  const float uR0 = kr[bestIdxR].x;
+  const float sfac = P.inv_scale[levelL];
+  const float scaleduL = roundf(kpL.x * sfac);
+  const float scaledvL = roundf(kpL.y * sfac);
+  const float scaleduR0 = roundf(uR0 * sfac);
+  const int w = 5, L = 5;
+  const float iniu = scaleduR0 + L - w;
+  const float endu = scaleduR0 + L + w + 1;
+  if (iniu < 0 || endu >= (float)P.pyrR.w[levelL]) return;
+  const int yL0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w), xRc = (int)scaleduR0;
+  // the reference reads these windows unchecked (cv::Mat::rowRange/colRange would throw); treat as no match
+  if (yL0 < 0 || yL0 + 2 * w >= P.pyrL.h[levelL] || xL0 < 0 || xL0 + 2 * w >= P.pyrL.w[levelL] ||
+      xRc - L - w < 0 || xRc + L + w >= P.pyrR.w[levelL] || yL0 + 2 * w >= P.pyrR.h[levelL])
+    return;
+  const uint8_t* imL = P.pyrL.base[levelL] + (size_t)pair * P.pyrL.img_stride[levelL];
+  const uint8_t* imR = P.pyrR.base[levelL] + (size_t)pair * P.pyrR.img_stride[levelL];
+  const int sL = P.pyrL.pitch[levelL], sR = P.pyrR.pitch[levelL];
+  const int cL = imL[(size_t)(yL0 + w) * sL + xL0 + w];
+  int acc[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) acc[k] = 0;
+  for (int p = lane; p < 121; p += WAVE) {
+    const int yy = p / 11, xx = p - yy * 11;
+    const int a = (int)imL[(size_t)(yL0 + yy) * sL + xL0 + xx] - cL;
+    const uint8_t* rrow = imR + (size_t)(yL0 + yy) * sR + (xRc - L - w) + xx;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const int cR = imR[(size_t)(yL0 + w) * sR + (xRc - L + k)];
+      const int b = (int)rrow[k] - cR;
+      const int d = a - b;
+      acc[k] += d < 0 ? -d : d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 11; k++) acc[k] = wave_sum_i32(acc[k]);
+  if (lane != 0) return;
+  int sadBest = 2147483647, bestincR = 0;
+  float vDists[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) {
+    const float dist = (float)acc[k];
+    if (dist < (float)sadBest) { sadBest = (int)dist; bestincR = k - L; }
+    vDists[k] = dist;
+  }
+  if (bestincR == -L || bestincR == L) return;
+  const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+  const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+  if (deltaR < -1 || deltaR > 1) return;
+  float bestuR = P.scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+  float disparity = (uL - bestuR);
+  if (disparity >= minD && disparity < maxD) {
+    if (disparity <= 0) {
+      disparity = (float)0.01;
+      bestuR = (float)((double)uL - 0.01);
+    }
+    out_depth[iL] = P.mbf / disparity;
+    out_ur[iL] = bestuR;
+    out_sad[iL] = sadBest;
+  }
+}
+
+// One block per stereo pair: the reference sorts (SAD, iL) pairs, takes the element at size/2 as the
+// median and drops every match with SAD >= 1.5*1.4*median (L/src/Frame.cc:634-645).  The order statistic
+// is found by a two-level 256-bin radix select (SAD <= 121*510 < 65536).
+__global__ __launch_bounds__(256) void stereo_median_kernel(StereoParams P) {
+  __shared__ int hist[256];
+  __shared__ int sh[4];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int nL = P.nL[pair];
+  float* out_ur = P.u_right + (size_t)pair * P.cap;
+  float* out_depth = P.depth + (size_t)pair * P.cap;
+  const int32_t* sad = P.sad + (size_t)pair * P.cap;
+  hist[tid] = 0;
+  if (tid == 0) sh[0] = 0;
+  __syncthreads();
+  int cntv = 0;
+  for (int i = tid; i < nL; i += 256) {
+    const int s = sad[i];
+    if (s >= 0) { atomicAdd(&hist[(s >> 8) & 0xff], 1); cntv++; }
+  }
+  atomicAdd(&sh[0], cntv);
+  __syncthreads();
+  const int total = sh[0];
+  if (total == 0) { if (tid == 0) P.n_matched[pair] = 0; return; }
+  const int k = total / 2;  // 0-based rank
+  if (tid == 0) {
+    int run = 0, hb = 0;
+    for (; hb < 256; hb++) { if (run + hist[hb] > k) break; run += hist[hb]; }
+    sh[1] = hb;
+    sh[2] = k - run;
+  }
+  __syncthreads();
+  const int hb = sh[1], k2 = sh[2];
+  __syncthreads();
+  hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < nL; i += 256) {
+    const int s = sad[i];
+    if (s >= 0 && ((s >> 8) & 0xff) == hb) atomicAdd(&hist[s & 0xff], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0, lb = 0;
+    for (; lb < 256; lb++) { if (run + hist[lb] > k2) break; run += hist[lb]; }
+    sh[3] = (hb << 8) | lb;
+    sh[0] = 0;
+  }
+  __syncthreads();
+  const float median = (float)sh[3];
+  const float thDist = 1.5f * 1.4f * median;
+  int kept = 0;
+  for (int i = tid; i < nL; i += 256) {
+    const int s = sad[i];
+    if (s >= 0) {
+      if ((float)s < thDist) kept++;
+      else { out_ur[i] = -1; out_depth[i] = -1; }
+    }
+  }
+  atomicAdd(&sh[0], kept);
+  __syncthreads();
+  if (tid == 0) P.n_matched[pair] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s) {
+  if (nA < 1 || nB < 1) return;
+  dim3 grid((nB + 255) / 256, (nA + 63) / 64);
+  hipLaunchKernelGGL(hamming_matrix_kernel, grid, dim3(256), 0, s, A, nA, B, nB, out);
+}
+void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s) {
+  if (max_nA < 1 || n_sets < 1) return;
+  dim3 grid((max_nA + 31) / 32, n_sets);
+  hipLaunchKernelGGL(hamming_bf_kernel, grid, dim3(256), 0, s, p);
+}
+void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {
+  hipLaunchKernelGGL(grid_build_kernel, dim3(n_frames), dim3(256), 0, s, f);
+}
+void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
+                                  int max_cand, int n_frames, hipStream_t s) {
+  if (q.cap < 1) return;
+  dim3 grid((q.cap + 3) / 4, n_frames);
+  hipLaunchKernelGGL(proj_candidates_kernel, grid, dim3(256), 0, s, f, q, cand, n_cand, max_cand);
+}
+void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
+                               int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
+                               int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s) {
+  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(64), (size_t)((f.cap + 15) & ~15), s, f, q, cand, n_cand, max_cand, mode, nnratio,
+                     check_ori, blocked, assigned, n_matches, push_idx, push_bin);
+}
+void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {
+  dim3 grid((p.cap + 3) / 4, n_pairs);
+  hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, p);
+}

@@ -1,0 +1,372 @@
+// matcher.cpp -- host side of liborbfe's ORBmatcher path: work-space handle, kernel sequencing, C ABI.
+// No CPU fallback: everything that computes runs in match_kernels.hip.
+//
+// Reference behaviour (L/ = Source/Libraries/ORB_SLAM2/):
+//   DescriptorDistance                         L/src/ORBmatcher.cc:1542-1556
+//   SearchByProjection(Frame&, MapPoints)      L/src/ORBmatcher.cc:45-128
+//   SearchByProjection(Frame& cur, last)       L/src/ORBmatcher.cc:1247-1383
+//   SearchByBoW inner loops                    L/src/ORBmatcher.cc:201-222
+//   Frame grid + GetFeaturesInArea             L/src/Frame.cc:250-263,341-410
+//   Frame::ComputeStereoMatches                L/src/Frame.cc:477-646
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "match_internal.h"
+
+void orbfe_set_error(const char* fmt, ...);
+int orbfe_internal_pyr_view(const orbfe_extractor* e, PyrView* v, int* n_images);
+int orbfe_internal_tables(const orbfe_extractor* e, float* scale, float* inv_scale, int* n_levels, int* device);
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      orbfe_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return ORBFE_ERR_HIP;                                                                       \
+    }                                                                                             \
+  } while (0)
+
+#define ORBFE_MAX_CAND 64  // stored candidates per query; longer lists are re-enumerated by the resolver
+
+struct MBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+static int mb_alloc(MBuf& b, size_t bytes) {
+  if (b.p && bytes <= b.bytes) return ORBFE_OK;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  if (bytes < 256) bytes = 256;
+  HIPCHK(hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return ORBFE_OK;
+}
+
+struct orbfe_matcher {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // scratch
+  MBuf cell_start, cell_idx, cand, n_cand, push_idx, push_bin, sad;
+  // staging for the host-pointer entry points
+  MBuf h_keys, h_desc, h_ur, h_q, h_n, h_nq, h_blocked, h_assigned, h_nm;
+  std::mutex mu;
+};
+
+extern "C" int orbfe_matcher_create(int device, orbfe_matcher** out) {
+  if (!out) return ORBFE_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    orbfe_set_error("no HIP device available (liborbfe has no CPU fallback)");
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+  if (device >= ndev) return ORBFE_ERR_INVALID;
+  HIPCHK(hipSetDevice(device));
+  orbfe_matcher* m = new orbfe_matcher();
+  m->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    orbfe_set_error("hipStreamCreate: %s", hipGetErrorString(e));
+    delete m;
+    return ORBFE_ERR_HIP;
+  }
+  *out = m;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_matcher_destroy(orbfe_matcher* m) {
+  if (!m) return ORBFE_OK;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->h_keys,
+                  &m->h_desc, &m->h_ur, &m->h_q, &m->h_n, &m->h_nq, &m->h_blocked, &m->h_assigned, &m->h_nm};
+  for (auto b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_matcher_sync(orbfe_matcher* m) {
+  if (!m) return ORBFE_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return ORBFE_OK;
+}
+
+static int launch_ok() {
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    orbfe_set_error("kernel launch failed: %s", hipGetErrorString(le));
+    return ORBFE_ERR_HIP;
+  }
+  return ORBFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Hamming
+extern "C" int orbfe_hamming_matrix_device(const uint8_t* d_A, int nA, const uint8_t* d_B, int nB, uint16_t* d_dist,
+                                           void* stream) {
+  if (!d_A || !d_B || !d_dist || nA < 0 || nB < 0) return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_A & 15) || ((uintptr_t)d_B & 15)) {
+    orbfe_set_error("descriptor matrices must be 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  orbfe_launch_hamming_matrix(d_A, nA, d_B, nB, d_dist, (hipStream_t)stream);
+  return launch_ok();
+}
+
+extern "C" int orbfe_hamming_bf_device(const uint8_t* d_A, const int32_t* d_nA, int strideA, int max_nA,
+                                       const uint8_t* d_B, const int32_t* d_nB, int strideB, const int32_t* d_groupA,
+                                       const int32_t* d_groupB, const uint8_t* d_maskB, int n_sets, orbfe_bf_match* d_out,
+                                       void* stream) {
+  if (!d_A || !d_B || !d_nA || !d_nB || !d_out || n_sets < 1 || max_nA < 0 || strideA < max_nA) return ORBFE_ERR_INVALID;
+  if ((d_groupA == nullptr) != (d_groupB == nullptr) || strideB >= 65536) {
+    orbfe_set_error("groupA/groupB must be given together; strideB must be < 65536");
+    return ORBFE_ERR_INVALID;
+  }
+  if (((uintptr_t)d_A & 15) || ((uintptr_t)d_B & 15)) {
+    orbfe_set_error("descriptor matrices must be 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  HammingBfParams p{d_A, d_nA, strideA, d_B, d_nB, strideB, d_groupA, d_groupB, d_maskB, d_out};
+  orbfe_launch_hamming_bf(p, max_nA, n_sets, (hipStream_t)stream);
+  return launch_ok();
+}
+
+// ------------------------------------------------------------------------------------------------ projection
+static int ensure_proj_scratch(orbfe_matcher* m, int n_frames, int cap, int q_cap) {
+  int rc;
+  const size_t F = (size_t)n_frames;
+  if ((rc = mb_alloc(m->cell_start, F * (GRID_CELLS + 1) * sizeof(int32_t)))) return rc;
+  if ((rc = mb_alloc(m->cell_idx, F * cap * sizeof(int32_t)))) return rc;
+  if ((rc = mb_alloc(m->cand, F * q_cap * ORBFE_MAX_CAND * sizeof(orbfe_cand)))) return rc;
+  if ((rc = mb_alloc(m->n_cand, F * q_cap * sizeof(int32_t)))) return rc;
+  if ((rc = mb_alloc(m->push_idx, F * q_cap * sizeof(int32_t)))) return rc;
+  if ((rc = mb_alloc(m->push_bin, F * q_cap))) return rc;
+  return ORBFE_OK;
+}
+
+static void fill_frame_batch(orbfe_matcher* m, FrameBatch& fb, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                             const int32_t* d_n, const float* d_ur, int cap, float min_x, float max_x, float min_y,
+                             float max_y) {
+  fb.keys = d_kps;
+  fb.desc = d_desc;
+  fb.u_right = d_ur;
+  fb.n = d_n;
+  fb.cell_start = (int32_t*)m->cell_start.p;
+  fb.cell_idx = (int32_t*)m->cell_idx.p;
+  fb.cap = cap;
+  fb.min_x = min_x;
+  fb.min_y = min_y;
+  // mfGridElementWidthInv / HeightInv, L/src/Frame.cc:109-112
+  fb.gw_inv = (float)ORBFE_GRID_COLS / (max_x - min_x);
+  fb.gh_inv = (float)ORBFE_GRID_ROWS / (max_y - min_y);
+}
+
+static int proj_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                        const int32_t* d_n, const float* d_ur, int cap, float min_x, float max_x, float min_y,
+                        float max_y, const orbfe_query* d_q, const int32_t* d_nq, int q_cap, int mode, float nnratio,
+                        int check_ori, uint8_t* d_blocked, int32_t* d_assigned, int32_t* d_nm, bool resolve,
+                        hipStream_t s) {
+  if (cap > 60000) {
+    orbfe_set_error("frame capacity %d too large (LDS-resident blocked[] needs cap <= 60000)", cap);
+    return ORBFE_ERR_INVALID;
+  }
+  if (((uintptr_t)d_desc & 15) || ((uintptr_t)d_q & 3) || ((uintptr_t)d_kps & 3)) {
+    orbfe_set_error("descriptors must be 16-byte aligned, queries/keypoints 4-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  int rc;
+  if ((rc = ensure_proj_scratch(m, n_frames, cap, q_cap))) return rc;
+  FrameBatch fb;
+  fill_frame_batch(m, fb, d_kps, d_desc, d_n, d_ur, cap, min_x, max_x, min_y, max_y);
+  QueryBatch qb{d_q, d_nq, q_cap};
+  orbfe_launch_grid_build(fb, n_frames, s);
+  orbfe_launch_proj_candidates(fb, qb, (orbfe_cand*)m->cand.p, (int32_t*)m->n_cand.p, ORBFE_MAX_CAND, n_frames, s);
+  if (resolve)
+    orbfe_launch_proj_resolve(fb, qb, (const orbfe_cand*)m->cand.p, (const int32_t*)m->n_cand.p, ORBFE_MAX_CAND, mode,
+                              nnratio, check_ori, d_blocked, d_assigned, d_nm, (int32_t*)m->push_idx.p,
+                              (uint8_t*)m->push_bin.p, n_frames, s);
+  return launch_ok();
+}
+
+extern "C" int orbfe_proj_match_batch_device(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps,
+                                             const uint8_t* d_desc, const int32_t* d_n, const float* d_u_right, int cap,
+                                             float min_x, float max_x, float min_y, float max_y, const orbfe_query* d_q,
+                                             const int32_t* d_nq, int q_cap, int mode, float nnratio,
+                                             int check_orientation, uint8_t* d_blocked, int32_t* d_assigned,
+                                             int32_t* d_n_matches, void* stream) {
+  if (!m || !d_kps || !d_desc || !d_n || !d_q || !d_nq || !d_blocked || !d_assigned || !d_n_matches || n_frames < 1 ||
+      cap < 1 || q_cap < 1 || (mode != 0 && mode != 1) || !(max_x > min_x) || !(max_y > min_y))
+    return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+  return proj_enqueue(m, n_frames, d_kps, d_desc, d_n, d_u_right, cap, min_x, max_x, min_y, max_y, d_q, d_nq, q_cap, mode,
+                      nnratio, check_orientation, d_blocked, d_assigned, d_n_matches, true, s);
+}
+
+// thread-local handle behind the handle-less host entry points
+// (not destroyed at thread exit: the HIP runtime may already be gone when thread_local destructors of the
+// main thread run; the leak is bounded by the number of threads that ever called the matcher)
+struct TlsMatcher {
+  orbfe_matcher* m = nullptr;
+};
+static int tls_matcher(orbfe_matcher** out) {
+  static thread_local TlsMatcher t;
+  if (!t.m) {
+    int rc = orbfe_matcher_create(-1, &t.m);
+    if (rc) return rc;
+  }
+  *out = t.m;
+  return ORBFE_OK;
+}
+
+// uploads one host frame + queries; returns device pointers inside the handle's staging buffers
+static int stage_host(orbfe_matcher* m, const orbfe_frame_view* f, const orbfe_query* q, int nq, hipStream_t s) {
+  int rc;
+  const int n = std::max(f->n, 1), nqq = std::max(nq, 1);
+  if ((rc = mb_alloc(m->h_keys, sizeof(orbfe_keypoint) * n))) return rc;
+  if ((rc = mb_alloc(m->h_desc, (size_t)32 * n))) return rc;
+  if ((rc = mb_alloc(m->h_ur, sizeof(float) * n))) return rc;
+  if ((rc = mb_alloc(m->h_q, sizeof(orbfe_query) * nqq))) return rc;
+  if ((rc = mb_alloc(m->h_n, 16))) return rc;
+  if ((rc = mb_alloc(m->h_nq, 16))) return rc;
+  if ((rc = mb_alloc(m->h_blocked, (size_t)n + 16))) return rc;
+  if ((rc = mb_alloc(m->h_assigned, sizeof(int32_t) * n))) return rc;
+  if ((rc = mb_alloc(m->h_nm, 16))) return rc;
+  if (f->n > 0) {
+    HIPCHK(hipMemcpyAsync(m->h_keys.p, f->keys_un, sizeof(orbfe_keypoint) * f->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->h_desc.p, f->desc, (size_t)32 * f->n, hipMemcpyHostToDevice, s));
+    if (f->u_right) HIPCHK(hipMemcpyAsync(m->h_ur.p, f->u_right, sizeof(float) * f->n, hipMemcpyHostToDevice, s));
+  }
+  if (nq > 0) HIPCHK(hipMemcpyAsync(m->h_q.p, q, sizeof(orbfe_query) * nq, hipMemcpyHostToDevice, s));
+  int32_t nn = f->n, nnq = nq;
+  HIPCHK(hipMemcpyAsync(m->h_n.p, &nn, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(m->h_nq.p, &nnq, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // nn / nnq live on this stack frame
+  return ORBFE_OK;
+}
+
+static bool frame_ok(const orbfe_frame_view* f) {
+  return f && f->n >= 0 && (f->n == 0 || (f->keys_un && f->desc)) && f->max_x > f->min_x && f->max_y > f->min_y;
+}
+
+extern "C" int orbfe_proj_candidates(const orbfe_frame_view* f, const orbfe_query* q, int nq, orbfe_cand* cand,
+                                     int32_t* n_cand, int max_cand) {
+  if (!frame_ok(f) || nq < 0 || (nq > 0 && (!q || !cand || !n_cand)) || max_cand < 1) return ORBFE_ERR_INVALID;
+  if (nq == 0) return ORBFE_OK;
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  if ((rc = stage_host(m, f, q, nq, s))) return rc;
+  const int cap = std::max(f->n, 1);
+  if ((rc = ensure_proj_scratch(m, 1, cap, nq))) return rc;
+  // a caller-chosen max_cand needs its own candidate buffer size
+  if ((rc = mb_alloc(m->cand, (size_t)nq * std::max(max_cand, ORBFE_MAX_CAND) * sizeof(orbfe_cand)))) return rc;
+  FrameBatch fb;
+  fill_frame_batch(m, fb, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
+                   f->u_right ? (const float*)m->h_ur.p : nullptr, cap, f->min_x, f->max_x, f->min_y, f->max_y);
+  QueryBatch qb{(const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, nq};
+  orbfe_launch_grid_build(fb, 1, s);
+  orbfe_launch_proj_candidates(fb, qb, (orbfe_cand*)m->cand.p, (int32_t*)m->n_cand.p, max_cand, 1, s);
+  if ((rc = launch_ok())) return rc;
+  HIPCHK(hipMemcpyAsync(cand, m->cand.p, sizeof(orbfe_cand) * (size_t)nq * max_cand, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(n_cand, m->n_cand.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ORBFE_OK;
+}
+
+static int search_host(const orbfe_frame_view* f, const orbfe_query* q, int nq, int mode, float nnratio, int check_ori,
+                       uint8_t* blocked, int32_t* assigned, int* n_matches) {
+  if (!frame_ok(f) || nq < 0 || (nq > 0 && !q) || !blocked || !assigned || !n_matches) return ORBFE_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || f->n == 0) return ORBFE_OK;
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  if ((rc = stage_host(m, f, q, nq, s))) return rc;
+  HIPCHK(hipMemcpyAsync(m->h_blocked.p, blocked, f->n, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(m->h_assigned.p, assigned, sizeof(int32_t) * f->n, hipMemcpyHostToDevice, s));
+  rc = proj_enqueue(m, 1, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
+                    f->u_right ? (const float*)m->h_ur.p : nullptr, f->n, f->min_x, f->max_x, f->min_y, f->max_y,
+                    (const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, nq, mode, nnratio, check_ori,
+                    (uint8_t*)m->h_blocked.p, (int32_t*)m->h_assigned.p, (int32_t*)m->h_nm.p, true, s);
+  if (rc) return rc;
+  int32_t nm = 0;
+  HIPCHK(hipMemcpyAsync(blocked, m->h_blocked.p, f->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(assigned, m->h_assigned.p, sizeof(int32_t) * f->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&nm, m->h_nm.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_matches = nm;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_projection_points(const orbfe_frame_view* f, const orbfe_query* q, int nq, float nnratio,
+                                                 uint8_t* blocked, int32_t* assigned, int* n_matches) {
+  return search_host(f, q, nq, 0, nnratio, 0, blocked, assigned, n_matches);
+}
+extern "C" int orbfe_search_by_projection_frame(const orbfe_frame_view* f, const orbfe_query* q, int nq,
+                                                int check_orientation, uint8_t* blocked, int32_t* assigned,
+                                                int* n_matches) {
+  return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches);
+}
+
+// ------------------------------------------------------------------------------------------------ stereo
+extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
+                                         const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                                         const orbfe_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r,
+                                         int cap, float mbf, float mb, float* d_u_right, float* d_depth,
+                                         int32_t* d_n_matched, void* stream) {
+  if (!m || !left || !right || n_pairs < 1 || !d_kps_l || !d_desc_l || !d_n_l || !d_kps_r || !d_desc_r || !d_n_r ||
+      cap < 1 || cap >= 65536 || !d_u_right || !d_depth || !d_n_matched || !(mb > 0))
+    return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_desc_l & 15) || ((uintptr_t)d_desc_r & 15)) {
+    orbfe_set_error("descriptor matrices must be 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  StereoParams p;
+  memset(&p, 0, sizeof(p));
+  int nl = 0, nr = 0, il = 0, ir = 0, devl = 0, devr = 0;
+  int rc;
+  if ((rc = orbfe_internal_pyr_view(left, &p.pyrL, &il)) || (rc = orbfe_internal_pyr_view(right, &p.pyrR, &ir))) {
+    orbfe_set_error("stereo match needs both extractors to have processed a device batch");
+    return ORBFE_ERR_INVALID;
+  }
+  float sr[ORBFE_MAX_LEVELS], isr[ORBFE_MAX_LEVELS];
+  orbfe_internal_tables(left, p.scale, p.inv_scale, &nl, &devl);
+  orbfe_internal_tables(right, sr, isr, &nr, &devr);
+  if (nl != nr || devl != m->device || devr != m->device || il < n_pairs || ir < n_pairs) {
+    orbfe_set_error("stereo match: extractors must share levels/device and hold >= n_pairs images");
+    return ORBFE_ERR_INVALID;
+  }
+  for (int l = 0; l < nl; l++)
+    if (p.pyrL.w[l] != p.pyrR.w[l] || p.pyrL.h[l] != p.pyrR.h[l]) {
+      orbfe_set_error("stereo match: left/right pyramids differ in size");
+      return ORBFE_ERR_INVALID;
+    }
+  if ((rc = mb_alloc(m->sad, sizeof(int32_t) * (size_t)n_pairs * cap))) return rc;
+  p.kpsL = d_kps_l; p.descL = d_desc_l; p.nL = d_n_l;
+  p.kpsR = d_kps_r; p.descR = d_desc_r; p.nR = d_n_r;
+  p.cap = cap;
+  p.mbf = mbf;
+  p.maxD = mbf / mb;  // minZ = mb, maxD = mbf / minZ (L/src/Frame.cc:505-507)
+  p.u_right = d_u_right;
+  p.depth = d_depth;
+  p.sad = (int32_t*)m->sad.p;
+  p.n_matched = d_n_matched;
+  orbfe_launch_stereo(p, n_pairs, stream ? (hipStream_t)stream : m->stream);
+  return launch_ok();
+}

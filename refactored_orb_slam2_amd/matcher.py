@@ -1,0 +1,237 @@
+"""Host-side mirror of ORB_SLAM2::ORBmatcher (+ the Frame helpers it reads) over the C ABI of liborbfe.so.
+
+Method names and argument meaning follow Source/Libraries/ORB_SLAM2/include/ORBmatcher.h:34-114; SLAM
+objects (Frame, MapPoint, KeyFrame) are replaced by plain arrays: a FrameView carries mvKeysUn /
+mDescriptors / mvuRight / image bounds, queries carry one projected map point each (``QUERY_DTYPE``).
+PyTorch is used only to hold device memory.  All distance / window / assignment work runs in HIP kernels;
+SearchByBoW's order-dependent pass replays on the host over the device-computed distance matrix.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BF_DTYPE, CAND_DTYPE, KP_DTYPE, QUERY_DTYPE
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+
+class FrameView:
+    """mvKeysUn, mDescriptors, mvuRight and mnMin/Max of a Frame (host arrays)."""
+
+    def __init__(self, keys_un, desc, min_x, max_x, min_y, max_y, u_right=None):
+        self.keys = np.ascontiguousarray(keys_un, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        self.bounds = (float(min_x), float(max_x), float(min_y), float(max_y))
+        v = _lib.FrameView()
+        v.n = len(self.keys)
+        v.keys_un = self.keys.ctypes.data
+        v.desc = self.desc.ctypes.data
+        v.u_right = None if self.u_right is None else self.u_right.ctypes.data
+        v.min_x, v.max_x, v.min_y, v.max_y = self.bounds
+        self.c = v
+
+    @property
+    def n(self):
+        return len(self.keys)
+
+
+def make_queries(n: int) -> np.ndarray:
+    q = np.zeros(n, QUERY_DTYPE)
+    q["valid"] = 1
+    q["min_level"] = -1
+    q["max_level"] = -1
+    return q
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio: float = 0.6, checkOri: bool = True):
+        self.mfNNratio = float(np.float32(nnratio))
+        self.mbCheckOrientation = bool(checkOri)
+        self._L = _lib.lib()
+
+    # ---- DescriptorDistance for all pairs (device)
+    @staticmethod
+    def DescriptorDistanceMatrix(A, B) -> np.ndarray:
+        import torch
+        L = _lib.lib()
+        dA = torch.from_numpy(np.ascontiguousarray(A, np.uint8).reshape(-1, 32)).cuda()
+        dB = torch.from_numpy(np.ascontiguousarray(B, np.uint8).reshape(-1, 32)).cuda()
+        out = torch.zeros((dA.shape[0], dB.shape[0]), dtype=torch.int16, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.orbfe_hamming_matrix_device(_lib.ptr(dA), dA.shape[0], _lib.ptr(dB), dB.shape[0], _lib.ptr(out),
+                                                 C.c_void_p(s)), "orbfe_hamming_matrix_device")
+        torch.cuda.synchronize()
+        return out.cpu().numpy().astype(np.int32)
+
+    @staticmethod
+    def DescriptorDistance(a, b) -> int:
+        return int(ORBmatcher.DescriptorDistanceMatrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32))[0, 0])
+
+    @staticmethod
+    def BruteForce(A, B, groupA=None, groupB=None, maskB=None) -> np.ndarray:
+        """Best / second-best of every row of A over B (device); returns BF_DTYPE records."""
+        import torch
+        L = _lib.lib()
+        A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32); B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        nA = torch.tensor([len(A)], dtype=torch.int32, device="cuda")
+        nB = torch.tensor([len(B)], dtype=torch.int32, device="cuda")
+        gA = None if groupA is None else torch.from_numpy(np.ascontiguousarray(groupA, np.int32)).cuda()
+        gB = None if groupB is None else torch.from_numpy(np.ascontiguousarray(groupB, np.int32)).cuda()
+        mB = None if maskB is None else torch.from_numpy(np.ascontiguousarray(maskB, np.uint8)).cuda()
+        out = torch.zeros((max(len(A), 1), 3), dtype=torch.int32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.orbfe_hamming_bf_device(_lib.ptr(dA), _lib.ptr(nA), max(len(A), 1), len(A), _lib.ptr(dB), _lib.ptr(nB),
+                                             max(len(B), 1), _lib.ptr(gA), _lib.ptr(gB), _lib.ptr(mB), 1, _lib.ptr(out),
+                                             C.c_void_p(s)), "orbfe_hamming_bf_device")
+        torch.cuda.synchronize()
+        return out.cpu().numpy()[: len(A)].copy().view(BF_DTYPE).reshape(-1)
+
+    # ---- window query (Frame::GetFeaturesInArea + distances)
+    def ProjCandidates(self, frame: FrameView, queries: np.ndarray, max_cand: int = 64):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        cand = np.zeros((len(q), max_cand), CAND_DTYPE)
+        n = np.zeros(len(q), np.int32)
+        _lib.check(self._L.orbfe_proj_candidates(C.byref(frame.c), _lib.ptr(q), len(q), _lib.ptr(cand), _lib.ptr(n),
+                                                 max_cand), "orbfe_proj_candidates")
+        return cand, n
+
+    # ---- SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+    def SearchByProjection(self, frame: FrameView, queries: np.ndarray, blocked=None, assigned=None):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        blocked = np.zeros(frame.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        assigned = np.full(frame.n, -1, np.int32) if assigned is None else np.ascontiguousarray(assigned, np.int32).copy()
+        nm = C.c_int(0)
+        _lib.check(self._L.orbfe_search_by_projection_points(C.byref(frame.c), _lib.ptr(q), len(q), self.mfNNratio,
+                                                             _lib.ptr(blocked), _lib.ptr(assigned), C.byref(nm)),
+                   "orbfe_search_by_projection_points")
+        return nm.value, assigned, blocked
+
+    # ---- SearchByProjection(Frame& cur, const Frame& last, th, bMono)
+    def SearchByProjectionFrame(self, cur: FrameView, queries: np.ndarray, blocked=None, assigned=None):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        blocked = np.zeros(cur.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        assigned = np.full(cur.n, -1, np.int32) if assigned is None else np.ascontiguousarray(assigned, np.int32).copy()
+        nm = C.c_int(0)
+        _lib.check(self._L.orbfe_search_by_projection_frame(C.byref(cur.c), _lib.ptr(q), len(q),
+                                                            int(self.mbCheckOrientation), _lib.ptr(blocked),
+                                                            _lib.ptr(assigned), C.byref(nm)),
+                   "orbfe_search_by_projection_frame")
+        return nm.value, assigned, blocked
+
+    # ---- SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&): ORBmatcher.cc:161-273
+    def SearchByBoW(self, descA, angleA, validA, groupsA: dict, descB, angleB, groupsB: dict):
+        """groupsA/groupsB: {node_id: [feature indices]} (DBoW2::FeatureVector).  Distances of every
+        same-node pair come from the device; the greedy pass (a matched frame feature is skipped by later
+        keyframe features, :208-209) replays on the host in the reference's order."""
+        descA = np.ascontiguousarray(descA, np.uint8).reshape(-1, 32)
+        descB = np.ascontiguousarray(descB, np.uint8).reshape(-1, 32)
+        D = self.DescriptorDistanceMatrix(descA, descB) if len(descA) and len(descB) else np.zeros((len(descA), len(descB)), np.int32)
+        matchB = np.full(len(descB), -1, np.int32)
+        nmatches = 0
+        rot = [[] for _ in range(HISTO_LENGTH)]
+        factor = np.float32(1.0) / np.float32(HISTO_LENGTH)
+        for nid in sorted(set(groupsA) & set(groupsB)):
+            for ia in groupsA[nid]:
+                if not validA[ia]:
+                    continue
+                best1, best2, bidx = 256, 256, -1
+                for jb in groupsB[nid]:
+                    if matchB[jb] >= 0:
+                        continue
+                    d = int(D[ia, jb])
+                    if d < best1:
+                        best2, best1, bidx = best1, d, jb
+                    elif d < best2:
+                        best2 = d
+                if best1 <= TH_LOW and np.float32(best1) < np.float32(self.mfNNratio) * np.float32(best2):
+                    matchB[bidx] = ia
+                    if self.mbCheckOrientation:
+                        r = np.float32(angleA[ia]) - np.float32(angleB[bidx])
+                        if r < 0:
+                            r = np.float32(r + np.float32(360.0))
+                        b = int(np.floor(np.float32(r * factor) + np.float32(0.5)))  # std::round, r >= 0
+                        if b == HISTO_LENGTH:
+                            b = 0
+                        rot[b].append(bidx)
+                    nmatches += 1
+        if self.mbCheckOrientation:
+            i1, i2, i3 = three_maxima([len(r) for r in rot])
+            for i in range(HISTO_LENGTH):
+                if i in (i1, i2, i3):
+                    continue
+                for j in rot[i]:
+                    matchB[j] = -1
+                    nmatches -= 1
+        return nmatches, matchB
+
+
+def three_maxima(sizes):
+    """ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1506-1538)."""
+    max1 = max2 = max3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(sizes):
+        if s > max1:
+            max3, max2, max1 = max2, max1, s
+            i3, i2, i1 = i2, i1, i
+        elif s > max2:
+            max3, max2 = max2, s
+            i3, i2 = i2, i
+        elif s > max3:
+            max3, i3 = s, i
+    if max2 < np.float32(0.1) * np.float32(max1):
+        i2 = i3 = -1
+    elif max3 < np.float32(0.1) * np.float32(max1):
+        i3 = -1
+    return i1, i2, i3
+
+
+class Matcher:
+    """Work-space handle for the device-resident batch entry points (orbfe_matcher)."""
+
+    def __init__(self, device: int = -1):
+        self._L = _lib.lib()
+        self._h = C.c_void_p(None)
+        _lib.check(self._L.orbfe_matcher_create(device, C.byref(self._h)), "orbfe_matcher_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbfe_matcher_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(self._L.orbfe_matcher_sync(self._h), "orbfe_matcher_sync")
+
+    def proj_match_batch(self, kps, desc, n, u_right, bounds, queries, nq, mode, nnratio, check_ori, blocked, assigned,
+                         n_matches, stream=None):
+        """All arguments are torch CUDA tensors: kps (F,cap,28) u8, desc (F,cap,32) u8, n (F) i32, u_right
+        (F,cap) f32 or None, queries (F,qcap,68) u8, nq (F) i32, blocked (F,cap) u8, assigned (F,cap) i32,
+        n_matches (F) i32."""
+        F, cap = desc.shape[0], desc.shape[1]
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(None)
+        _lib.check(self._L.orbfe_proj_match_batch_device(
+            self._h, F, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n), _lib.ptr(u_right), cap, bounds[0], bounds[1], bounds[2],
+            bounds[3], _lib.ptr(queries), _lib.ptr(nq), queries.shape[1], mode, nnratio, int(check_ori), _lib.ptr(blocked),
+            _lib.ptr(assigned), _lib.ptr(n_matches), s), "orbfe_proj_match_batch_device")
+
+    def stereo_match(self, ex_left, ex_right, kps_l, desc_l, n_l, kps_r, desc_r, n_r, mbf, mb, u_right, depth, n_matched,
+                     stream=None):
+        """Frame::ComputeStereoMatches for a batch of pairs (torch CUDA tensors, see proj_match_batch)."""
+        P, cap = desc_l.shape[0], desc_l.shape[1]
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(None)
+        _lib.check(self._L.orbfe_stereo_match_device(
+            self._h, ex_left._h, ex_right._h, P, _lib.ptr(kps_l), _lib.ptr(desc_l), _lib.ptr(n_l), _lib.ptr(kps_r),
+            _lib.ptr(desc_r), _lib.ptr(n_r), cap, mbf, mb, _lib.ptr(u_right), _lib.ptr(depth), _lib.ptr(n_matched), s),
+            "orbfe_stereo_match_device")

@@ -1,0 +1,242 @@
+"""GPU parity of the matcher path (HIP kernels through the C ABI) against the CPU oracle.  Bit-exact bar:
+distances, candidate lists and their order, assignments, match counts; stereo u_right/depth floats equal.
+"""
+import numpy as np
+import pytest
+
+from refactored_orb_slam2_amd import ORBextractor, synth
+from refactored_orb_slam2_amd.matcher import FrameView, Matcher, ORBmatcher, make_queries
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_dist(A, B):
+    x = np.bitwise_xor(A[:, None, :], B[None, :, :])
+    return np.unpackbits(x, axis=2).sum(axis=2).astype(np.int32)
+
+
+def _rand_desc(rng, n):
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+def test_hamming_matrix_and_known_answers():
+    rng = np.random.default_rng(1)
+    A = _rand_desc(rng, 300)
+    B = _rand_desc(rng, 517)
+    A[0] = 0
+    B[0] = 255          # all-zeros vs all-ones = 256
+    B[1] = A[5]         # planted duplicate
+    D = ORBmatcher.DescriptorDistanceMatrix(A, B)
+    assert D[0, 0] == 256 and D[5, 1] == 0
+    np.testing.assert_array_equal(D, _np_dist(A, B))
+    for i, j in [(0, 0), (5, 1), (17, 300), (299, 516)]:
+        assert D[i, j] == ol.descriptor_distance(A[i], B[j])
+    assert ORBmatcher.DescriptorDistance(A[3], B[4]) == ol.descriptor_distance(A[3], B[4])
+
+
+def _seq_best_second(Drow, js):
+    b1, b2, bi = 256, 256, -1
+    for j in js:
+        d = int(Drow[j])
+        if d < b1:
+            b2, b1, bi = b1, d, j
+        elif d < b2:
+            b2 = d
+    return bi, b1, b2
+
+
+@pytest.mark.parametrize("nA,nB", [(1, 1), (33, 700), (1000, 1000), (257, 2049)])
+def test_brute_force_best_second(nA, nB):
+    rng = np.random.default_rng(nA * 7 + nB)
+    A = _rand_desc(rng, nA)
+    B = _rand_desc(rng, nB)
+    if nB > 40:  # ties: identical descriptors at several j -> first index must win, second == best
+        B[30] = B[7]
+        B[nB - 1] = B[7]
+        A[0] = B[7]
+    D = _np_dist(A, B)
+    out = ORBmatcher.BruteForce(A, B)
+    for i in range(nA):
+        bi, b1, b2 = _seq_best_second(D[i], range(nB))
+        assert (out[i]["best_idx"], out[i]["best_dist"], out[i]["second_dist"]) == (bi, b1, b2), i
+    # grouped (vocabulary node ids) + mask of already matched
+    gA = rng.integers(0, 10, nA).astype(np.int32)
+    gB = rng.integers(0, 10, nB).astype(np.int32)
+    mB = (rng.random(nB) < 0.2).astype(np.uint8)
+    out = ORBmatcher.BruteForce(A, B, gA, gB, mB)
+    for i in range(nA):
+        js = [j for j in range(nB) if gB[j] == gA[i] and not mB[j]]
+        bi, b1, b2 = _seq_best_second(D[i], js)
+        assert (out[i]["best_idx"], out[i]["best_dist"], out[i]["second_dist"]) == (bi, b1, b2), i
+
+
+def _two_frames(w, h, nfeat, with_right=False):
+    ex = ORBextractor(nfeat)
+    seq = synth.sequence(w, h, 2, seq=5)
+    (k0, d0), (k1, d1) = ex.extract_batch(seq)
+    sf = ex.GetScaleFactors()
+    ex.close()
+    return k0, d0, k1, d1, sf
+
+
+def _queries_from_last(k0, d0, sf, th, shift=(-2.0, 0.0), rng=None, blocks_p=0.7):
+    rng = rng or np.random.default_rng(3)
+    q = make_queries(len(k0))
+    q["u"] = k0["x"] + np.float32(shift[0]) + rng.normal(0, 0.7, len(k0)).astype(np.float32)
+    q["v"] = k0["y"] + np.float32(shift[1]) + rng.normal(0, 0.7, len(k0)).astype(np.float32)
+    q["u_r"] = q["u"] - np.float32(20.0)
+    q["radius"] = np.float32(th) * sf[k0["octave"]]
+    q["min_level"] = k0["octave"] - 1
+    q["max_level"] = k0["octave"] + 1
+    q["valid"] = (rng.random(len(k0)) < 0.95).astype(np.int32)
+    q["blocks"] = (rng.random(len(k0)) < blocks_p).astype(np.int32)
+    q["angle"] = k0["angle"]
+    q["desc"] = d0
+    return q
+
+
+@pytest.mark.parametrize("geom", [(1241, 376, 2000), (640, 480, 1000)])
+def test_proj_candidates_order_and_distances(geom):
+    w, h, nf = geom
+    k0, d0, k1, d1, sf = _two_frames(w, h, nf)
+    rng = np.random.default_rng(11)
+    ur = np.where(rng.random(len(k1)) < 0.6, k1["x"] - np.float32(20.0) + rng.normal(0, 4, len(k1)).astype(np.float32), np.float32(-1)).astype(np.float32)
+    q = _queries_from_last(k0, d0, sf, 15.0, rng=rng)
+    q["min_level"][::7] = 0
+    q["max_level"][::7] = -1     # bCheckLevels false
+    q["max_level"][3::11] = -1   # only a lower bound
+    fv = FrameView(k1, d1, 0, w, 0, h, ur)
+    of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, ur)
+    m = ORBmatcher()
+    cand, n = m.ProjCandidates(fv, q, max_cand=256)
+    tot = 0
+    for i in range(len(q)):
+        if not q["valid"][i]:
+            assert n[i] == 0
+            continue
+        idx = of.features_in_area(float(q["u"][i]), float(q["v"][i]), float(q["radius"][i]), int(q["min_level"][i]), int(q["max_level"][i]))
+        keep = [j for j in idx if not (ur[j] > 0 and abs(np.float32(q["u_r"][i]) - ur[j]) > q["radius"][i])]
+        assert n[i] == len(keep), i
+        np.testing.assert_array_equal(cand[i, : n[i]]["idx"], np.asarray(keep, np.int32), err_msg=f"query {i}")
+        for c in range(0, n[i], 5):
+            assert cand[i, c]["dist"] == ol.descriptor_distance(q["desc"][i], d1[keep[c]])
+        tot += n[i]
+    assert tot > len(q)  # the test exercises real windows
+
+
+@pytest.mark.parametrize("geom,th", [((1241, 376, 2000), 7.0), ((640, 480, 1000), 15.0), ((640, 480, 1000), 40.0)])
+def test_search_by_projection_frame(geom, th):
+    w, h, nf = geom
+    k0, d0, k1, d1, sf = _two_frames(w, h, nf)
+    rng = np.random.default_rng(5)
+    ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - np.float32(20.0) + rng.normal(0, 3, len(k1)).astype(np.float32), np.float32(-1)).astype(np.float32)
+    q = _queries_from_last(k0, d0, sf, th, rng=rng, blocks_p=0.5)
+    blocked0 = (rng.random(len(k1)) < 0.05).astype(np.uint8)
+    fv = FrameView(k1, d1, 0, w, 0, h, ur)
+    of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, ur)
+    for check in (True, False):
+        nm, assigned, blocked = ORBmatcher(0.9, check).SearchByProjectionFrame(fv, q, blocked0)
+        onm, oassigned, oblocked = of.search_by_projection_frame(q, check, blocked0)
+        assert nm == onm
+        np.testing.assert_array_equal(assigned, oassigned)
+        np.testing.assert_array_equal(blocked, oblocked)
+        assert nm > 0.3 * len(k1)
+
+
+@pytest.mark.parametrize("geom,th,ratio", [((1241, 376, 2000), 1.0, 0.8), ((640, 480, 1000), 3.0, 0.8), ((752, 480, 1200), 5.0, 0.6)])
+def test_search_by_projection_points(geom, th, ratio):
+    w, h, nf = geom
+    k0, d0, k1, d1, sf = _two_frames(w, h, nf)
+    rng = np.random.default_rng(9)
+    q = _queries_from_last(k0, d0, sf, 4.0 * th, rng=rng)
+    q["min_level"] = k0["octave"] - 1
+    q["max_level"] = k0["octave"]
+    # duplicate a few queries so that later ones meet blocked candidates
+    q = np.concatenate([q, q[:200]])
+    fv = FrameView(k1, d1, 0, w, 0, h, None)
+    of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, None)
+    nm, assigned, blocked = ORBmatcher(ratio).SearchByProjection(fv, q)
+    onm, oassigned, oblocked = of.search_by_projection_points(q, np.float32(ratio))
+    assert nm == onm
+    np.testing.assert_array_equal(assigned, oassigned)
+    np.testing.assert_array_equal(blocked, oblocked)
+    assert nm > 0.3 * len(k1)
+
+
+def test_search_by_bow_grouped():
+    k0, d0, k1, d1, sf = _two_frames(640, 480, 1000)
+    # stand-in vocabulary: 100 buckets from a hash of the first two descriptor bytes
+    bucket = lambda d: (d[:, 0].astype(np.int64) * 256 + d[:, 1]) % 100
+    gA, gB = {}, {}
+    for i, b in enumerate(bucket(d0)):
+        gA.setdefault(int(b), []).append(i)
+    for i, b in enumerate(bucket(d1)):
+        gB.setdefault(int(b), []).append(i)
+    # one big shared bucket with near-duplicates so that matches actually occur
+    rng = np.random.default_rng(2)
+    dA = d0.copy(); dB = d1.copy()
+    for t in range(150):
+        dB[t] = dA[t]
+        flip = rng.integers(0, 256, 6)
+        for f in flip:
+            dB[t, f // 8] ^= np.uint8(1 << (f % 8))
+    gA = {7: list(range(150)), **{k + 1000: v for k, v in gA.items()}}
+    gB = {7: list(range(150)), **{k + 1000: v for k, v in gB.items()}}
+    valid = (rng.random(len(dA)) < 0.9).astype(np.uint8)
+    for ratio, check in ((0.7, True), (0.9, False)):
+        nm, matchB = ORBmatcher(ratio, check).SearchByBoW(dA, k0["angle"], valid, gA, dB, k1["angle"], gB)
+        onm, omatchB = ol.search_by_bow(dA, k0["angle"], valid, gA, dB, k1["angle"], gB, np.float32(ratio), check)
+        assert nm == onm
+        np.testing.assert_array_equal(matchB, omatchB)
+    assert onm > 50
+
+
+@pytest.mark.parametrize("geom", [(1241, 376, 2000), (752, 480, 1200)])
+def test_stereo_matches_batch(geom):
+    import torch
+    w, h, nf = geom
+    P = 3
+    pairs = synth.sequence(w, h, P, seq=8, stereo=True)
+    exL, exR = ORBextractor(nf), ORBextractor(nf)
+    cap = exL.max_keypoints(w, h)
+    dev = "cuda"
+    L = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    R = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    mk = lambda: (torch.zeros((P, cap, 28), dtype=torch.uint8, device=dev), torch.zeros((P, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.zeros(P, dtype=torch.int32, device=dev))
+    kl, dl, nl = mk()
+    kr, dr, nr = mk()
+    exL.extract_batch_device(L, kl, dl, nl)
+    exR.extract_batch_device(R, kr, dr, nr)
+    exL.sync(); exR.sync()
+    ur = torch.zeros((P, cap), dtype=torch.float32, device=dev)
+    depth = torch.zeros((P, cap), dtype=torch.float32, device=dev)
+    nmatched = torch.zeros(P, dtype=torch.int32, device=dev)
+    mbf, fx = 386.1448, 718.856
+    mb = mbf / fx
+    m = Matcher()
+    m.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, mbf, mb, ur, depth, nmatched)
+    m.sync()
+    sf, isf = exL.GetScaleFactors(), exL.GetInverseScaleFactors()
+    from refactored_orb_slam2_amd._lib import KP_DTYPE
+    for p in range(P):
+        n_l, n_r = int(nl[p]), int(nr[p])
+        kL = kl[p].cpu().numpy().view(KP_DTYPE).reshape(-1)[:n_l]
+        kR = kr[p].cpu().numpy().view(KP_DTYPE).reshape(-1)[:n_r]
+        dL = dl[p].cpu().numpy()[:n_l]
+        dR = dr[p].cpu().numpy()[:n_r]
+        oL, oR = ol.OracleExtractor(nf), ol.OracleExtractor(nf)
+        okL, odL = oL(pairs[p][0])
+        okR, odR = oR(pairs[p][1])
+        np.testing.assert_array_equal(dL, odL)
+        np.testing.assert_array_equal(dR, odR)
+        planesL = [oL.level_pixels(l) for l in range(8)]
+        planesR = [oR.level_pixels(l) for l in range(8)]
+        on, our, odepth = ol.compute_stereo_matches(okL, odL, okR, odR, planesL, planesR, sf, isf, mbf, mb)
+        gur = ur[p].cpu().numpy()[:n_l]
+        gdepth = depth[p].cpu().numpy()[:n_l]
+        np.testing.assert_array_equal(gur, our)
+        np.testing.assert_array_equal(gdepth, odepth)
+        assert int(nmatched[p]) == on
+        assert on > 0.2 * n_l
