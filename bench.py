@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: stereo frames/s of the ORB front end (extract + match).
+
+One "step" = one batch of F synthetic KITTI-geometry stereo frames (1241x376, 2000 features, 8 levels)
+resident in HBM, pushed through the whole hot path on one GPU:
+    ORBextractor left + right  ->  Frame::ComputeStereoMatches  ->  SearchByProjection(cur, last)
+N > 1 shards independent frames over ranks (one process per GPU, weak scaling: F frames per rank per step)
+and gathers the per-frame keypoint/descriptor records with one RCCL all_gather per step -- the only
+exchange the path has (BASELINE.json north_star).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP
+events on the launching stream) and, at N=1, `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS = 1241, 376, 2000, 8
+MBF, FX = 386.1448, 718.856           # Source/Examples/Stereo/KITTI00-02.yaml: Camera.bf, Camera.fx
+TH_STEREO = 7.0                       # Tracking::TrackWithMotionModel: th = 7 for stereo (Tracking.cc:793-798)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def level_pixels(ex):
+    return [ex.level_size(l, W, H) for l in range(NLEVELS)]
+
+
+def build_queries(torch, kps, desc, n, ur, sf_t, shift_x):
+    """Project frame f-1 ("last") into frame f with the known image motion: the caller-side part of
+    SearchByProjection(cur, last) (Source/Libraries/ORB_SLAM2/src/ORBmatcher.cc:1270-1308), as tensor ops."""
+    F, cap = desc.shape[0], desc.shape[1]
+    k32 = kps.view(torch.int32).view(F, cap, 7)
+    last = torch.roll(k32, 1, 0)
+    dlast = torch.roll(desc.view(torch.int32).view(F, cap, 8), 1, 0)
+    nlast = torch.roll(n, 1, 0)
+    urlast = torch.roll(ur, 1, 0)
+    x = last[..., 0].view(torch.float32)
+    y = last[..., 1].view(torch.float32)
+    ang = last[..., 3].view(torch.float32)
+    octv = last[..., 5].clamp(0, NLEVELS - 1)
+    q = torch.empty((F, cap, 17), dtype=torch.int32, device=desc.device)
+    u = x + shift_x
+    q[..., 0] = u.view(torch.int32)
+    q[..., 1] = y.view(torch.int32)
+    q[..., 2] = (u - (x - urlast)).view(torch.int32)
+    q[..., 3] = (TH_STEREO * sf_t[octv.long()]).view(torch.int32)
+    q[..., 4] = octv - 1
+    q[..., 5] = octv + 1
+    idx = torch.arange(cap, device=desc.device, dtype=torch.int32)[None, :]
+    q[..., 6] = ((idx < nlast[:, None]) & (urlast >= 0)).to(torch.int32)
+    q[..., 7] = 1
+    q[..., 8] = ang.view(torch.int32)
+    q[..., 9:17] = dlast
+    return q.view(torch.uint8).view(F, cap, 68), nlast.contiguous()
+
+
+def cpu_baseline(sample_frames: int):
+    """The CPU oracle (scalar C restatement of the reference path, 1 thread) on a bounded sample."""
+    from refactored_orb_slam2_amd import synth
+    from tests import oracle_lib as ol
+    pairs = synth.sequence(W, H, sample_frames, seq=0, stereo=True)
+    oL, oR = ol.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7), ol.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7)
+    sf, isf = oL.scale_factors, oL.inv_scale_factors
+    mb = MBF / FX
+    prev = None
+    t0 = time.perf_counter()
+    for (L, R) in pairs:
+        kL, dL = oL(L)
+        kR, dR = oR(R)
+        planesL = [oL.level_pixels(l) for l in range(NLEVELS)]
+        planesR = [oR.level_pixels(l) for l in range(NLEVELS)]
+        _, ur, _ = ol.compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, MBF, mb)
+        if prev is not None:
+            pk, pd, pur = prev
+            q = np.zeros(len(pk), ol.QUERY_DTYPE)
+            q["u"] = pk["x"] - np.float32(2.0); q["v"] = pk["y"]
+            q["u_r"] = q["u"] - (pk["x"] - pur)
+            q["radius"] = np.float32(TH_STEREO) * sf[pk["octave"]]
+            q["min_level"] = pk["octave"] - 1; q["max_level"] = pk["octave"] + 1
+            q["valid"] = (pur >= 0).astype(np.int32); q["blocks"] = 1
+            q["angle"] = pk["angle"]; q["desc"] = pd
+            ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(q, True)
+        prev = (kL, dL, ur)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_frames} synthetic KITTI-geometry stereo frames (2x extract + stereo match + "
+                      f"SearchByProjection vs previous frame), oracle/orb_oracle.c -O2 scalar, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="stereo frames per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="stereo frames timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from refactored_orb_slam2_amd import ORBextractor, synth
+    from refactored_orb_slam2_amd.matcher import Matcher
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    F = args.frames
+    # ---- synthetic input, resident in HBM before the timed region (each rank its own sequence)
+    pairs = synth.sequence(W, H, F, seq=rank, stereo=True)
+    dL = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    dR = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+
+    exL, exR = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local), ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
+    mt = Matcher(local)
+    cap = exL.max_keypoints(W, H)
+    mk = lambda: (torch.zeros((F, cap, 28), dtype=torch.uint8, device=dev),
+                  torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev), torch.zeros(F, dtype=torch.int32, device=dev))
+    kl, dl, nl = mk()
+    kr, dr, nr = mk()
+    ur = torch.zeros((F, cap), dtype=torch.float32, device=dev)
+    depth = torch.zeros((F, cap), dtype=torch.float32, device=dev)
+    n_stereo = torch.zeros(F, dtype=torch.int32, device=dev)
+    blocked = torch.zeros((F, cap), dtype=torch.uint8, device=dev)
+    assigned = torch.zeros((F, cap), dtype=torch.int32, device=dev)
+    n_track = torch.zeros(F, dtype=torch.int32, device=dev)
+    sf_t = torch.from_numpy(exL.GetScaleFactors()).to(dev)
+    mb = MBF / FX
+    sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    evL, evR = torch.cuda.Event(), torch.cuda.Event()
+    if world > 1:
+        g_n = torch.zeros((world, F), dtype=torch.int32, device=dev)
+        g_k = torch.zeros((world,) + tuple(kl.shape), dtype=torch.uint8, device=dev)
+        g_d = torch.zeros((world,) + tuple(dl.shape), dtype=torch.uint8, device=dev)
+
+    def step():
+        cur = torch.cuda.current_stream()
+        sL.wait_stream(cur); sR.wait_stream(cur)
+        exL.extract_batch_device(dL, kl, dl, nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90 runs them in 2 threads)
+        exR.extract_batch_device(dR, kr, dr, nr, stream=sR)   # ORBextractor right
+        evL.record(sL); evR.record(sR)
+        cur.wait_event(evL); cur.wait_event(evR)
+        mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, MBF, mb, ur, depth, n_stereo, stream=cur)  # ComputeStereoMatches
+        q, nq = build_queries(torch, kl, dl, nl, ur, sf_t, -2.0)
+        blocked.zero_(); assigned.fill_(-1)
+        mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned,
+                            n_track, stream=cur)              # SearchByProjection(cur, last, th=7)
+        if world > 1:  # the path's only exchange: gather of the per-frame keypoint records
+            dist.all_gather_into_tensor(g_n, nl)
+            dist.all_gather_into_tensor(g_k, kl)
+            dist.all_gather_into_tensor(g_d, dl)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1) if args.warmup >= 0 else 0):
+        step()
+    barrier()
+    exL.device_status(); exR.device_status()
+    n_kp = int(nl.sum().item()) + int(nr.sum().item())
+    n_st = int(n_stereo.sum().item())
+    n_tr = int(n_track.sum().item())
+    # measured FAST candidates per image (for the algorithmic byte count of the FAST kernel)
+    cand_per_img = float(np.mean([sum(len(exL.debug_candidates(i, l)[0]) for l in range(NLEVELS)) for i in range(min(F, 4))]))
+
+    exL.profile(True); exR.profile(True)
+    exL.stage_times(reset=True); exR.stage_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stL, stR = exL.stage_times(), exR.stage_times()
+    exL.profile(False); exR.profile(False)
+
+    if rank == 0:
+        px = level_pixels(exL)
+        sumP = sum(w * h for w, h in px)
+        P0, P7 = px[0][0] * px[0][1], px[-1][0] * px[-1][1]
+        # algorithmic bytes per image and per kernel; one launch processes F images
+        alg = {
+            "pyramid": (sumP - P7) + (sumP - P0) + 2 * P0,   # level chain + the level-0 copy (read + write)
+            "fast": sumP + 8 * cand_per_img,
+            "octree": 8 * cand_per_img + 4 * NFEAT,
+            "blur": 2 * sumP,
+            "describe": NFEAT * (749 + 512 + 60),
+        }
+        per_launch_ms = {}
+        for k in stL:
+            ms = stL[k][0] + stR[k][0]
+            cnt = stL[k][1] + stR[k][1]
+            if k == "pyramid":
+                cnt //= 2  # two timed groups (level-0 copy, resize chain) per batch
+            per_launch_ms[k] = ms / max(cnt, 1)
+        dom = max(per_launch_ms, key=lambda k: per_launch_ms[k])
+        achieved = alg[dom] * F / (per_launch_ms[dom] * 1e-3) / 1e9
+        value = world * F * args.steps / dt
+        out = {
+            "metric": "frames/s (extract+match) at KITTI 1241×376, 2000 feat; 1/2/4/8 GPU + CPU ref",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "kitti_stereo_1241x376_2000feat_8lvl: 2x ORBextractor + ComputeStereoMatches + "
+                                   "SearchByProjection(cur,last)", "stereo_frames_per_gpu_per_step": F,
+                       "images_per_step": 2 * F * world, "parallelism": f"frame-shard x{world}",
+                       "keypoints_per_image": round(n_kp / (2 * F), 1), "stereo_matches_per_frame": round(n_st / F, 1),
+                       "tracked_per_frame": round(n_tr / F, 1)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
+                         "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
