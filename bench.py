@@ -109,6 +109,7 @@ def main():
     import torch.distributed as dist
     from refactored_orb_slam2_amd import ORBextractor, synth
     from refactored_orb_slam2_amd.matcher import Matcher
+    from refactored_orb_slam2_amd.sharding import gather_records
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,10 +145,6 @@ def main():
     mb = MBF / FX
     sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     evL, evR = torch.cuda.Event(), torch.cuda.Event()
-    if world > 1:
-        g_n = torch.zeros((world, F), dtype=torch.int32, device=dev)
-        g_k = torch.zeros((world,) + tuple(kl.shape), dtype=torch.uint8, device=dev)
-        g_d = torch.zeros((world,) + tuple(dl.shape), dtype=torch.uint8, device=dev)
 
     def step():
         cur = torch.cuda.current_stream()
@@ -162,9 +159,7 @@ def main():
         mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned,
                             n_track, stream=cur)              # SearchByProjection(cur, last, th=7)
         if world > 1:  # the path's only exchange: gather of the per-frame keypoint records
-            dist.all_gather_into_tensor(g_n, nl)
-            dist.all_gather_into_tensor(g_k, kl)
-            dist.all_gather_into_tensor(g_d, dl)
+            gather_records(nl, kl, dl)
 
     def barrier():
         torch.cuda.synchronize()

@@ -1,0 +1,59 @@
+"""Batched-sequence mode: independent frames are sharded over ranks (one process per GPU) and the per-frame
+keypoint records are gathered with one collective (RCCL all_gather on GPUs, gloo in the CPU tests).
+
+The reference processes frames strictly sequentially in one process (Source/Examples/Stereo/stereo_kitti.cc:
+36-150); extraction carries no state between frames, so contiguous chunks of the frame range are independent
+units.  Contiguous rather than round-robin keeps consecutive-frame matching rank-local.
+"""
+from __future__ import annotations
+
+
+def shard_range(n_frames: int, rank: int, world: int) -> tuple[int, int]:
+    """[begin, end) of the frames rank `rank` owns: contiguous chunks, sizes differ by at most one."""
+    if world < 1 or not (0 <= rank < world) or n_frames < 0:
+        raise ValueError("bad shard arguments")
+    base, rem = divmod(n_frames, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def padded_chunk(n_frames: int, world: int) -> int:
+    """Frames per rank after padding the last chunks, so every rank contributes equally sized records."""
+    return (n_frames + world - 1) // world
+
+
+def gather_records(n, kps, desc, group=None):
+    """all_gather of fixed-size padded per-frame records {n[f]; kps[f, cap, 28]; desc[f, cap, 32]}.
+
+    n: int32 (F,), kps: uint8 (F, cap, 28), desc: uint8 (F, cap, 32) -- F identical on every rank.
+    Returns (n_all (world*F,), kps_all (world*F, cap, 28), desc_all (world*F, cap, 32)) in rank order, i.e.
+    in global frame order for contiguous shards.  With world size 1 (or no process group) it is the identity.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return n, kps, desc
+    world = dist.get_world_size(group)
+    out = []
+    for t in (n, kps, desc):
+        t = t.contiguous()
+        g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(g, t, group=group)  # concatenation along dim 0, rank order
+        out.append(g)
+    return tuple(out)
+
+
+def unpack_records(n_all, kps_all, desc_all, n_frames: int):
+    """Drops the padding frames and returns per-frame (keypoints, descriptors) numpy views."""
+    import numpy as np
+    from ._lib import KP_DTYPE
+
+    n_np = n_all.cpu().numpy()
+    k_np = kps_all.cpu().numpy()
+    d_np = desc_all.cpu().numpy()
+    res = []
+    for f in range(n_frames):
+        c = int(n_np[f])
+        res.append((k_np[f, :c].copy().view(KP_DTYPE).reshape(-1), d_np[f, :c].copy()))
+    return res

@@ -1,0 +1,82 @@
+"""CPU suite, part 2: the C-ABI library builds for gfx950, loads, exports every symbol include/orbfe.h
+declares, and fails loudly (no CPU fallback) when no HIP device is present.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from refactored_orb_slam2_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    _lib.build()
+    return _lib.lib()
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "orbfe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbfe_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(L):
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == names  # the ctypes binding covers exactly the header
+
+
+def test_library_is_gfx950_code_object():
+    out = os.popen(f"/opt/rocm/lib/llvm/bin/llvm-readelf -S {_lib.LIB_PATH} 2>/dev/null | grep -c hip_fatbin").read().strip()
+    assert out and int(out) >= 1
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_struct_layouts():
+    assert _lib.KP_DTYPE.itemsize == 28 and _lib.QUERY_DTYPE.itemsize == 68
+    assert _lib.CAND_DTYPE.itemsize == 8 and _lib.BF_DTYPE.itemsize == 12
+    assert C.sizeof(_lib.Params) == 20 and C.sizeof(_lib.FrameView) == 48
+
+
+def _gpu_present(L):
+    n = C.c_int(0)
+    return L.orbfe_device_count(C.byref(n)) == 0 and n.value > 0
+
+
+def test_no_device_is_an_error_not_a_fallback(L):
+    if _gpu_present(L):
+        pytest.skip("a GPU is present")
+    h = C.c_void_p(None)
+    prm = _lib.Params(2000, 1.2, 8, 20, 7)
+    assert L.orbfe_extractor_create(C.byref(prm), -1, C.byref(h)) == _lib.ERR_NO_DEVICE
+    assert not h.value and b"no CPU fallback" in L.orbfe_last_error()
+    m = C.c_void_p(None)
+    assert L.orbfe_matcher_create(-1, C.byref(m)) == _lib.ERR_NO_DEVICE
+    from refactored_orb_slam2_amd import ORBextractor
+    with pytest.raises(_lib.OrbfeError):
+        ORBextractor()
+    # host-pointer matcher entry point: also refuses
+    k = np.zeros(4, _lib.KP_DTYPE); d = np.zeros((4, 32), np.uint8)
+    fv = _lib.FrameView(4, k.ctypes.data, d.ctypes.data, None, 0, 100, 0, 100)
+    q = np.zeros(1, _lib.QUERY_DTYPE); q["valid"] = 1
+    blocked = np.zeros(4, np.uint8); assigned = np.zeros(4, np.int32); nm = C.c_int(0)
+    rc = L.orbfe_search_by_projection_frame(C.byref(fv), q.ctypes.data, 1, 1, blocked.ctypes.data, assigned.ctypes.data, C.byref(nm))
+    assert rc == _lib.ERR_NO_DEVICE
+
+
+def test_argument_validation_without_compute(L):
+    assert L.orbfe_extractor_create(None, -1, None) == _lib.ERR_INVALID
+    h = C.c_void_p(None)
+    bad = _lib.Params(2000, 0.9, 8, 20, 7)  # scale factor <= 1
+    assert L.orbfe_extractor_create(C.byref(bad), -1, C.byref(h)) == _lib.ERR_INVALID
+    bad = _lib.Params(2000, 1.2, 99, 20, 7)
+    assert L.orbfe_extractor_create(C.byref(bad), -1, C.byref(h)) == _lib.ERR_INVALID
+    assert L.orbfe_extractor_destroy(None) == 0 and L.orbfe_matcher_destroy(None) == 0
+    assert L.orbfe_sync(None) == _lib.ERR_INVALID

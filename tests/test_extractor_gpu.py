@@ -56,3 +56,127 @@ def test_stage_parity_synthetic(name):
     img = synth.frame(w, h, seq=3, f=1)
     n = _compare_stages(img, nf)
     assert n >= nf * 0.9
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures
+import glob
+import os
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "extract_*.npz"))))
+def test_hip_reproduces_golden_extraction(path):
+    g = np.load(path)
+    ex = ORBextractor(int(g["nfeatures"]))
+    k, d = ex(g["image"])
+    np.testing.assert_array_equal(k, g["keypoints"])
+    np.testing.assert_array_equal(d, g["descriptors"])
+    for l in (0, 7):
+        x, y, s = ex.debug_candidates(0, l)
+        np.testing.assert_array_equal(np.stack([x, y, s]).astype(np.int16), g[f"cand_{l}"])
+    # mvImagePyramid semantics: level 0 is the input itself
+    np.testing.assert_array_equal(ex.pyramid_level(0), g["image"])
+    assert [p.shape for p in ex.mvImagePyramid] == [(ex.level_size(l)[1], ex.level_size(l)[0]) for l in range(8)]
+    ex.close()
+
+
+# ------------------------------------------------------------------------------------------ batch / device API
+def test_batch_equals_single_and_is_idempotent():
+    import torch
+    w, h, nf, B = 1241, 376, 2000, 6
+    imgs = synth.sequence(w, h, B, seq=6)
+    ex = ORBextractor(nf)
+    single = [ex(i) for i in imgs]
+    batch = ex.extract_batch(imgs)
+    for (k1, d1), (k2, d2) in zip(single, batch):
+        np.testing.assert_array_equal(k1, k2); np.testing.assert_array_equal(d1, d2)
+    # device-resident path, non-contiguous source rows (stride > width), twice (idempotence)
+    pad = np.zeros((B, h, w + 37), np.uint8)
+    pad[:, :, :w] = np.stack(imgs)
+    dimg = torch.from_numpy(pad).cuda()[:, :, :w]
+    cap = ex.max_keypoints(w, h)
+    kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    from refactored_orb_slam2_amd._lib import KP_DTYPE
+    for _ in range(2):
+        kps.zero_(); desc.zero_()
+        ex.extract_batch_device(dimg, kps, desc, n)
+        ex.sync(); ex.device_status()
+        for i in range(B):
+            c = int(n[i])
+            np.testing.assert_array_equal(kps[i, :c].cpu().numpy().view(KP_DTYPE).reshape(-1), single[i][0])
+            np.testing.assert_array_equal(desc[i, :c].cpu().numpy(), single[i][1])
+    ex.close()
+
+
+def test_keypoint_invariants_at_full_size():
+    """size-independent properties on the benchmark geometry (no oracle needed)."""
+    w, h, nf = 1241, 376, 2000
+    ex = ORBextractor(nf)
+    k, d = ex(synth.frame(w, h, seq=9, f=4))
+    sf = ex.GetScaleFactors()
+    fpl = ex.features_per_level()
+    assert np.all(np.diff(k["octave"]) >= 0)                       # level order
+    for l in range(8):
+        m = k["octave"] == l
+        assert fpl[l] <= m.sum() <= fpl[l] + 3 or m.sum() < fpl[l]  # N..N+3 per level (SURVEY §7 hard part 2)
+        lw, lh = ex.level_size(l)
+        x, y = k["x"][m] / sf[l], k["y"][m] / sf[l]
+        assert x.min() >= 19 - 1e-3 and x.max() <= lw - 19 + 1e-3 and y.min() >= 19 - 1e-3 and y.max() <= lh - 19 + 1e-3
+        assert np.all(k["size"][m] == float(int(31 * sf[l])))
+    assert np.all((k["angle"] >= 0) & (k["angle"] < 360)) and np.all(k["class_id"] == -1)
+    assert np.all(k["response"] >= 7) and len(np.unique(d, axis=0)) > 0.98 * len(d)
+    ex.close()
+
+
+def test_edge_cases():
+    from refactored_orb_slam2_amd import _lib
+    ex = ORBextractor(500)
+    # flat image: no corners at all -> zero keypoints (reference releases the descriptor matrix)
+    k, d = ex(np.full((120, 160), 77, np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # small image whose upper levels have no FAST cell (nCols/nRows < 1, guarded divide-by-zero of the reference)
+    img = synth.frame(100, 90, seq=1)
+    k, d = ex(img)
+    ok, od = ol.OracleExtractor(500)(img)
+    np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
+    # empty image: silent no-op in the reference, ORBFE_ERR_EMPTY at the C ABI, None in the mirror
+    assert ex(np.zeros((0, 0), np.uint8)) is None
+    # capacity too small is reported, never silently truncated
+    import ctypes as C
+    img = synth.frame(640, 480, seq=2)
+    kps = np.zeros(10, _lib.KP_DTYPE); desc = np.zeros((10, 32), np.uint8); n = C.c_int(0)
+    rc = ex._L.orbfe_extract(ex._h, _lib.ptr(img), 640, 480, 640, _lib.ptr(kps), _lib.ptr(desc), 10, C.byref(n))
+    assert rc == _lib.ERR_CAPACITY and n.value > 10
+    # geometry change on the same handle re-plans
+    k2, d2 = ex(synth.frame(320, 240, seq=2))
+    ok2, od2 = ol.OracleExtractor(500)(synth.frame(320, 240, seq=2))
+    np.testing.assert_array_equal(k2, ok2); np.testing.assert_array_equal(d2, od2)
+    ex.close()
+
+
+@pytest.mark.parametrize("params", [(1500, 1.2, 8, 20, 7), (800, 1.1, 12, 12, 5), (3000, 1.5, 4, 30, 10), (200, 1.2, 1, 20, 7)])
+def test_other_extractor_parameters(params):
+    nf, sf, nl, ini, mn = params
+    img = synth.frame(752, 480, seq=10, f=2)
+    ex = ORBextractor(nf, sf, nl, ini, mn)
+    k, d = ex(img)
+    ok, od = ol.OracleExtractor(nf, sf, nl, ini, mn)(img)
+    np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
+    np.testing.assert_array_equal(ex.GetScaleFactors(), ol.OracleExtractor(nf, sf, nl, ini, mn).scale_factors)
+    np.testing.assert_array_equal(ex.GetInverseScaleSigmaSquares(), ol.OracleExtractor(nf, sf, nl, ini, mn).inv_sigma2)
+    ex.close()
+
+
+def test_dense_texture_spills_keys_to_hbm():
+    """white noise: tens of thousands of FAST candidates per level (> the LDS key budget) -> global-key path"""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (376, 1241), dtype=np.uint8)
+    ex = ORBextractor(2000)
+    k, d = ex(img)
+    assert len(ex.debug_candidates(0, 0)[0]) > 8000
+    ok, od = ol.OracleExtractor(2000)(img)
+    np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
+    ex.close()

@@ -1,0 +1,133 @@
+"""CPU suite, part 3: host-side logic (synthetic data, query construction, frame sharding, RCCL-gather
+packing with the gloo backend at world size 2)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from refactored_orb_slam2_amd import sharding, synth
+from refactored_orb_slam2_amd._lib import KP_DTYPE, QUERY_DTYPE
+from refactored_orb_slam2_amd.matcher import three_maxima
+from tests import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synth_is_deterministic_and_textured():
+    a = synth.frame(320, 200, seq=2, f=3)
+    b = synth.frame(320, 200, seq=2, f=3)
+    np.testing.assert_array_equal(a, b)
+    assert a.dtype == np.uint8 and a.shape == (200, 320) and a.std() > 20
+    L, R = synth.stereo_pair(320, 200, seq=2, f=3)
+    np.testing.assert_array_equal(L, a)
+    assert not np.array_equal(L, R)
+    k, _ = ol.OracleExtractor(300, 1.2, 4, 20, 7)(a)
+    assert len(k) > 200  # FAST corners exist at every level
+
+
+def test_three_maxima_matches_oracle():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        hs = rng.integers(0, 40, 30).astype(np.int32)
+        if rng.random() < 0.3:
+            hs[rng.integers(0, 30)] = 500  # dominant bin -> the 10 % rule kicks in
+        i1, i2, i3 = ol.C.c_int(), ol.C.c_int(), ol.C.c_int()
+        ol.lib().oo_three_maxima(hs.ctypes.data, 30, ol.C.byref(i1), ol.C.byref(i2), ol.C.byref(i3))
+        assert three_maxima(hs.tolist()) == (i1.value, i2.value, i3.value)
+
+
+def test_shard_range_partitions_frames():
+    for n in (0, 1, 7, 64, 4541):
+        for world in (1, 2, 3, 4, 8):
+            got = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in got]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == sharding.padded_chunk(n, world) or n == 0
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 4, 4)
+
+
+def test_bench_query_builder_matches_record_layout():
+    sys.path.insert(0, ROOT)
+    import bench
+    rng = np.random.default_rng(1)
+    F, cap = 3, 50
+    kp = np.zeros((F, cap), KP_DTYPE)
+    kp["x"] = rng.uniform(20, 1200, (F, cap)).astype(np.float32); kp["y"] = rng.uniform(20, 350, (F, cap)).astype(np.float32)
+    kp["angle"] = rng.uniform(0, 360, (F, cap)).astype(np.float32); kp["octave"] = rng.integers(0, 8, (F, cap))
+    desc = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    n = np.array([50, 31, 44], np.int32)
+    ur = np.where(rng.random((F, cap)) < 0.7, kp["x"] - 20, -1).astype(np.float32)
+    sf = ol.OracleExtractor(100).scale_factors
+    q, nq = bench.build_queries(torch, torch.from_numpy(kp.view(np.uint8).reshape(F, cap, 28)), torch.from_numpy(desc),
+                                torch.from_numpy(n), torch.from_numpy(ur), torch.from_numpy(sf), -2.0)
+    rec = q.numpy().reshape(F, cap * 68).view(QUERY_DTYPE).reshape(F, cap)
+    for f in range(F):
+        last = (f - 1) % F
+        assert int(nq[f]) == n[last]
+        np.testing.assert_array_equal(rec[f]["u"], kp[last]["x"] + np.float32(-2.0))
+        np.testing.assert_array_equal(rec[f]["v"], kp[last]["y"])
+        np.testing.assert_array_equal(rec[f]["radius"], np.float32(7.0) * sf[kp[last]["octave"]])
+        np.testing.assert_array_equal(rec[f]["min_level"], kp[last]["octave"] - 1)
+        np.testing.assert_array_equal(rec[f]["max_level"], kp[last]["octave"] + 1)
+        np.testing.assert_array_equal(rec[f]["desc"], desc[last])
+        np.testing.assert_array_equal(rec[f]["angle"], kp[last]["angle"])
+        np.testing.assert_array_equal(rec[f]["valid"], ((np.arange(cap) < n[last]) & (ur[last] >= 0)).astype(np.int32))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _gather_worker(rank, world, port, n_frames, cap, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chunk = sharding.padded_chunk(n_frames, world)
+        b, e = sharding.shard_range(n_frames, rank, world)
+        # deterministic per-frame records: frame f has (f*7 % cap) keypoints with recognisable content
+        n = torch.zeros(chunk, dtype=torch.int32)
+        kps = torch.zeros((chunk, cap, 28), dtype=torch.uint8)
+        desc = torch.zeros((chunk, cap, 32), dtype=torch.uint8)
+        for i, f in enumerate(range(b, e)):
+            c = (f * 7) % cap
+            n[i] = c
+            kps[i, :c] = (f % 251)
+            desc[i, :c] = ((f * 3) % 253)
+        n_all, k_all, d_all = sharding.gather_records(n, kps, desc)
+        assert n_all.shape[0] == world * chunk
+        # global frame order: rank r's chunk starts at r*chunk; padding frames carry n = 0
+        for r in range(world):
+            rb, re_ = sharding.shard_range(n_frames, r, world)
+            for i, f in enumerate(range(rb, re_)):
+                g = r * chunk + i
+                c = (f * 7) % cap
+                assert int(n_all[g]) == c
+                assert bool((k_all[g, :c] == f % 251).all()) and bool((d_all[g, :c] == (f * 3) % 253).all())
+            for i in range(re_ - rb, chunk):
+                assert int(n_all[r * chunk + i]) == 0
+        dist.barrier()
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 9), (2, 8)])
+def test_gather_records_gloo_world2(tmp_path, world, n_frames):
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(world, port, n_frames, 40, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_gather_records_identity_without_group():
+    n = torch.arange(4, dtype=torch.int32)
+    k = torch.zeros((4, 5, 28), dtype=torch.uint8)
+    d = torch.zeros((4, 5, 32), dtype=torch.uint8)
+    out = sharding.gather_records(n, k, d)
+    assert out[0] is n and out[1] is k and out[2] is d

@@ -240,3 +240,64 @@ def test_stereo_matches_batch(geom):
         np.testing.assert_array_equal(gdepth, odepth)
         assert int(nmatched[p]) == on
         assert on > 0.2 * n_l
+
+
+def test_hip_reproduces_golden_matcher():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "matcher_tum.npz"))
+    fv = FrameView(g["k1"], g["d1"], 0, int(g["w"]), 0, int(g["h"]), g["u_right"])
+    q = g["queries"]
+    nm, a, b = ORBmatcher(0.9, True).SearchByProjectionFrame(fv, q)
+    assert nm == int(g["frame_nm"])
+    np.testing.assert_array_equal(a, g["frame_assigned"]); np.testing.assert_array_equal(b, g["frame_blocked"])
+    q2 = q.copy(); q2["max_level"] = g["k0"]["octave"]
+    nm, a, b = ORBmatcher(0.8).SearchByProjection(fv, q2)
+    assert nm == int(g["points_nm"])
+    np.testing.assert_array_equal(a, g["points_assigned"]); np.testing.assert_array_equal(b, g["points_blocked"])
+    # window enumeration order: without the stereo gate the candidate list == GetFeaturesInArea
+    fv2 = FrameView(g["k1"], g["d1"], 0, int(g["w"]), 0, int(g["h"]), None)
+    cand, n = ORBmatcher().ProjCandidates(fv2, q[:64], max_cand=512)
+    pos = 0
+    for i in range(64):
+        exp = g["win_idx"][pos:pos + int(g["win_n"][i])] if q["valid"][i] else np.zeros(0, np.int32)
+        pos += int(g["win_n"][i])
+        np.testing.assert_array_equal(cand[i, : n[i]]["idx"], exp)
+
+
+def test_proj_overflowing_candidate_lists_are_reenumerated():
+    """windows holding more than the stored 64 candidates: the resolver re-enumerates them (same result)"""
+    k0, d0, k1, d1, sf = _two_frames(640, 480, 1000)
+    rng = np.random.default_rng(21)
+    q = _queries_from_last(k0, d0, sf, 120.0, rng=rng, blocks_p=0.5)   # huge windows
+    q["min_level"] = 0; q["max_level"] = -1
+    fv = FrameView(k1, d1, 0, 640, 0, 480, None)
+    of = ol.OracleFrame(k1, d1, sf, 0, 640, 0, 480, None)
+    _, n = ORBmatcher().ProjCandidates(fv, q[:50], max_cand=8)
+    assert n.max() > 64
+    for mode in (0, 1):
+        if mode:
+            got = ORBmatcher(0.9, True).SearchByProjectionFrame(fv, q)
+            exp = of.search_by_projection_frame(q, True)
+        else:
+            got = ORBmatcher(0.7).SearchByProjection(fv, q)
+            exp = of.search_by_projection_points(q, np.float32(0.7))
+        assert got[0] == exp[0]
+        np.testing.assert_array_equal(got[1], exp[1]); np.testing.assert_array_equal(got[2], exp[2])
+
+
+def test_empty_inputs():
+    fv = FrameView(np.zeros(0, ol.KP_DTYPE), np.zeros((0, 32), np.uint8), 0, 640, 0, 480)
+    q = make_queries(5)
+    nm, a, b = ORBmatcher().SearchByProjectionFrame(fv, q)
+    assert nm == 0 and len(a) == 0
+    k0, d0, k1, d1, sf = _two_frames(640, 480, 1000)
+    fv = FrameView(k1, d1, 0, 640, 0, 480)
+    nm, a, b = ORBmatcher().SearchByProjection(fv, make_queries(0))
+    assert nm == 0 and np.all(a == -1)
+    q = _queries_from_last(k0, d0, sf, 7.0)
+    q["valid"] = 0
+    nm, a, b = ORBmatcher().SearchByProjectionFrame(fv, q)
+    assert nm == 0 and np.all(a == -1)
+    q["valid"] = 1; q["u"] = 5000.0   # every projection outside the grid
+    nm, a, b = ORBmatcher().SearchByProjectionFrame(fv, q)
+    assert nm == 0

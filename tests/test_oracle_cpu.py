@@ -1,0 +1,186 @@
+"""CPU suite, part 1: the oracle against known-answer constants, against the independent
+numpy restatement, and against the committed golden fixtures.  No GPU needed."""
+import glob
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from refactored_orb_slam2_amd import synth
+from tests import np_restatement as nr
+from tests import oracle_lib as ol
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_known_answer_constants():
+    e = ol.OracleExtractor(2000, 1.2, 8, 20, 7)
+    assert e.features_per_level == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert e.umax == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3] == nr.umax_table()
+    np.testing.assert_allclose(e.scale_factors, [1, 1.2000000477, 1.4400000572, 1.7280001640, 2.0736002922,
+                                                 2.4883203506, 2.9859845638, 3.5831816196], rtol=1e-7)
+    assert ol.OracleExtractor(1000, 1.2, 8, 20, 7).features_per_level == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert ol.OracleExtractor(1200, 1.2, 8, 20, 7).features_per_level == [261, 217, 181, 151, 126, 105, 87, 72]
+    taps = (ol.C.c_int * 7)()
+    ol.lib().oo_gauss_taps7(taps)
+    assert list(taps) == [18, 34, 48, 56, 48, 34, 18]
+    pat = np.array([ol.lib().oo_pattern()[i] for i in range(1024)], dtype=np.int8)
+    assert hashlib.sha256(pat.tobytes()).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    assert pat[:8].tolist() == [8, -3, 9, 5, 4, 2, 7, -12] and pat[-4:].tolist() == [-1, -6, 0, -11]
+    assert pat.min() == -13 and pat.max() == 12
+    assert ol.descriptor_distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    assert [ol.lib().oo_cvround(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+@pytest.mark.parametrize("wh,sizes", [
+    ((1241, 376), [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]),
+    ((640, 480), [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]),
+    ((752, 480), [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]),
+])
+def test_pyramid_sizes(wh, sizes):
+    e = ol.OracleExtractor(500, 1.2, 8, 20, 7)
+    e(np.zeros((wh[1], wh[0]), np.uint8))
+    assert [e.level_size(l) for l in range(8)] == sizes
+
+
+def test_fast_atan2_against_true_atan2():
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = rng.integers(-200000, 200000, 2)
+        a = ol.lib().oo_fast_atan2(float(y), float(x))
+        t = np.degrees(np.arctan2(float(y), float(x))) % 360.0
+        d = abs(a - t)
+        assert min(d, 360 - d) < 0.35
+        assert a == nr.fast_atan2(y, x)
+    assert ol.lib().oo_fast_atan2(0.0, 0.0) == 0.0
+
+
+def test_restated_sincos_equals_libm_exhaustively(tmp_path):
+    """every float in [0, 6.3] (all angles the extractor can produce): oo_sinf/oo_cosf == libm, bit for bit"""
+    exe = str(tmp_path / "sc")
+    lib = ol.build()
+    subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(os.path.dirname(__file__), "c", "sincos_exhaustive.c"), lib, "-lm"], check=True)
+    r = subprocess.run([exe, "6.3"], capture_output=True, text=True, env={**os.environ, "LD_LIBRARY_PATH": os.path.dirname(lib)})
+    n, bad = r.stdout.split()
+    assert int(n) > 1_000_000_000 and int(bad) == 0 and r.returncode == 0
+
+
+@pytest.mark.parametrize("seed,shape", [(1, (97, 131)), (2, (61, 300)), (3, (240, 33))])
+def test_primitives_vs_numpy_restatement(seed, shape):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    h, w = shape
+    dw, dh = int(round(w / 1.2)), int(round(h / 1.2))
+    np.testing.assert_array_equal(ol.resize_linear(img, dw, dh), nr.resize_linear(img, dw, dh))
+    np.testing.assert_array_equal(ol.gaussian_blur7(img), nr.gaussian_blur7(img))
+    # literal cv::FAST at one threshold == score map thresholded + NMS
+    for th in (7, 20, 40):
+        x, y, s = ol.fast9_16(img, th, True)
+        S = nr.fast_score_map(img)
+        S = np.where(S >= th, S, 0)
+        P = np.pad(S, 1)
+        keep = S > 0
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx or dy:
+                    keep &= S > P[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+        yy, xx = np.nonzero(keep)
+        np.testing.assert_array_equal(x, xx); np.testing.assert_array_equal(y, yy)
+        np.testing.assert_array_equal(s, S[yy, xx])
+
+
+def test_octree_edge_cases():
+    # empty input, single key, N = 0, duplicates of the response, keys on node borders
+    assert len(ol.distribute_octree([], [], [], 16, 200, 16, 100, 10)) == 0
+    assert ol.distribute_octree([5], [7], [30], 16, 200, 16, 100, 10).tolist() == [0]
+    rng = np.random.default_rng(4)
+    for trial in range(30):
+        W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 400))
+        if round(W / H) < 1:
+            continue
+        n = int(rng.integers(1, 3000))
+        pts = set()
+        while len(pts) < n:
+            pts.add((int(rng.integers(0, W)), int(rng.integers(0, H))))
+        pts = sorted(pts, key=lambda p: (p[1] // 30, p[0] // 30, p[1], p[0]))
+        x = np.array([p[0] for p in pts]); y = np.array([p[1] for p in pts])
+        s = rng.integers(7, 12 if trial % 2 else 120, n)  # many response ties on odd trials
+        N = int(rng.integers(0, 500))
+        a = ol.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
+        b = nr.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
+        np.testing.assert_array_equal(a, b, err_msg=f"trial {trial}")
+        assert len(a) <= max(N + 3, 4 * max(1, round(W / H)))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "extract_*.npz"))))
+def test_oracle_reproduces_golden_extraction(path):
+    g = np.load(path)
+    e = ol.OracleExtractor(int(g["nfeatures"]), 1.2, 8, 20, 7)
+    k, d = e(g["image"])
+    np.testing.assert_array_equal(k, g["keypoints"])
+    np.testing.assert_array_equal(d, g["descriptors"])
+    for l in range(8):
+        x, y, s = e.level_candidates(l)
+        assert len(x) == int(g[f"cand_n_{l}"]) and len(e.level_keypoints(l)) == int(g[f"kp_n_{l}"])
+    for l in (0, 7):
+        x, y, s = e.level_candidates(l)
+        np.testing.assert_array_equal(np.stack([x, y, s]).astype(np.int16), g[f"cand_{l}"])
+    # descriptors / angles of a sample of keypoints against the numpy restatement
+    pat = np.array([ol.lib().oo_pattern()[i] for i in range(1024)])
+    off = 0
+    for l in range(8):
+        kl = e.level_keypoints(l)
+        b = e.level_blurred(l)
+        for i in range(0, len(kl), 37):
+            assert nr.ic_angle(e.level_pixels(l), int(kl[i]["x"]), int(kl[i]["y"])) == kl[i]["angle"]
+            np.testing.assert_array_equal(nr.orb_descriptor(b, int(kl[i]["x"]), int(kl[i]["y"]), kl[i]["angle"], pat), d[off + i])
+        off += len(kl)
+
+
+def test_oracle_reproduces_golden_matcher():
+    g = np.load(os.path.join(GOLD, "matcher_tum.npz"))
+    of = ol.OracleFrame(g["k1"], g["d1"], g["sf"], 0, int(g["w"]), 0, int(g["h"]), g["u_right"])
+    np.testing.assert_array_equal(of.cell_start, g["cell_start"])
+    q = g["queries"]
+    nm, a, b = of.search_by_projection_frame(q, True)
+    assert nm == int(g["frame_nm"])
+    np.testing.assert_array_equal(a, g["frame_assigned"]); np.testing.assert_array_equal(b, g["frame_blocked"])
+    q2 = q.copy(); q2["max_level"] = g["k0"]["octave"]
+    nm, a, b = of.search_by_projection_points(q2, np.float32(0.8))
+    assert nm == int(g["points_nm"])
+    np.testing.assert_array_equal(a, g["points_assigned"]); np.testing.assert_array_equal(b, g["points_blocked"])
+    pos = 0
+    for i in range(64):
+        idx = of.features_in_area(float(q["u"][i]), float(q["v"][i]), float(q["radius"][i]), int(q["min_level"][i]), int(q["max_level"][i]))
+        np.testing.assert_array_equal(idx, g["win_idx"][pos:pos + int(g["win_n"][i])])
+        pos += int(g["win_n"][i])
+        # enumeration order: cells x-major, then y, then ascending index inside a cell (Frame.cc:371-392)
+        k1 = g["k1"]
+        gx = np.floor((k1["x"][idx] - 0) * np.float32(64) / np.float32(g["w"]) + np.float32(0.5)).astype(int)
+        gy = np.floor((k1["y"][idx] - 0) * np.float32(48) / np.float32(g["h"]) + np.float32(0.5)).astype(int)
+        order = list(zip(gx.tolist(), gy.tolist(), idx.tolist()))
+        assert order == sorted(order)
+
+
+def test_hamming_matches_numpy_popcount():
+    rng = np.random.default_rng(6)
+    A = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    for i in range(49):
+        assert ol.descriptor_distance(A[i], A[i + 1]) == nr.hamming(A[i], A[i + 1])
+
+
+def test_stereo_oracle_sane():
+    L, R = synth.stereo_pair(640, 480, seq=4, f=0)
+    eL, eR = ol.OracleExtractor(1000), ol.OracleExtractor(1000)
+    kL, dL = eL(L); kR, dR = eR(R)
+    n, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, [eL.level_pixels(l) for l in range(8)],
+                                             [eR.level_pixels(l) for l in range(8)], eL.scale_factors, eL.inv_scale_factors,
+                                             386.1448, 386.1448 / 718.856)
+    ok = ur >= 0
+    assert n == ok.sum() and n > 200
+    disp = kL["x"][ok] - ur[ok]
+    true = 5 + 55 * kL["y"][ok] / 479.0           # synthetic disparity field of synth.stereo_pair
+    assert np.median(np.abs(disp - true)) < 1.0
+    np.testing.assert_allclose(depth[ok], np.float32(386.1448) / disp.astype(np.float32), rtol=1e-6)
