@@ -1,0 +1,154 @@
+// test_dropin.cpp -- exercises the C++ drop-in classes (csrc/host/) exactly as Tracking.cc / Frame.cc use
+// the reference's: `new ORBextractor(...)`, getters, `(*extractor)(im, cv::Mat(), keys, descriptors)`,
+// mvImagePyramid, and the ORBmatcher adapter with mock Frame / MapPoint types carrying the reference's member
+// names.  Results are compared with the CPU oracle (TEST INFRASTRUCTURE) through its C API.
+//   usage: test_dropin <image.raw> <w> <h> <nfeatures>      exit code 0 = parity
+//          test_dropin --nodevice                            checks the no-GPU error behaviour
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../oracle/orb_oracle.h"
+#include "../../refactored_orb_slam2_amd/csrc/host/ORBextractor.h"
+#include "../../refactored_orb_slam2_amd/csrc/host/ORBmatcher_hip.h"
+
+struct MockMapPoint {
+  bool mbTrackInView = true;
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+  int mnTrackScaleLevel = 0;
+  float mTrackViewCos = 1.f;
+  int nObs = 1;
+  bool bad = false;
+  cv::Mat desc;
+  bool isBad() { return bad; }
+  int Observations() { return nObs; }
+  cv::Mat GetDescriptor() { return desc.clone(); }
+};
+struct MockFrame {
+  int N = 0;
+  std::vector<cv::KeyPoint> mvKeysUn;
+  cv::Mat mDescriptors;
+  std::vector<float> mvuRight;
+  std::vector<MockMapPoint*> mvpMapPoints;
+  std::vector<float> mvScaleFactors;
+  float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+};
+
+#define CHECK(c)                                                  \
+  do {                                                            \
+    if (!(c)) { fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "--nodevice")) {
+    ORB_SLAM2::ORBextractor ex(1000, 1.2f, 8, 20, 7);
+    cv::Mat im(64, 64, cv::CV_8U);
+    memset(im.data, 0, 64 * 64);
+    std::vector<cv::KeyPoint> keys(3);
+    cv::Mat desc;
+    ex(im, cv::Mat(), keys, desc);  // must not throw or crash: zero keypoints + stderr log
+    CHECK(keys.empty() && desc.empty());
+    CHECK(ex.GetLevels() == 8);
+    printf("nodevice ok\n");
+    return 0;
+  }
+  if (argc < 5) return 2;
+  const int w = atoi(argv[2]), h = atoi(argv[3]), nf = atoi(argv[4]);
+  std::vector<uint8_t> raw((size_t)w * h);
+  FILE* f = fopen(argv[1], "rb");
+  CHECK(f && fread(raw.data(), 1, raw.size(), f) == raw.size());
+  fclose(f);
+  cv::Mat im(h, w, cv::CV_8U, raw.data());
+
+  // --- as Tracking::Tracking does (L/src/Tracking.cc:118)
+  ORB_SLAM2::ORBextractor* ext = new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7);
+  oo_extractor* orc = oo_extractor_create(nf, 1.2f, 8, 20, 7);
+  CHECK(ext->GetLevels() == 8 && ext->GetScaleFactor() == 1.2f);
+  std::vector<float> sf = ext->GetScaleFactors(), isf = ext->GetInverseScaleFactors(), s2 = ext->GetScaleSigmaSquares(),
+                     is2 = ext->GetInverseScaleSigmaSquares();
+  for (int l = 0; l < 8; l++) {
+    CHECK(sf[l] == oo_extractor_scale_factors(orc)[l] && isf[l] == oo_extractor_inv_scale_factors(orc)[l]);
+    CHECK(s2[l] == oo_extractor_sigma2(orc)[l] && is2[l] == oo_extractor_inv_sigma2(orc)[l]);
+  }
+  // --- as Frame::ExtractORB does (L/src/Frame.cc:265-270), twice (outputs are cleared and refilled)
+  std::vector<cv::KeyPoint> keys;
+  cv::Mat desc;
+  for (int rep = 0; rep < 2; rep++) (*ext)(im, cv::Mat(), keys, desc);
+  std::vector<oo_keypoint> okeys(nf + 64);
+  std::vector<uint8_t> odesc((size_t)(nf + 64) * 32);
+  int on = 0;
+  CHECK(oo_extract(orc, raw.data(), w, h, w, okeys.data(), odesc.data(), nf + 64, &on) == 0);
+  CHECK((int)keys.size() == on && desc.rows == on && desc.cols == 32);
+  CHECK(memcmp(keys.data(), okeys.data(), sizeof(oo_keypoint) * on) == 0);
+  for (int i = 0; i < on; i++) CHECK(memcmp(desc.ptr(i), &odesc[(size_t)i * 32], 32) == 0);
+  // --- mvImagePyramid: level pixels + REFLECT_101 border like the reference's padded buffers
+  for (int l = 0; l < 8; l++) {
+    int lw, lh, st;
+    oo_level_size(orc, l, &lw, &lh);
+    const uint8_t* op = oo_level_pixels(orc, l, &st);
+    cv::Mat& m = ext->mvImagePyramid[l];
+    CHECK(m.cols == lw && m.rows == lh);
+    std::vector<uint8_t> bordered((size_t)(lw + 38) * (lh + 38));
+    oo_copy_make_border_reflect101(op, lw, lh, st, bordered.data(), lw + 38, 19);
+    for (int y = -19; y < lh + 19; y++)
+      CHECK(memcmp(m.ptr(0) + (ptrdiff_t)y * (ptrdiff_t)m.step - 19, &bordered[(size_t)(y + 19) * (lw + 38)], lw + 38) == 0);
+  }
+  // --- ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) through the adapter vs the oracle
+  MockFrame F;
+  F.N = on;
+  F.mvKeysUn = keys;
+  F.mDescriptors = desc;
+  F.mvuRight.assign(on, -1.f);
+  F.mvpMapPoints.assign(on, nullptr);
+  F.mvScaleFactors = sf;
+  F.mnMaxX = (float)w;
+  F.mnMaxY = (float)h;
+  std::vector<MockMapPoint> mps(on);
+  std::vector<MockMapPoint*> vp(on);
+  std::vector<oo_query> oq(on);
+  for (int i = 0; i < on; i++) {
+    MockMapPoint& p = mps[i];
+    p.mTrackProjX = keys[i].pt.x + 1.5f;
+    p.mTrackProjY = keys[i].pt.y - 0.75f;
+    p.mTrackProjXR = p.mTrackProjX - 10.f;
+    p.mnTrackScaleLevel = keys[i].octave;
+    p.mTrackViewCos = (i % 3) ? 0.9995f : 0.9f;
+    p.nObs = (i % 5) ? 2 : 0;
+    p.mbTrackInView = (i % 17) != 0;
+    p.bad = (i % 29) == 0;
+    p.desc = desc.row(i).clone();
+    if (i % 2) p.desc.ptr(0)[i % 32] ^= 0x5a;  // perturb some descriptors
+    vp[i] = &p;
+    oo_query& e = oq[i];
+    memset(&e, 0, sizeof(e));
+    e.valid = p.mbTrackInView && !p.bad;
+    float r = (p.mTrackViewCos > 0.998 ? 2.5f : 4.0f) * 3.0f;
+    e.u = p.mTrackProjX; e.v = p.mTrackProjY; e.u_r = p.mTrackProjXR;
+    e.radius = r * sf[keys[i].octave];
+    e.min_level = keys[i].octave - 1; e.max_level = keys[i].octave;
+    e.blocks = p.nObs > 0;
+    memcpy(e.desc, p.desc.ptr(0), 32);
+  }
+  const int nm = ORB_SLAM2::orbfe_host::SearchByProjectionPoints(F, vp, 3.0f, 0.8f);
+  oo_frame of;
+  memset(&of, 0, sizeof(of));
+  std::vector<int32_t> cell_idx(on);
+  of.n = on; of.keys_un = okeys.data(); of.desc = odesc.data(); of.u_right = F.mvuRight.data();
+  of.max_x = (float)w; of.max_y = (float)h;
+  of.grid_w_inv = 64.f / (float)w; of.grid_h_inv = 48.f / (float)h;
+  of.n_levels = 8; of.scale_factors = sf.data(); of.cell_idx = cell_idx.data();
+  oo_frame_build_grid(&of);
+  std::vector<uint8_t> blocked(on, 0);
+  std::vector<int32_t> assigned(on, -1);
+  const int onm = oo_search_by_projection_points(&of, oq.data(), on, 0.8f, blocked.data(), assigned.data());
+  CHECK(nm == onm && nm > on / 4);
+  for (int i = 0; i < on; i++) CHECK(F.mvpMapPoints[i] == (assigned[i] >= 0 ? vp[assigned[i]] : nullptr));
+  CHECK(ORB_SLAM2::orbfe_host::DescriptorDistance(desc.ptr(0), desc.ptr(1)) == oo_descriptor_distance(desc.ptr(0), desc.ptr(1)));
+  oo_extractor_destroy(orc);
+  delete ext;
+  printf("dropin ok: %d keypoints, %d matches\n", on, nm);
+  return 0;
+}
