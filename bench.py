@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="stereo frames per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=24, help="stereo frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--lr-streams", type=int, default=2, choices=(1, 2),
+                    help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
     args = ap.parse_args()
 
     import torch
@@ -143,16 +145,25 @@ def main():
     n_track = torch.zeros(F, dtype=torch.int32, device=dev)
     sf_t = torch.from_numpy(exL.GetScaleFactors()).to(dev)
     mb = MBF / FX
-    sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    # three explicit HIP streams: torch's default stream is the NULL stream, which the C ABI reads as "use the
+    # handle's own stream"; the whole step therefore runs on named streams ordered by events
+    sM, sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     evL, evR = torch.cuda.Event(), torch.cuda.Event()
 
     def step():
-        cur = torch.cuda.current_stream()
-        sL.wait_stream(cur); sR.wait_stream(cur)
-        exL.extract_batch_device(dL, kl, dl, nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90 runs them in 2 threads)
-        exR.extract_batch_device(dR, kr, dr, nr, stream=sR)   # ORBextractor right
-        evL.record(sL); evR.record(sR)
-        cur.wait_event(evL); cur.wait_event(evR)
+        with torch.cuda.stream(sM):
+            _step(sM)
+
+    def _step(cur):
+        if args.lr_streams == 2:
+            sL.wait_stream(cur); sR.wait_stream(cur)
+            exL.extract_batch_device(dL, kl, dl, nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90: two threads)
+            exR.extract_batch_device(dR, kr, dr, nr, stream=sR)   # ORBextractor right
+            evL.record(sL); evR.record(sR)
+            cur.wait_event(evL); cur.wait_event(evR)
+        else:
+            exL.extract_batch_device(dL, kl, dl, nl, stream=cur)
+            exR.extract_batch_device(dR, kr, dr, nr, stream=cur)
         mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, MBF, mb, ur, depth, n_stereo, stream=cur)  # ComputeStereoMatches
         q, nq = build_queries(torch, kl, dl, nl, ur, sf_t, -2.0)
         blocked.zero_(); assigned.fill_(-1)

@@ -129,6 +129,17 @@ def check(rc: int, where: str):
         raise OrbfeError(rc, where, lib().orbfe_last_error().decode(errors="replace"))
 
 
+def stream_handle(stream) -> C.c_void_p:
+    """torch stream -> hipStream_t.  None selects the handle's own stream.  torch's default stream is the NULL
+    stream, which the C ABI also reads as "the handle's own stream" -- refuse it instead of racing silently."""
+    if stream is None:
+        return C.c_void_p(None)
+    h = int(stream.cuda_stream)
+    if h == 0:
+        raise ValueError("pass an explicit torch.cuda.Stream (or None for the handle's own stream), not the default stream")
+    return C.c_void_p(h)
+
+
 def ptr(a) -> C.c_void_p:
     """Host numpy array or torch tensor -> void*."""
     if a is None:

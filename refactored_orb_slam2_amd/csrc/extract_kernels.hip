@@ -168,8 +168,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
     uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
     uint32_t* s32 = reinterpret_cast<uint32_t*>(sc);
     const int total = rows * ndw;
+    const float inv_ndw = 1.0f / (float)ndw;
     for (int i = tid; i < total; i += 256) {
-      int r = (int)((i + 0.5f) / (float)ndw);
+      int r = (int)((i + 0.5f) * inv_ndw);
       int c = i - r * ndw;
       t32[r * (ORBFE_TILE_PITCH / 4) + c] =
           *reinterpret_cast<const uint32_t*>(plane + (size_t)(cd.y0 + r) * pitch + ax + 4 * c);
@@ -179,32 +180,36 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   __syncthreads();
 
   const int tw = cols - 6, th = rows - 6;  // tested region [3, cols-3) x [3, rows-3)
+  const float inv_tw = 1.0f / (float)(tw > 0 ? tw : 1);  // (p + 0.5) * inv_tw floors exactly for p < 4096, tw < 64
   const int npix = (tw > 0 && th > 0) ? tw * th : 0;
   const uint8_t* T = tile + xo;
 
-  // pass A1: corner test at min_th, compact corner pixels into clist
+  // pass A1: quick reject.  A 9-arc of the 16-ring contains at least one pixel of every antipodal pair, so a
+  // corner needs, in each of the pairs (0,8) (2,10) (4,12) (6,14), a pixel darker than v-t (dark arc) -- or, in
+  // each of them, one brighter than v+t (bright arc).  Sign bits do the comparisons; survivors are compacted.
   for (int p = tid; p < npix; p += 256) {
-    const int ty = (int)((p + 0.5f) / (float)tw);
+    const int ty = (int)((p + 0.5f) * inv_tw);
     const int tx = p - ty * tw;
     const int x = tx + 3, y = ty + 3;
     const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
     const int v = c[0];
     const int lo = v - min_th, hi = v + min_th;
-    uint32_t dark = 0, bright = 0;
+    int dark = -1, bright = -1;  // sign bit = "every pair so far has a darker / brighter member"
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int q = c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
-      dark |= (uint32_t)(q < lo) << k;
-      bright |= (uint32_t)(q > hi) << k;
+    for (int k = 0; k < 8; k += 2) {
+      const int qa = c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
+      const int qb = c[RDY[k + 8] * ORBFE_TILE_PITCH + RDX[k + 8]];
+      dark &= (qa - lo) | (qb - lo);
+      bright &= (hi - qa) | (hi - qb);
     }
-    if (ring_has9(dark) || ring_has9(bright)) {
+    if ((dark | bright) < 0) {
       int idx = atomicAdd(&nlist, 1);
       clist[idx] = (uint16_t)((y << 8) | x);
     }
   }
   __syncthreads();
 
-  // pass A2: score the corners (dense over the compacted list)
+  // pass A2: exact score of the survivors (dense over the compacted list).  score >= t  <=>  corner at t.
   const int nl = nlist;
   for (int i = tid; i < nl; i += 256) {
     const int e = clist[i];
@@ -214,7 +219,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
     int d[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) d[k] = v - (int)c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
-    sc[y * ORBFE_TILE_PITCH + x] = (uint8_t)corner_score16(d);
+    const int sc16 = corner_score16(d);
+    if (sc16 >= min_th) sc[y * ORBFE_TILE_PITCH + x] = (uint8_t)sc16;
   }
   __syncthreads();
 
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   const int p0 = tid * K;
   int ty0 = 0, tx0 = 0;
   if (p0 < npix) {
-    ty0 = (int)((p0 + 0.5f) / (float)tw);
+    ty0 = (int)((p0 + 0.5f) * inv_tw);
     tx0 = p0 - ty0 * tw;
   }
   {
@@ -584,43 +590,93 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 }
 
 // ------------------------------------------------------------------------------------------------ blur
-// 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps, exact 16.16 accumulation, round half up.
-// One 64x16 output tile per workgroup, separable through LDS; 4 outputs per thread, one dword store.
+// 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps [18,34,48,56,48,34,18], exact 16.16 accumulation,
+// round half up.  One 64x32 output tile per workgroup, separable through LDS.  Interior tiles stage the
+// (64+8)x(32+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
+// REFLECT_101 indexing.  Both passes produce 4 adjacent pixels per work item (dword LDS/global accesses).
+#define BT_W 64
+#define BT_H 32
+#define BT_INP 80   // LDS pitch (bytes) of the input window: column j <-> level x = ox - 4 + j
+#define BT_HP 68    // LDS pitch (dwords) of one row PAIR of the horizontal-pass result (two u16 rows interleaved)
 __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles) {
-  __shared__ uint8_t in[22][72];
-  __shared__ uint16_t hb[22][64];
+  __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
+  __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
   const int tid = threadIdx.x;
   const BlurTile t = tiles[blockIdx.x];
   const int lvl = t.level;
   const int w = src.w[lvl], h = src.h[lvl], pitch = src.pitch[lvl];
   const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
-  const int ox = t.tx * 64, oy = t.ty * 16;
-  for (int i = tid; i < 22 * 70; i += 256) {
-    const int r = i / 70, c = i - r * 70;
-    const int gy = reflect101(oy + r - 3, h), gx = reflect101(ox + c - 3, w);
-    in[r][c] = S[(size_t)gy * pitch + gx];
+  const int ox = t.tx * BT_W, oy = t.ty * BT_H;
+  const bool interior = ox >= 4 && ox + BT_W + 3 < w && oy >= 3 && oy + BT_H + 3 <= h;
+  if (interior) {
+    uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
+    for (int i = tid; i < (BT_H + 6) * 18; i += 256) {
+      const int r = i / 18, c = i - r * 18;
+      in32[r * (BT_INP / 4) + c] = *reinterpret_cast<const uint32_t*>(S + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c);
+    }
+  } else {
+    for (int i = tid; i < (BT_H + 6) * 70; i += 256) {
+      const int r = i / 70, c = i - r * 70;  // c <-> x = ox - 3 + c  <-> column j = c + 1
+      const int gy = reflect101(oy + r - 3, h), gx = reflect101(ox + c - 3, w);
+      in[r * BT_INP + c + 1] = S[(size_t)gy * pitch + gx];
+    }
   }
   __syncthreads();
-  for (int i = tid; i < 22 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const uint8_t* p = &in[r][c];
-    hb[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-  }
-  __syncthreads();
-  {
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    const int gy = oy + r, gx = ox + c4;
-    if (gy < h && gx < w) {
-      uint32_t out = 0;
+  // horizontal pass: item = (row pair k, 4-pixel group g).  Output x = 4g+i needs window columns 4g+i+1 .. 4g+i+7:
+  // two byte windows cut with v_alignbyte and two v_dot4_u32_u8 against the packed taps.  The two rows of a pair
+  // are stored interleaved (even row in the low half) so the vertical pass can use v_dot2_u32_u16.
+  for (int it = tid; it < ((BT_H + 6) / 2) * 16; it += 256) {
+    const int k = it >> 4, g = it & 15;
+    uint32_t o[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int c = c4 + i;
-        const uint32_t acc = 18u * (hb[r][c] + hb[r + 6][c]) + 34u * (hb[r + 1][c] + hb[r + 5][c]) +
-                             48u * (hb[r + 2][c] + hb[r + 4][c]) + 56u * hb[r + 3][c];
-        out |= ((acc + 32768u) >> 16) << (8 * i);
-      }
-      *reinterpret_cast<uint32_t*>(D + (size_t)gy * dst.pitch[lvl] + gx) = out;
+    for (int rr = 0; rr < 2; rr++) {
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(in + (2 * k + rr) * BT_INP + 4 * g);
+      const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+      const uint32_t T1 = 18u | (34u << 8) | (48u << 16) | (56u << 24), T2 = 48u | (34u << 8) | (18u << 16);
+      o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), T2,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), T1, 0u, false), false);
+      o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), T2,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), T1, 0u, false), false);
+      o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), T2,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), T1, 0u, false), false);
+      o[rr][3] = __builtin_amdgcn_udot4(w2, T2, __builtin_amdgcn_udot4(w1, T1, 0u, false), false);
+    }
+    uint4 st;
+    st.x = o[0][0] | (o[1][0] << 16);
+    st.y = o[0][1] | (o[1][1] << 16);
+    st.z = o[0][2] | (o[1][2] << 16);
+    st.w = o[0][3] | (o[1][3] << 16);
+    *reinterpret_cast<uint4*>(hbp + k * BT_HP + 4 * g) = st;
+  }
+  __syncthreads();
+  // vertical pass: thread = (4-pixel group g, row pair rp): output rows 2rp, 2rp+1 from the row pairs rp .. rp+3
+  {
+    typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+    const int g = tid & 15, rp = tid >> 4;
+    uint4 P[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4*>(hbp + (rp + k) * BT_HP + 4 * g);
+    const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;        // even row
+    const uint32_t O0 = 18u << 16, O1 = 34u | (48u << 16), O2 = 56u | (48u << 16), O3 = 34u | (18u << 16);  // odd row
+    uint32_t outE = 0, outO = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t p0 = i == 0 ? P[0].x : i == 1 ? P[0].y : i == 2 ? P[0].z : P[0].w;
+      const uint32_t p1 = i == 0 ? P[1].x : i == 1 ? P[1].y : i == 2 ? P[1].z : P[1].w;
+      const uint32_t p2 = i == 0 ? P[2].x : i == 1 ? P[2].y : i == 2 ? P[2].z : P[2].w;
+      const uint32_t p3 = i == 0 ? P[3].x : i == 1 ? P[3].y : i == 2 ? P[3].z : P[3].w;
+#define UD2(a, b, c) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (uint32_t)(a)), __builtin_bit_cast(us2, (uint32_t)(b)), (c), false)
+      const uint32_t accE = UD2(p3, E3, UD2(p2, E2, UD2(p1, E1, UD2(p0, E0, 32768u))));
+      const uint32_t accO = UD2(p3, O3, UD2(p2, O2, UD2(p1, O1, UD2(p0, O0, 32768u))));
+#undef UD2
+      outE |= (accE >> 16) << (8 * i);
+      outO |= (accO >> 16) << (8 * i);
+    }
+    const int gy = oy + 2 * rp, gx = ox + 4 * g;
+    if (gx < w) {
+      if (gy < h) *reinterpret_cast<uint32_t*>(D + (size_t)gy * dst.pitch[lvl] + gx) = outE;
+      if (gy + 1 < h) *reinterpret_cast<uint32_t*>(D + (size_t)(gy + 1) * dst.pitch[lvl] + gx) = outO;
     }
   }
 }
@@ -702,7 +758,12 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 
 // One wave per keypoint slot.  IC_Angle on the un-blurred level, steered BRIEF on the blurred level,
 // 4 x __ballot -> 256 bits; writes the cv::KeyPoint record (pt scaled to level-0 pixels) and 32 bytes.
+#define ORI_PITCH 36
+#define DSC_PITCH 40
+#define ORI_BYTES (31 * ORI_PITCH)                        // 1116
+#define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 2608
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) {
+  __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
   const int lane = threadIdx.x & (WAVE - 1);
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.y;
@@ -725,19 +786,43 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const int cx = (int)(e & 0xfff) + ORBFE_EDGE, cy = (int)((e >> 12) & 0xfff) + ORBFE_EDGE;
   const int score = (int)(e >> 24);
 
-  // --- IC_Angle (L/src/ORBextractor.cc:76-100): two rows per step, lanes 0-31 / 32-63
+  // --- stage both patches of this keypoint in the wave's LDS slice with aligned dword loads:
+  //     un-blurred 31x31 (orientation) and blurred 37x37 (rotated pattern offsets reach +-18)
+  uint8_t* ori = &patch[threadIdx.x >> 6][0];
+  uint8_t* dsc = ori + ORI_BYTES;
   const int pitch = P.pyr.pitch[level];
-  const uint8_t* center = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level] + (size_t)cy * pitch + cx;
+  const int bpitch = P.blur.pitch[level];
+  const uint8_t* plane = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level];
+  const uint8_t* bplane = P.blur.base[level] + (size_t)img * P.blur.img_stride[level];
+  const int ax_o = (cx - 15) & ~3, ax_d = (cx - 18) & ~3;
+  constexpr int ndw_o = 9, ndw_d = 10;  // enough for any alignment; the extra dword stays inside the row pitch + slack
+  for (int i = lane; i < 31 * ndw_o; i += WAVE) {
+    const int r = i / ndw_o, c = i - r * ndw_o;
+    reinterpret_cast<uint32_t*>(ori)[r * (ORI_PITCH / 4) + c] =
+        *reinterpret_cast<const uint32_t*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 4 * c);
+  }
+  for (int i = lane; i < 37 * ndw_d; i += WAVE) {
+    const int r = i / ndw_d, c = i - r * ndw_d;
+    reinterpret_cast<uint32_t*>(dsc)[r * (DSC_PITCH / 4) + c] =
+        *reinterpret_cast<const uint32_t*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 4 * c);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // --- IC_Angle (L/src/ORBextractor.cc:76-100): two rows per step, lanes 0-31 / 32-63
+  const uint8_t* center = ori + 15 * ORI_PITCH + (cx - ax_o);
   int m10 = 0, m01 = 0;
   const int u = (lane & 31) - 15;
+  // the circular patch is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]): one table look-up per lane
+  const int vlim = (lane & 31) < 31 ? UMAX[u < 0 ? -u : u] : -1;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     const int v = -15 + 2 * i + (lane >> 5);
-    if (v <= 15 && (lane & 31) < 31) {
+    {
       const int av = v < 0 ? -v : v;
-      const int au = u < 0 ? -u : u;
-      if (au <= UMAX[av]) {
-        const int val = center[v * pitch + u];
+      if (av <= vlim) {
+        const int val = center[v * ORI_PITCH + u];
         m10 += u * val;
         m01 += v * val;
       }
@@ -755,8 +840,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const float arad = angle * factorPI;
   float a, b;
   glibc_sincosf(arad, &b, &a);
-  const int bpitch = P.blur.pitch[level];
-  const uint8_t* bc = P.blur.base[level] + (size_t)img * P.blur.img_stride[level] + (size_t)cy * bpitch + cx;
+  const uint8_t* bc = dsc + 18 * DSC_PITCH + (cx - ax_d);
   uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -766,8 +850,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
     const float x1 = (float)(int8_t)((pk >> 16) & 0xff), y1 = (float)(int8_t)((pk >> 24) & 0xff);
     const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
     const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
-    const int t0 = bc[ry0 * bpitch + rx0];
-    const int t1 = bc[ry1 * bpitch + rx1];
+    const int t0 = bc[ry0 * DSC_PITCH + rx0];
+    const int t1 = bc[ry1 * DSC_PITCH + rx1];
     const unsigned long long bits = __ballot(t0 < t1);
     if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = bits;
   }

@@ -250,7 +250,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     o.key_cap = (int)std::min<size_t>(level_slots, 0xFFFFFF);
     key_off += level_slots;
     // blur tiles
-    for (int ty = 0; ty < (g.h + 15) / 16; ty++)
+    for (int ty = 0; ty < (g.h + 31) / 32; ty++)
       for (int tx = 0; tx < (g.w + 63) / 64; tx++) e->tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
   }
   e->total_cells = (int)e->cells.size();
@@ -310,8 +310,9 @@ static int ensure_workspace(orbfe_extractor* e, int n_images) {
   HIPCHK(hipStreamSynchronize(e->stream));
   const size_t B = (size_t)n_images;
   int rc;
-  if ((rc = dev_alloc(e->d_pyr, pyr_bytes_per_image(e) * B))) return rc;
-  if ((rc = dev_alloc(e->d_blur, pyr_bytes_per_image(e) * B))) return rc;
+  // + 4 KiB slack: kernels read whole aligned dwords / fixed-size patch rows that may end past the last plane
+  if ((rc = dev_alloc(e->d_pyr, pyr_bytes_per_image(e) * B + 4096))) return rc;
+  if ((rc = dev_alloc(e->d_blur, pyr_bytes_per_image(e) * B + 4096))) return rc;
   if ((rc = dev_alloc(e->d_cell_cnt, sizeof(int32_t) * e->total_cells * B))) return rc;
   if ((rc = dev_alloc(e->d_cell_off, sizeof(int32_t) * e->total_cells * B))) return rc;
   if ((rc = dev_alloc(e->d_slots, sizeof(uint32_t) * e->slots_per_image * B))) return rc;

@@ -50,7 +50,13 @@ struct StereoParams {
   float* depth;
   int32_t* sad;        // scratch [n_pairs][cap]
   int32_t* n_matched;  // [n_pairs]
+  // row buckets of the right keypoints (bucket b = image rows [8b, 8b+8)): CSR per pair
+  int32_t* bucket_start;  // [n_pairs][STEREO_MAX_BUCKETS + 1]
+  int32_t* bucket_idx;    // [n_pairs][cap * STEREO_BUCKET_SPAN]
+  int n_buckets;
 };
+#define STEREO_MAX_BUCKETS 512      // rows / 8, rows <= 4095
+#define STEREO_BUCKET_SPAN 8        // a band [y-r, y+r], r = 2*scale <= ~25 rows, overlaps at most this many buckets
 
 void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s);
 void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s);

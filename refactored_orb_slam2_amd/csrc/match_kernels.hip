@@ -35,6 +35,15 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   for (int d = 32; d >= 1; d >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, d, WAVE));
   return v;
 }
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    int t = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
@@ -273,8 +282,9 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, Quer
   if (q.valid) {
     uint4 q0, q1;
     load_desc4(qp->desc, q0, q1);
+    const orbfe_keypoint* keys_oct = F.keys + (size_t)f * F.cap;
     total = enumerate_window(F, f, q, q0, q1, [&](int rank, int idx, int dist) {
-      if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist; }
+      if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist | (keys_oct[idx].octave << 16); }
     });
   }
   if ((threadIdx.x & 63) == 0) n_cand[(size_t)f * Q.cap + qi] = total;
@@ -294,117 +304,291 @@ __device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& in
   else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// One wave per frame walks the queries IN ORDER (assignments of earlier queries block candidates of later
-// ones).  Per query the lanes take its stored candidates (or, when the list was truncated, re-enumerate the
-// window), drop blocked ones and min-reduce the key (dist << 16 | rank).
-// mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)  -- best/second with the same-level ratio test
+// Order-dependent assignment of SearchByProjection.  One 256-thread workgroup per frame.  Queries are taken
+// up to 256 at a time (one per thread) and resolved SPECULATIVELY against the current blocked[] state; a
+// thread's result is exact unless an earlier thread of the same chunk blocks its best (mode 0: best or
+// second-best) candidate.  Threads before the first such conflict commit together, the rest are recomputed --
+// the outcome is identical to walking the queries one by one (L/src/ORBmatcher.cc:52-125, 1270-1361), and
+// conflicts are rare.  A query whose candidate list was truncated (> max_cand) ends the chunk and is handled
+// alone by wave 0, which re-enumerates its window.
+// mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)   -- best/second with the same-level ratio test
 // mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, TH_HIGH, rotation histogram
-__global__ __launch_bounds__(64) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
+#define RC_LIST_CAP 8192  // staged candidate entries per chunk (32 KiB)
+__global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
                                                            const int32_t* __restrict__ n_cand, int max_cand, int mode,
                                                            float nnratio, int check_ori, uint8_t* __restrict__ blocked_all,
                                                            int32_t* __restrict__ assigned_all, int32_t* __restrict__ n_matches,
                                                            int32_t* __restrict__ push_idx_all, uint8_t* __restrict__ push_bin_all) {
   __shared__ int hist[ORBFE_HISTO_LENGTH];
-  extern __shared__ uint8_t blocked[];  // F.cap bytes: F.mvpMapPoints[idx]->Observations() > 0
-  const int f = blockIdx.x, lane = threadIdx.x;
+  __shared__ uint32_t lc[RC_LIST_CAP];  // staged candidate lists: dist<<20 | octave<<16 | idx
+  __shared__ int loff[257];
+  __shared__ int scan_tmp[8];
+  __shared__ int sh_len, sh_nm, sh_npush;
+  __shared__ int sh_changed[2];
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+  const int capA = (F.cap + 15) & ~15;
+  uint8_t* blocked = dyn;                                   // F.mvpMapPoints[idx]->Observations() > 0
+  int* claim = reinterpret_cast<int*>(dyn + capA);          // smallest chunk thread that blocks idx this round
+  int* claimB = claim + F.cap;                              // second claim buffer (the two alternate per iteration)
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid >> 6;
   const int nq = Q.n[f];
   uint8_t* blocked_g = blocked_all + (size_t)f * F.cap;
-  for (int i = lane; i < F.cap; i += WAVE) blocked[i] = blocked_g[i];
   int32_t* assigned = assigned_all + (size_t)f * F.cap;
   int32_t* push_idx = push_idx_all + (size_t)f * Q.cap;
   uint8_t* push_bin = push_bin_all + (size_t)f * Q.cap;
   const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
-  if (lane < ORBFE_HISTO_LENGTH) hist[lane] = 0;
+  const orbfe_query* qbase = Q.q + (size_t)f * Q.cap;
+  const int32_t* ncb = n_cand + (size_t)f * Q.cap;
+  for (int i = tid; i < F.cap; i += 256) { blocked[i] = blocked_g[i]; claim[i] = 0x7fffffff; claimB[i] = 0x7fffffff; }
+  if (tid < ORBFE_HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) { sh_nm = 0; sh_npush = 0; }
   __syncthreads();
-  int nmatches = 0, npush = 0;
-  for (int qi = 0; qi < nq; qi++) {
-    const orbfe_query* qp = Q.q + (size_t)f * Q.cap + qi;
-    if (!qp->valid) continue;
-    const int total = n_cand[(size_t)f * Q.cap + qi];
-    if (total == 0) continue;
-    // lane-local best / second keys; key = dist<<16 | rank, payload = idx
-    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-    int i1 = -1, i2 = -1;
-    auto consider = [&](int rank, int idx, int dist) {
-      if (blocked[idx]) return;
-      const unsigned key = ((unsigned)dist << 16) | (unsigned)rank;
-      if (key < k1) { k2 = k1; i2 = i1; k1 = key; i1 = idx; }
-      else if (key < k2) { k2 = key; i2 = idx; }
-    };
-    if (total <= max_cand) {
-      const orbfe_cand* cl = cand + ((size_t)f * Q.cap + qi) * max_cand;
-      for (int c = lane; c < total; c += WAVE) consider(c, cl[c].idx, cl[c].dist);
-    } else {
-      const orbfe_query q = *qp;
-      uint4 q0, q1;
-      load_desc4(qp->desc, q0, q1);
-      enumerate_window(F, f, q, q0, q1, consider);
+  const bool use_hist = (mode == 1) && check_ori;
+  int q0 = 0;
+  while (q0 < nq) {
+    const int qi = q0 + tid;
+    int tot = 0, qblocks = 0;
+    float qangle = 0.f;
+    if (qi < nq && qbase[qi].valid) {
+      tot = ncb[qi];
+      qblocks = qbase[qi].blocks != 0;
+      qangle = qbase[qi].angle;
     }
-    const unsigned b = wave_min_u32(k1);
-    if (b == 0xFFFFFFFFu) continue;  // every candidate blocked: bestDist stays 256
-    const unsigned long long wm = __ballot(k1 == b);
-    const int wl = __ffsll((long long)wm) - 1;
-    const int bestIdx = __shfl(i1, wl, WAVE);
-    const int bestDist = (int)(b >> 16);
-    bool accept = false;
-    if (mode == 0) {
-      // second = minimum key over everything but the winner
-      const unsigned mine = (lane == wl) ? k2 : k1;
-      const int mine_i = (lane == wl) ? i2 : i1;
-      const unsigned s = wave_min_u32(mine);
-      int bestDist2 = 256, bestLevel2 = -1;
-      if (s != 0xFFFFFFFFu) {
-        const unsigned long long sm = __ballot(mine == s);
-        const int sl = __ffsll((long long)sm) - 1;
-        const int secIdx = __shfl(mine_i, sl, WAVE);
-        bestDist2 = (int)(s >> 16);
-        bestLevel2 = keys[secIdx].octave;
-      }
-      const int bestLevel = keys[bestIdx].octave;
-      if (bestDist <= ORBFE_TH_HIGH) {
-        if (!(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) accept = true;
-      }
-    } else {
-      accept = bestDist <= ORBFE_TH_HIGH;
+    // chunk = queries q0 .. q0+len-1: stops before the first truncated list and before the staging area is full
+    if (tid == 0) { sh_len = min(256, nq - q0); sh_changed[0] = 0; sh_changed[1] = 0; }
+    __syncthreads();
+    {
+      const int v = tot > max_cand ? 0 : tot;
+      const int w = wave_incl_scan_i(v);
+      if (lane == WAVE - 1) scan_tmp[wid] = w;
+      __syncthreads();
+      int off = 0;
+      for (int k = 0; k < wid; k++) off += scan_tmp[k];
+      const int incl = off + w;
+      loff[tid + 1] = incl;
+      if (tid == 0) loff[0] = 0;
+      if (tot > max_cand || incl > RC_LIST_CAP) atomicMin(&sh_len, tid);
     }
-    if (accept) {
-      if (lane == 0) {
-        assigned[bestIdx] = qi;
-        blocked[bestIdx] = (uint8_t)(qp->blocks != 0);
-        if (mode == 1 && check_ori) {
-          float rot = qp->angle - keys[bestIdx].angle;
-          if (rot < 0.0f) rot += 360.0f;
-          int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));  // the reference's factor (sic), :1255
-          if (bin == ORBFE_HISTO_LENGTH) bin = 0;
-          push_idx[npush] = bestIdx;
-          push_bin[npush] = (uint8_t)bin;
-          hist[bin]++;
+    __syncthreads();
+    const int len = sh_len;
+    if (len == 0) {
+      // ---- truncated list at q0: wave 0 re-enumerates this one window, the other waves wait
+      if (wid == 0) {
+        const orbfe_query* qp = qbase + q0;
+        const orbfe_query q = *qp;
+        uint4 d0, d1;
+        load_desc4(qp->desc, d0, d1);
+        unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        int i1 = -1, i2 = -1;
+        enumerate_window(F, f, q, d0, d1, [&](int rank, int idx, int dist) {
+          if (blocked[idx]) return;
+          const unsigned key = ((unsigned)dist << 16) | (unsigned)min(rank, 0xffff);
+          if (key < k1) { k2 = k1; i2 = i1; k1 = key; i1 = idx; }
+          else if (key < k2) { k2 = key; i2 = idx; }
+        });
+        const unsigned b = wave_min_u32(k1);
+        if (b != 0xFFFFFFFFu) {
+          const unsigned long long wm = __ballot(k1 == b);
+          const int wl = __ffsll((long long)wm) - 1;
+          const int bestIdx = __shfl(i1, wl, WAVE);
+          const int bestDist = (int)(b >> 16);
+          bool accept = false;
+          if (mode == 0) {
+            const unsigned mine = (lane == wl) ? k2 : k1;
+            const int mine_i = (lane == wl) ? i2 : i1;
+            const unsigned s2 = wave_min_u32(mine);
+            int bestDist2 = 256, bestLevel2 = -1;
+            if (s2 != 0xFFFFFFFFu) {
+              const unsigned long long sm = __ballot(mine == s2);
+              const int sl = __ffsll((long long)sm) - 1;
+              bestDist2 = (int)(s2 >> 16);
+              bestLevel2 = keys[__shfl(mine_i, sl, WAVE)].octave;
+            }
+            const int bestLevel = keys[bestIdx].octave;
+            if (bestDist <= ORBFE_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2))
+              accept = true;
+          } else {
+            accept = bestDist <= ORBFE_TH_HIGH;
+          }
+          if (accept && lane == 0) {
+            assigned[bestIdx] = q0;
+            blocked[bestIdx] = (uint8_t)(q.blocks != 0);
+            sh_nm += 1;
+            if (use_hist) {
+              float rot = q.angle - keys[bestIdx].angle;
+              if (rot < 0.0f) rot += 360.0f;
+              int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));  // the reference's factor (sic), :1255
+              if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+              push_idx[sh_npush] = bestIdx;
+              push_bin[sh_npush] = (uint8_t)bin;
+              sh_npush += 1;
+              hist[bin]++;
+            }
+          }
         }
       }
-      nmatches++;
-      npush++;
+      __syncthreads();
+      q0 += 1;
+      continue;
     }
-    __syncthreads();  // single wave: lane 0's LDS store to blocked[] is ordered before the next query's reads
-  }
-  for (int i = lane; i < F.cap; i += WAVE) blocked_g[i] = blocked[i];
-  if (mode == 1 && check_ori) {
+    // ---- stage the candidate lists (each wave its own 64 queries, 8 lists in flight per step)
+    for (int j0 = 0; j0 < WAVE; j0 += 8) {
+      orbfe_cand c[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = wid * WAVE + j0 + u;
+        const int tj = __shfl(tot, j0 + u, WAVE);
+        dst[u] = -1;
+        if (t < len && lane < tj) {
+          c[u] = cand[((size_t)f * Q.cap + q0 + t) * max_cand + lane];
+          dst[u] = loff[t] + lane;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (dst[u] >= 0)
+          lc[dst[u]] = ((uint32_t)(c[u].dist & 0xffff) << 20) | ((uint32_t)((c[u].dist >> 16) & 0xf) << 16) |
+                       (uint32_t)(c[u].idx & 0xffff);
+    }
     __syncthreads();
-    if (lane == 0) {
-      int i1, i2, i3;
-      three_maxima(hist, ORBFE_HISTO_LENGTH, i1, i2, i3);
-      for (int k = 0; k < npush; k++) {
-        const int bin = push_bin[k];
-        if (bin != i1 && bin != i2 && bin != i3) { assigned[push_idx[k]] = -1; nmatches--; }
+    const bool active = tid < len && tot > 0;
+    const uint32_t* mylist = lc + loff[tid < len ? tid : 0];
+    // Fixed-point iteration over the chunk.  Thread t's choice = best candidate that is neither blocked nor
+    // claimed (blocked-to-be) by an EARLIER thread of the chunk; claims come from the previous iteration.
+    // Thread t's choice is final after at most t+1 iterations (it only depends on earlier threads), so the
+    // iteration converges to exactly the sequential result; in practice the dependency chains are 2-4 deep.
+    uint32_t e1 = 0, e2 = 0;
+    bool has = false, has2 = false, accept = false;
+    int myclaim = -1;
+    for (int iter = 0;; iter++) {
+      int* cprev = (iter & 1) ? claimB : claim;
+      int* cnew = (iter & 1) ? claim : claimB;
+      const uint32_t pe1 = e1, pe2 = e2;
+      const bool phas = has, phas2 = has2;
+      int bestDist = 256, bestDist2 = 256;
+      e1 = e2 = 0;
+      has = has2 = accept = false;
+      if (active) {
+        for (int c = 0; c < tot; c++) {
+          const uint32_t e = mylist[c];
+          const int idx = (int)(e & 0xffff);
+          if (blocked[idx] || cprev[idx] < tid) continue;
+          const int dist = (int)(e >> 20);
+          if (dist < bestDist) { bestDist2 = bestDist; e2 = e1; has2 = has; bestDist = dist; e1 = e; has = true; }
+          else if (dist < bestDist2) { bestDist2 = dist; e2 = e; has2 = true; }
+        }
+        if (has) {
+          if (mode == 0) {
+            const int bestLevel = (int)((e1 >> 16) & 0xf), bestLevel2 = has2 ? (int)((e2 >> 16) & 0xf) : -1;
+            accept = bestDist <= ORBFE_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+          } else {
+            accept = bestDist <= ORBFE_TH_HIGH;
+          }
+        }
+      }
+      const int bestIdx = (int)(e1 & 0xffff);
+      const bool blk = accept && qblocks;
+      if (blk) atomicMin(&cnew[bestIdx], tid);
+      if (iter == 0 || e1 != pe1 || e2 != pe2 || has != phas || has2 != phas2) sh_changed[iter & 1] = 1;
+      __syncthreads();
+      const int again = sh_changed[iter & 1];
+      if (myclaim >= 0) cprev[myclaim] = 0x7fffffff;  // everybody is done reading cprev: recycle it as the next cnew
+      myclaim = blk ? bestIdx : -1;
+      if (tid == 0) sh_changed[(iter + 1) & 1] = 0;
+      __syncthreads();
+      if (!again) {
+        // converged: commit every accepted query of the chunk.  Several queries may take the same keypoint
+        // (only when the earlier ones do not block it): the last one in query order wins, as in the reference.
+        if (active && accept) atomicMin(&cprev[bestIdx], 255 - tid);
+        __syncthreads();
+        if (active && accept) {
+          if (cprev[bestIdx] == 255 - tid) {
+            assigned[bestIdx] = qi;
+            blocked[bestIdx] = (uint8_t)qblocks;
+          }
+          atomicAdd(&sh_nm, 1);
+          if (use_hist) {
+            float rot = qangle - keys[bestIdx].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));  // the reference's factor (sic), :1255
+            if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+            const int pos = atomicAdd(&sh_npush, 1);
+            push_idx[pos] = bestIdx;
+            push_bin[pos] = (uint8_t)bin;
+            atomicAdd(&hist[bin], 1);
+          }
+        }
+        __syncthreads();
+        if (active && accept) cprev[bestIdx] = 0x7fffffff;
+        if (myclaim >= 0) cnew[myclaim] = 0x7fffffff;
+        __syncthreads();
+        break;
       }
     }
+    q0 += len;
   }
-  if (lane == 0) n_matches[f] = nmatches;
+  __syncthreads();
+  if (use_hist && tid == 0) {
+    int i1, i2, i3;
+    three_maxima(hist, ORBFE_HISTO_LENGTH, i1, i2, i3);
+    const int np = sh_npush;
+    int removed = 0;
+    for (int k = 0; k < np; k++) {
+      const int bin = push_bin[k];
+      if (bin != i1 && bin != i2 && bin != i3) { assigned[push_idx[k]] = -1; removed++; }
+    }
+    sh_nm -= removed;
+  }
+  __syncthreads();
+  for (int i = tid; i < F.cap; i += 256) blocked_g[i] = blocked[i];
+  if (tid == 0) n_matches[f] = sh_nm;
 }
 
 // ------------------------------------------------------------------------------------------------ stereo
-// One wave per left keypoint.  Candidates = right keypoints whose row band [floor(y-r), ceil(y+r)],
-// r = 2*scale[octave], contains row (int)vL -- in ascending right index, which is the order the reference's
-// row table yields them (L/src/Frame.cc:493-502).
+// Right keypoints are first binned by the 8-row buckets their band [floor(y-r), ceil(y+r)], r = 2*scale[octave],
+// overlaps (one block per pair).  A left keypoint then only visits the bucket of its row (int)vL and re-tests
+// the exact band.  The reference walks its per-row lists in ascending right index with a strict "<"
+// (L/src/Frame.cc:493-502,536-553): the (distance, index) lexicographic minimum reproduces that first-wins
+// rule whatever order the candidates are visited in.
+__global__ __launch_bounds__(256) void stereo_bucket_kernel(StereoParams P) {
+  __shared__ int cnt[STEREO_MAX_BUCKETS];
+  __shared__ int start[STEREO_MAX_BUCKETS + 1];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int nR = P.nR[pair];
+  const int nb = P.n_buckets;
+  const orbfe_keypoint* kr = P.kpsR + (size_t)pair * P.cap;
+  int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
+  int32_t* bi = P.bucket_idx + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
+  for (int b = tid; b < nb; b += 256) cnt[b] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; pass++) {
+    for (int iR = tid; iR < nR; iR += 256) {
+      const orbfe_keypoint kp = kr[iR];
+      const float r = 2.0f * P.scale[kp.octave];
+      const int maxr = (int)ceilf(kp.y + r), minr = (int)floorf(kp.y - r);
+      int b0 = max(minr, 0) >> 3, b1 = min(maxr >> 3, nb - 1);
+      if (b1 - b0 >= STEREO_BUCKET_SPAN) b1 = b0 + STEREO_BUCKET_SPAN - 1;  // cannot happen for scale <= 12
+      for (int b = b0; b <= b1; b++) {
+        const int pos = atomicAdd(&cnt[b], 1);
+        if (pass == 1) bi[start[b] + pos] = iR;
+      }
+    }
+    __syncthreads();
+    if (pass == 0) {
+      if (tid == 0) {
+        int run = 0;
+        for (int b = 0; b < nb; b++) { start[b] = run; run += cnt[b]; }
+        start[nb] = run;
+      }
+      __syncthreads();
+      for (int b = tid; b <= nb; b += 256) bs[b] = start[b];
+      for (int b = tid; b < nb; b += 256) cnt[b] = 0;
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const int pair = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -413,7 +597,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   float* out_ur = P.u_right + (size_t)pair * P.cap;
   float* out_depth = P.depth + (size_t)pair * P.cap;
   int32_t* out_sad = P.sad + (size_t)pair * P.cap;
-  const int nL = P.nL[pair], nR = P.nR[pair];
+  const int nL = P.nL[pair];
   if (lane == 0) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
   if (iL >= nL) return;
   const orbfe_keypoint* kl = P.kpsL + (size_t)pair * P.cap;
@@ -431,8 +615,12 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   if (maxU < 0) return;
   uint4 a0, a1;
   load_desc(dl + (size_t)iL * 32, a0, a1);
-  unsigned best = ((unsigned)ORBFE_TH_HIGH << 16);  // bestDist starts at TH_HIGH; strict <
-  for (int iR = lane; iR < nR; iR += WAVE) {
+  unsigned best = ((unsigned)ORBFE_TH_HIGH << 16) | 0xffffu;  // bestDist starts at TH_HIGH; strict <
+  const int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
+  const int32_t* bidx = P.bucket_idx + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
+  const int e0 = bs[row >> 3], e1 = bs[(row >> 3) + 1];
+  for (int e = e0 + lane; e < e1; e += WAVE) {
+    const int iR = bidx[e];
     const orbfe_keypoint kpR = kr[iR];
     const float r = 2.0f * P.scale[kpR.octave];
     const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
@@ -442,7 +630,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
     uint4 b0, b1;
     load_desc(dr + (size_t)iR * 32, b0, b1);
     const unsigned key = ((unsigned)hamming256(a0, a1, b0, b1) << 16) | (unsigned)iR;
-    if ((key >> 16) < (best >> 16)) best = key;
+    if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) best = key;  // (dist, index) minimum among dist < TH_HIGH
   }
   // first minimum in index order
   {
@@ -602,10 +790,18 @@ void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbf
 void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
                                int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
                                int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s) {
-  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(64), (size_t)((f.cap + 15) & ~15), s, f, q, cand, n_cand, max_cand, mode, nnratio,
+  const size_t dyn = (size_t)(((f.cap + 15) & ~15) + 8 * (size_t)f.cap);
+  static size_t dyn_allowed = 28 * 1024;  // 64 KiB default limit minus this kernel's static LDS
+  if (dyn > dyn_allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_resolve_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    dyn_allowed = 120 * 1024;
+  }
+  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(256), dyn, s, f, q, cand, n_cand, max_cand, mode, nnratio,
                      check_ori, blocked, assigned, n_matches, push_idx, push_bin);
 }
 void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {
+  hipLaunchKernelGGL(stereo_bucket_kernel, dim3(n_pairs), dim3(256), 0, s, p);
   dim3 grid((p.cap + 3) / 4, n_pairs);
   hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, p);
   hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, p);

@@ -50,7 +50,7 @@ struct orbfe_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
   // scratch
-  MBuf cell_start, cell_idx, cand, n_cand, push_idx, push_bin, sad;
+  MBuf cell_start, cell_idx, cand, n_cand, push_idx, push_bin, sad, bucket_start, bucket_idx;
   // staging for the host-pointer entry points
   MBuf h_keys, h_desc, h_ur, h_q, h_n, h_nq, h_blocked, h_assigned, h_nm;
   std::mutex mu;
@@ -83,7 +83,7 @@ extern "C" int orbfe_matcher_destroy(orbfe_matcher* m) {
   if (!m) return ORBFE_OK;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->h_keys,
+  MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->bucket_start, &m->bucket_idx, &m->h_keys,
                   &m->h_desc, &m->h_ur, &m->h_q, &m->h_n, &m->h_nq, &m->h_blocked, &m->h_assigned, &m->h_nm};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -172,8 +172,8 @@ static int proj_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_
                         float max_y, const orbfe_query* d_q, const int32_t* d_nq, int q_cap, int mode, float nnratio,
                         int check_ori, uint8_t* d_blocked, int32_t* d_assigned, int32_t* d_nm, bool resolve,
                         hipStream_t s) {
-  if (cap > 60000) {
-    orbfe_set_error("frame capacity %d too large (LDS-resident blocked[] needs cap <= 60000)", cap);
+  if (cap > 13000) {  // blocked[] + claim[] + lastw[] (9 bytes per keypoint) live in LDS next to the staging area
+    orbfe_set_error("frame capacity %d too large for the LDS-resident resolver state (cap <= 13000)", cap);
     return ORBFE_ERR_INVALID;
   }
   if (((uintptr_t)d_desc & 15) || ((uintptr_t)d_q & 3) || ((uintptr_t)d_kps & 3)) {
@@ -281,6 +281,9 @@ extern "C" int orbfe_proj_candidates(const orbfe_frame_view* f, const orbfe_quer
   HIPCHK(hipMemcpyAsync(cand, m->cand.p, sizeof(orbfe_cand) * (size_t)nq * max_cand, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(n_cand, m->n_cand.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  // the kernel keeps the candidate's octave in bits 16..19 of dist for the resolver; the public field is the distance
+  for (int i = 0; i < nq; i++)
+    for (int c = 0; c < std::min(n_cand[i], max_cand); c++) cand[(size_t)i * max_cand + c].dist &= 0xffff;
   return ORBFE_OK;
 }
 
@@ -358,6 +361,17 @@ extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left
       return ORBFE_ERR_INVALID;
     }
   if ((rc = mb_alloc(m->sad, sizeof(int32_t) * (size_t)n_pairs * cap))) return rc;
+  if ((rc = mb_alloc(m->bucket_start, sizeof(int32_t) * (size_t)n_pairs * (STEREO_MAX_BUCKETS + 1)))) return rc;
+  if ((rc = mb_alloc(m->bucket_idx, sizeof(int32_t) * (size_t)n_pairs * cap * STEREO_BUCKET_SPAN))) return rc;
+  p.bucket_start = (int32_t*)m->bucket_start.p;
+  p.bucket_idx = (int32_t*)m->bucket_idx.p;
+  p.n_buckets = (p.pyrL.h[0] + 7) / 8;
+  if (p.n_buckets > STEREO_MAX_BUCKETS) return ORBFE_ERR_INVALID;
+  for (int l = 0; l < nl; l++)
+    if (2.0f * p.scale[l] + 2.0f > 8.0f * (STEREO_BUCKET_SPAN - 1) / 2.0f) {
+      orbfe_set_error("stereo match: pyramid scale %.2f too large for the row buckets", p.scale[l]);
+      return ORBFE_ERR_INVALID;
+    }
   p.kpsL = d_kps_l; p.descL = d_desc_l; p.nL = d_n_l;
   p.kpsR = d_kps_r; p.descR = d_desc_r; p.nR = d_n_r;
   p.cap = cap;

@@ -83,7 +83,7 @@ struct DescribeParams {
 };
 
 struct BlurTile {
-  int16_t level, tx, ty;  // tile origin = (tx*64, ty*16)
+  int16_t level, tx, ty;  // tile origin = (tx*64, ty*32)
   int16_t pad;
 };
 

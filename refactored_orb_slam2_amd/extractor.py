@@ -112,7 +112,7 @@ class ORBextractor:
         desc: uint8 (B, cap, 32); n_out: int32 (B).  Asynchronous on `stream` (torch stream or None)."""
         B, h, w = d_imgs.shape
         cap = desc.shape[1]
-        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(None)
+        s = _lib.stream_handle(stream)
         _lib.check(self._L.orbfe_extract_batch_device(
             self._h, _lib.ptr(d_imgs), B, w, h, d_imgs.stride(1), d_imgs.stride(0), _lib.ptr(kps), _lib.ptr(desc), cap,
             _lib.ptr(n_out), s), "orbfe_extract_batch_device")

@@ -63,9 +63,9 @@ class ORBmatcher:
         dA = torch.from_numpy(np.ascontiguousarray(A, np.uint8).reshape(-1, 32)).cuda()
         dB = torch.from_numpy(np.ascontiguousarray(B, np.uint8).reshape(-1, 32)).cuda()
         out = torch.zeros((dA.shape[0], dB.shape[0]), dtype=torch.int16, device="cuda")
-        s = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()  # inputs were produced on torch's default stream; the kernel runs on the NULL stream
         _lib.check(L.orbfe_hamming_matrix_device(_lib.ptr(dA), dA.shape[0], _lib.ptr(dB), dB.shape[0], _lib.ptr(out),
-                                                 C.c_void_p(s)), "orbfe_hamming_matrix_device")
+                                                 C.c_void_p(None)), "orbfe_hamming_matrix_device")
         torch.cuda.synchronize()
         return out.cpu().numpy().astype(np.int32)
 
@@ -86,10 +86,10 @@ class ORBmatcher:
         gB = None if groupB is None else torch.from_numpy(np.ascontiguousarray(groupB, np.int32)).cuda()
         mB = None if maskB is None else torch.from_numpy(np.ascontiguousarray(maskB, np.uint8)).cuda()
         out = torch.zeros((max(len(A), 1), 3), dtype=torch.int32, device="cuda")
-        s = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
         _lib.check(L.orbfe_hamming_bf_device(_lib.ptr(dA), _lib.ptr(nA), max(len(A), 1), len(A), _lib.ptr(dB), _lib.ptr(nB),
                                              max(len(B), 1), _lib.ptr(gA), _lib.ptr(gB), _lib.ptr(mB), 1, _lib.ptr(out),
-                                             C.c_void_p(s)), "orbfe_hamming_bf_device")
+                                             C.c_void_p(None)), "orbfe_hamming_bf_device")
         torch.cuda.synchronize()
         return out.cpu().numpy()[: len(A)].copy().view(BF_DTYPE).reshape(-1)
 
@@ -220,7 +220,7 @@ class Matcher:
         (F,cap) f32 or None, queries (F,qcap,68) u8, nq (F) i32, blocked (F,cap) u8, assigned (F,cap) i32,
         n_matches (F) i32."""
         F, cap = desc.shape[0], desc.shape[1]
-        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(None)
+        s = _lib.stream_handle(stream)
         _lib.check(self._L.orbfe_proj_match_batch_device(
             self._h, F, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n), _lib.ptr(u_right), cap, bounds[0], bounds[1], bounds[2],
             bounds[3], _lib.ptr(queries), _lib.ptr(nq), queries.shape[1], mode, nnratio, int(check_ori), _lib.ptr(blocked),
@@ -230,7 +230,7 @@ class Matcher:
                      stream=None):
         """Frame::ComputeStereoMatches for a batch of pairs (torch CUDA tensors, see proj_match_batch)."""
         P, cap = desc_l.shape[0], desc_l.shape[1]
-        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(None)
+        s = _lib.stream_handle(stream)
         _lib.check(self._L.orbfe_stereo_match_device(
             self._h, ex_left._h, ex_right._h, P, _lib.ptr(kps_l), _lib.ptr(desc_l), _lib.ptr(n_l), _lib.ptr(kps_r),
             _lib.ptr(desc_r), _lib.ptr(n_r), cap, mbf, mb, _lib.ptr(u_right), _lib.ptr(depth), _lib.ptr(n_matched), s),

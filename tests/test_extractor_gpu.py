@@ -102,6 +102,7 @@ def test_batch_equals_single_and_is_idempotent():
     from refactored_orb_slam2_amd._lib import KP_DTYPE
     for _ in range(2):
         kps.zero_(); desc.zero_()
+        torch.cuda.synchronize()  # torch's default stream does not order against the handle's own stream
         ex.extract_batch_device(dimg, kps, desc, n)
         ex.sync(); ex.device_status()
         for i in range(B):

@@ -207,12 +207,13 @@ def test_stereo_matches_batch(geom):
                   torch.zeros(P, dtype=torch.int32, device=dev))
     kl, dl, nl = mk()
     kr, dr, nr = mk()
-    exL.extract_batch_device(L, kl, dl, nl)
-    exR.extract_batch_device(R, kr, dr, nr)
-    exL.sync(); exR.sync()
     ur = torch.zeros((P, cap), dtype=torch.float32, device=dev)
     depth = torch.zeros((P, cap), dtype=torch.float32, device=dev)
     nmatched = torch.zeros(P, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # torch's default stream does not order against the handles' own streams
+    exL.extract_batch_device(L, kl, dl, nl)
+    exR.extract_batch_device(R, kr, dr, nr)
+    exL.sync(); exR.sync()
     mbf, fx = 386.1448, 718.856
     mb = mbf / fx
     m = Matcher()
@@ -301,3 +302,49 @@ def test_empty_inputs():
     q["valid"] = 1; q["u"] = 5000.0   # every projection outside the grid
     nm, a, b = ORBmatcher().SearchByProjectionFrame(fv, q)
     assert nm == 0
+
+
+def test_bench_pipeline_matches_oracle():
+    """The exact device-resident sequence bench.py times (2x extract -> stereo -> queries -> SearchByProjection
+    (cur,last)) on a short KITTI-geometry sequence, every frame checked against the oracle."""
+    import torch
+    import bench
+    from refactored_orb_slam2_amd._lib import KP_DTYPE, QUERY_DTYPE
+    W, H, NF, F = bench.W, bench.H, bench.NFEAT, 4
+    pairs = synth.sequence(W, H, F, seq=0, stereo=True)
+    dev = "cuda"
+    dL = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    dR = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    exL, exR, mt = ORBextractor(NF), ORBextractor(NF), Matcher()
+    cap = exL.max_keypoints(W, H)
+    mk = lambda: (torch.zeros((F, cap, 28), dtype=torch.uint8, device=dev), torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.zeros(F, dtype=torch.int32, device=dev))
+    kl, dl, nl = mk(); kr, dr, nr = mk()
+    ur = torch.zeros((F, cap), dtype=torch.float32, device=dev); depth = torch.zeros_like(ur)
+    n_st = torch.zeros(F, dtype=torch.int32, device=dev)
+    blocked = torch.zeros((F, cap), dtype=torch.uint8, device=dev)
+    assigned = torch.full((F, cap), -1, dtype=torch.int32, device=dev)
+    n_tr = torch.zeros(F, dtype=torch.int32, device=dev)
+    sf = exL.GetScaleFactors(); isf = exL.GetInverseScaleFactors()
+    mb = bench.MBF / bench.FX
+    torch.cuda.synchronize()
+    exL.extract_batch_device(dL, kl, dl, nl); exR.extract_batch_device(dR, kr, dr, nr)
+    exL.sync(); exR.sync()
+    cur = torch.cuda.Stream()
+    with torch.cuda.stream(cur):
+        mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, bench.MBF, mb, ur, depth, n_st, stream=cur)
+        q, nq = bench.build_queries(torch, kl, dl, nl, ur, torch.from_numpy(sf).to(dev), -2.0)
+        mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned, n_tr, stream=cur)
+    torch.cuda.synchronize()
+    qh = q.cpu().numpy().reshape(F, cap * 68).view(QUERY_DTYPE).reshape(F, cap)
+    for f in range(F):
+        n = int(nl[f])
+        k = kl[f].cpu().numpy().view(KP_DTYPE).reshape(-1)[:n]
+        d = dl[f].cpu().numpy()[:n]
+        u = ur[f].cpu().numpy()[:n]
+        of = ol.OracleFrame(k, d, sf, 0, W, 0, H, u)
+        onm, oa, ob = of.search_by_projection_frame(qh[f, : int(nq[f])], True)
+        assert int(n_tr[f]) == onm, f
+        np.testing.assert_array_equal(assigned[f].cpu().numpy()[:n], oa)
+        np.testing.assert_array_equal(blocked[f].cpu().numpy()[:n], ob)
+        assert onm > 500
