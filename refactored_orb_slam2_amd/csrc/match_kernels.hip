@@ -304,8 +304,8 @@ __device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& in
   else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// Order-dependent assignment of SearchByProjection.  One 256-thread workgroup per frame.  Queries are taken
-// up to 256 at a time (one per thread) and resolved SPECULATIVELY against the current blocked[] state; a
+// Order-dependent assignment of SearchByProjection.  One 1024-thread workgroup per frame.  Queries are taken
+// up to RC_THREADS (1024) at a time (one per thread) and resolved SPECULATIVELY against the current blocked[] state; a
 // thread's result is exact unless an earlier thread of the same chunk blocks its best (mode 0: best or
 // second-best) candidate.  Threads before the first such conflict commit together, the rest are recomputed --
 // the outcome is identical to walking the queries one by one (L/src/ORBmatcher.cc:52-125, 1270-1361), and
@@ -313,16 +313,17 @@ __device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& in
 // alone by wave 0, which re-enumerates its window.
 // mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)   -- best/second with the same-level ratio test
 // mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, TH_HIGH, rotation histogram
-#define RC_LIST_CAP 8192  // staged candidate entries per chunk (32 KiB)
-__global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
+#define RC_THREADS 1024
+#define RC_LIST_CAP 16384  // staged candidate entries per chunk (64 KiB)
+__global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
                                                            const int32_t* __restrict__ n_cand, int max_cand, int mode,
                                                            float nnratio, int check_ori, uint8_t* __restrict__ blocked_all,
                                                            int32_t* __restrict__ assigned_all, int32_t* __restrict__ n_matches,
                                                            int32_t* __restrict__ push_idx_all, uint8_t* __restrict__ push_bin_all) {
   __shared__ int hist[ORBFE_HISTO_LENGTH];
   __shared__ uint32_t lc[RC_LIST_CAP];  // staged candidate lists: dist<<20 | octave<<16 | idx
-  __shared__ int loff[257];
-  __shared__ int scan_tmp[8];
+  __shared__ int loff[RC_THREADS + 1];
+  __shared__ int scan_tmp[RC_THREADS / WAVE];
   __shared__ int sh_len, sh_nm, sh_npush;
   __shared__ int sh_changed[2];
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBa
   const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
   const orbfe_query* qbase = Q.q + (size_t)f * Q.cap;
   const int32_t* ncb = n_cand + (size_t)f * Q.cap;
-  for (int i = tid; i < F.cap; i += 256) { blocked[i] = blocked_g[i]; claim[i] = 0x7fffffff; claimB[i] = 0x7fffffff; }
+  for (int i = tid; i < F.cap; i += RC_THREADS) { blocked[i] = blocked_g[i]; claim[i] = 0x7fffffff; claimB[i] = 0x7fffffff; }
   if (tid < ORBFE_HISTO_LENGTH) hist[tid] = 0;
   if (tid == 0) { sh_nm = 0; sh_npush = 0; }
   __syncthreads();
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBa
       qangle = qbase[qi].angle;
     }
     // chunk = queries q0 .. q0+len-1: stops before the first truncated list and before the staging area is full
-    if (tid == 0) { sh_len = min(256, nq - q0); sh_changed[0] = 0; sh_changed[1] = 0; }
+    if (tid == 0) { sh_len = min(RC_THREADS, nq - q0); sh_changed[0] = 0; sh_changed[1] = 0; }
     __syncthreads();
     {
       const int v = tot > max_cand ? 0 : tot;
@@ -470,13 +471,24 @@ __global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBa
       e1 = e2 = 0;
       has = has2 = accept = false;
       if (active) {
-        for (int c = 0; c < tot; c++) {
-          const uint32_t e = mylist[c];
-          const int idx = (int)(e & 0xffff);
-          if (blocked[idx] || cprev[idx] < tid) continue;
-          const int dist = (int)(e >> 20);
-          if (dist < bestDist) { bestDist2 = bestDist; e2 = e1; has2 = has; bestDist = dist; e1 = e; has = true; }
-          else if (dist < bestDist2) { bestDist2 = dist; e2 = e; has2 = true; }
+        for (int c0 = 0; c0 < tot; c0 += 4) {  // 4 candidates in flight: independent LDS loads first, then the scan
+          uint32_t ev[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) ev[u] = mylist[min(c0 + u, tot - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int idx = (int)(ev[u] & 0xffff);
+            ok[u] = (c0 + u < tot) && !blocked[idx] && !(cprev[idx] < tid);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            const uint32_t e = ev[u];
+            const int dist = (int)(e >> 20);
+            if (dist < bestDist) { bestDist2 = bestDist; e2 = e1; has2 = has; bestDist = dist; e1 = e; has = true; }
+            else if (dist < bestDist2) { bestDist2 = dist; e2 = e; has2 = true; }
+          }
         }
         if (has) {
           if (mode == 0) {
@@ -500,10 +512,10 @@ __global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBa
       if (!again) {
         // converged: commit every accepted query of the chunk.  Several queries may take the same keypoint
         // (only when the earlier ones do not block it): the last one in query order wins, as in the reference.
-        if (active && accept) atomicMin(&cprev[bestIdx], 255 - tid);
+        if (active && accept) atomicMin(&cprev[bestIdx], RC_THREADS - 1 - tid);
         __syncthreads();
         if (active && accept) {
-          if (cprev[bestIdx] == 255 - tid) {
+          if (cprev[bestIdx] == RC_THREADS - 1 - tid) {
             assigned[bestIdx] = qi;
             blocked[bestIdx] = (uint8_t)qblocks;
           }
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(256) void proj_resolve_kernel(FrameBatch F, QueryBa
     sh_nm -= removed;
   }
   __syncthreads();
-  for (int i = tid; i < F.cap; i += 256) blocked_g[i] = blocked[i];
+  for (int i = tid; i < F.cap; i += RC_THREADS) blocked_g[i] = blocked[i];
   if (tid == 0) n_matches[f] = sh_nm;
 }
 
@@ -791,13 +803,13 @@ void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const o
                                int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
                                int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s) {
   const size_t dyn = (size_t)(((f.cap + 15) & ~15) + 8 * (size_t)f.cap);
-  static size_t dyn_allowed = 28 * 1024;  // 64 KiB default limit minus this kernel's static LDS
+  static size_t dyn_allowed = 0;  // this kernel's static LDS alone is ~69 KiB: always raise the limit
   if (dyn > dyn_allowed) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_resolve_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    dyn_allowed = 120 * 1024;
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024);
+    dyn_allowed = 88 * 1024;
   }
-  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(256), dyn, s, f, q, cand, n_cand, max_cand, mode, nnratio,
+  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, nnratio,
                      check_ori, blocked, assigned, n_matches, push_idx, push_bin);
 }
 void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {

@@ -172,8 +172,8 @@ static int proj_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_
                         float max_y, const orbfe_query* d_q, const int32_t* d_nq, int q_cap, int mode, float nnratio,
                         int check_ori, uint8_t* d_blocked, int32_t* d_assigned, int32_t* d_nm, bool resolve,
                         hipStream_t s) {
-  if (cap > 13000) {  // blocked[] + claim[] + lastw[] (9 bytes per keypoint) live in LDS next to the staging area
-    orbfe_set_error("frame capacity %d too large for the LDS-resident resolver state (cap <= 13000)", cap);
+  if (cap > 9500) {  // blocked[] + two claim buffers (9 bytes per keypoint) live in LDS next to the 64 KiB staging area
+    orbfe_set_error("frame capacity %d too large for the LDS-resident resolver state (cap <= 9500)", cap);
     return ORBFE_ERR_INVALID;
   }
   if (((uintptr_t)d_desc & 15) || ((uintptr_t)d_q & 3) || ((uintptr_t)d_kps & 3)) {
