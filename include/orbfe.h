@@ -215,6 +215,14 @@ int orbfe_search_by_projection_points(const orbfe_frame_view* frame, const orbfe
 int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_query* q, int nq,
                                      int check_orientation, uint8_t* blocked, int32_t* assigned, int* n_matches);
 
+/* SearchForInitialization (L/src/ORBmatcher.cc:388-492), the monocular map-initialisation matcher: level-0
+ * keypoints of F1 are searched in a window of `window_size` pixels around prev_matched_xy[2*i..2*i+1] in F2; a
+ * closer later keypoint steals an earlier match (vMatchedDistance / vnMatches21).  matches12[i] = F2 index or -1;
+ * prev_matched_xy is updated for the matched keypoints (:487-489).  HOST pointers, synchronous. */
+int orbfe_search_for_initialization(const orbfe_frame_view* f1, const orbfe_frame_view* f2, float* prev_matched_xy,
+                                    int window_size, float nnratio, int check_orientation, int32_t* matches12,
+                                    int* n_matches);
+
 /* Both searches for n_frames frames at once, DEVICE pointers, asynchronous on stream (NULL: the handle's).
  * Frame f: keypoints/descriptors/u_right rows [f*cap, f*cap + d_n[f]); queries [f*q_cap, f*q_cap + d_nq[f]).
  * mode 0 = A11 (points, ratio test nnratio), mode 1 = A12 (frame, rotation histogram if check_orientation).

@@ -66,4 +66,7 @@ void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbf
 void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
                                int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
                                int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s);
+void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
+                               int max_cand, float nnratio, int check_ori, int32_t* matches12, float* prev_xy,
+                               int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, hipStream_t s);
 void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s);

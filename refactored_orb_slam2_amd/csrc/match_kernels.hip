@@ -557,6 +557,110 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
   if (tid == 0) n_matches[f] = sh_nm;
 }
 
+// ------------------------------------------------------------------------------------------------ mono init
+// ORBmatcher::SearchForInitialization (L/src/ORBmatcher.cc:388-492).  Every F1 keypoint may steal an F2 keypoint
+// from an earlier one when it is strictly closer (vMatchedDistance / vnMatches21), so the queries are walked
+// strictly in order by ONE wave; the lanes share each query's candidates (stored list, or the re-enumerated
+// window when the list was truncated).  Runs a handful of times per session (map initialisation).
+__global__ __launch_bounds__(64) void init_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
+                                                           const int32_t* __restrict__ n_cand, int max_cand, float nnratio,
+                                                           int check_ori, int32_t* __restrict__ matches12,
+                                                           float* __restrict__ prev_xy, int32_t* __restrict__ n_matches,
+                                                           int32_t* __restrict__ push_idx, uint8_t* __restrict__ push_bin) {
+  __shared__ int hist[ORBFE_HISTO_LENGTH];
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+  int* matchedDist = reinterpret_cast<int*>(dyn);  // vMatchedDistance
+  int* matches21 = matchedDist + F.cap;             // vnMatches21
+  const int lane = threadIdx.x;
+  const int n1 = Q.n[0], n2 = F.n[0];
+  const orbfe_keypoint* keys2 = F.keys;
+  for (int i = lane; i < n2; i += WAVE) { matchedDist[i] = 2147483647; matches21[i] = -1; }
+  for (int i = lane; i < n1; i += WAVE) matches12[i] = -1;
+  if (lane < ORBFE_HISTO_LENGTH) hist[lane] = 0;
+  __syncthreads();
+  int npush = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    const orbfe_query* qp = Q.q + i1;
+    if (!qp->valid) continue;  // level1 > 0
+    const int total = n_cand[i1];
+    if (total == 0) continue;
+    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    int i1b = -1;
+    auto consider = [&](int rank, int idx, int dist) {
+      if (matchedDist[idx] <= dist) return;
+      const unsigned key = ((unsigned)dist << 16) | (unsigned)min(rank, 0xffff);
+      if (key < k1) { k2 = k1; k1 = key; i1b = idx; }
+      else if (key < k2) { k2 = key; }
+    };
+    if (total <= max_cand) {
+      const orbfe_cand* cl = cand + (size_t)i1 * max_cand;
+      for (int c = lane; c < total; c += WAVE) consider(c, cl[c].idx, cl[c].dist & 0xffff);
+    } else {
+      const orbfe_query q = *qp;
+      uint4 d0, d1;
+      load_desc4(qp->desc, d0, d1);
+      enumerate_window(F, 0, q, d0, d1, consider);
+    }
+    const unsigned b = wave_min_u32(k1);
+    if (b != 0xFFFFFFFFu) {
+      const unsigned long long wm = __ballot(k1 == b);
+      const int wl = __ffsll((long long)wm) - 1;
+      const int bestIdx2 = __shfl(i1b, wl, WAVE);
+      const int bestDist = (int)(b >> 16);
+      const unsigned mine = (lane == wl) ? k2 : k1;
+      const unsigned s2 = wave_min_u32(mine);
+      const int bestDist2 = s2 != 0xFFFFFFFFu ? (int)(s2 >> 16) : 2147483647;
+      if (bestDist <= ORBFE_TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {
+        if (lane == 0) {
+          const int prev = matches21[bestIdx2];
+          if (prev >= 0) matches12[prev] = -1;
+          matches12[i1] = bestIdx2;
+          matches21[bestIdx2] = i1;
+          matchedDist[bestIdx2] = bestDist;
+          if (check_ori) {
+            float rot = qp->angle - keys2[bestIdx2].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
+            if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+            push_idx[npush] = i1;
+            push_bin[npush] = (uint8_t)bin;
+            hist[bin]++;
+          }
+        }
+        npush += check_ori ? 1 : 0;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (check_ori) {
+      int a, b2, c;
+      three_maxima(hist, ORBFE_HISTO_LENGTH, a, b2, c);
+      for (int k = 0; k < npush; k++) {
+        const int bin = push_bin[k];
+        if (bin != a && bin != b2 && bin != c) {
+          const int idx1 = push_idx[k];
+          if (matches12[idx1] >= 0) matches12[idx1] = -1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int i = lane; i < n1; i += WAVE) {
+    const int m = matches12[i];
+    if (m >= 0) {
+      cnt++;
+      prev_xy[2 * i] = keys2[m].x;      // vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt (:487-489)
+      prev_xy[2 * i + 1] = keys2[m].y;
+    }
+  }
+  // the reference's nmatches (++ on assignment, -- on steal / rotation reject) == F1 keypoints still holding a match
+  cnt = wave_sum_i32(cnt);
+  if (lane == 0) n_matches[0] = cnt;
+}
+
 // ------------------------------------------------------------------------------------------------ stereo
 // Right keypoints are first binned by the 8-row buckets their band [floor(y-r), ceil(y+r)], r = 2*scale[octave],
 // overlaps (one block per pair).  A left keypoint then only visits the bucket of its row (int)vL and re-tests
@@ -811,6 +915,12 @@ void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const o
   }
   hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, nnratio,
                      check_ori, blocked, assigned, n_matches, push_idx, push_bin);
+}
+void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
+                               int max_cand, float nnratio, int check_ori, int32_t* matches12, float* prev_xy,
+                               int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, hipStream_t s) {
+  hipLaunchKernelGGL(init_resolve_kernel, dim3(1), dim3(64), (size_t)f.cap * 8, s, f, q, cand, n_cand, max_cand, nnratio,
+                     check_ori, matches12, prev_xy, n_matches, push_idx, push_bin);
 }
 void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {
   hipLaunchKernelGGL(stereo_bucket_kernel, dim3(n_pairs), dim3(256), 0, s, p);

@@ -325,6 +325,70 @@ extern "C" int orbfe_search_by_projection_frame(const orbfe_frame_view* f, const
   return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches);
 }
 
+// SearchForInitialization (L/src/ORBmatcher.cc:388-492), host pointers, synchronous
+extern "C" int orbfe_search_for_initialization(const orbfe_frame_view* f1, const orbfe_frame_view* f2, float* prev_matched_xy,
+                                               int window_size, float nnratio, int check_orientation, int32_t* matches12,
+                                               int* n_matches) {
+  if (!frame_ok(f2) || !f1 || f1->n < 0 || (f1->n > 0 && (!f1->keys_un || !f1->desc || !prev_matched_xy || !matches12)) ||
+      !n_matches || window_size < 0)
+    return ORBFE_ERR_INVALID;
+  *n_matches = 0;
+  const int n1 = f1->n;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0 || f2->n == 0) return ORBFE_OK;
+  // one query per F1 keypoint: window around vbPrevMatched[i1], level filter (level1, level1) (:403-410)
+  std::vector<orbfe_query> q((size_t)n1);
+  for (int i = 0; i < n1; i++) {
+    orbfe_query& e = q[i];
+    memset(&e, 0, sizeof(e));
+    const int level1 = f1->keys_un[i].octave;
+    if (level1 > 0) continue;
+    e.u = prev_matched_xy[2 * i];
+    e.v = prev_matched_xy[2 * i + 1];
+    e.radius = (float)window_size;
+    e.min_level = level1;
+    e.max_level = level1;
+    e.valid = 1;
+    e.angle = f1->keys_un[i].angle;
+    memcpy(e.desc, f1->desc + (size_t)i * 32, 32);
+  }
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  orbfe_frame_view f2n = *f2;
+  f2n.u_right = nullptr;  // no stereo gate in this search
+  if ((rc = stage_host(m, &f2n, q.data(), n1, s))) return rc;
+  const int cap = f2->n;
+  if ((rc = ensure_proj_scratch(m, 1, cap, n1))) return rc;
+  if ((rc = mb_alloc(m->h_assigned, sizeof(int32_t) * (size_t)std::max(n1, cap)))) return rc;
+  if ((rc = mb_alloc(m->h_ur, sizeof(float) * 2 * (size_t)std::max(n1, cap)))) return rc;  // prev_matched staging
+  if ((size_t)cap * 8 > 60 * 1024) {
+    orbfe_set_error("SearchForInitialization: frame with %d keypoints exceeds the LDS-resident tables", cap);
+    return ORBFE_ERR_INVALID;
+  }
+  HIPCHK(hipMemcpyAsync(m->h_ur.p, prev_matched_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
+  FrameBatch fb;
+  fill_frame_batch(m, fb, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p, nullptr,
+                   cap, f2->min_x, f2->max_x, f2->min_y, f2->max_y);
+  QueryBatch qb{(const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, n1};
+  orbfe_launch_grid_build(fb, 1, s);
+  orbfe_launch_proj_candidates(fb, qb, (orbfe_cand*)m->cand.p, (int32_t*)m->n_cand.p, ORBFE_MAX_CAND, 1, s);
+  orbfe_launch_init_resolve(fb, qb, (const orbfe_cand*)m->cand.p, (const int32_t*)m->n_cand.p, ORBFE_MAX_CAND, nnratio,
+                            check_orientation, (int32_t*)m->h_assigned.p, (float*)m->h_ur.p, (int32_t*)m->h_nm.p,
+                            (int32_t*)m->push_idx.p, (uint8_t*)m->push_bin.p, s);
+  if ((rc = launch_ok())) return rc;
+  int32_t nm = 0;
+  HIPCHK(hipMemcpyAsync(matches12, m->h_assigned.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(prev_matched_xy, m->h_ur.p, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&nm, m->h_nm.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_matches = nm;
+  return ORBFE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ stereo
 extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
                                          const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,

@@ -125,6 +125,17 @@ class ORBmatcher:
                    "orbfe_search_by_projection_frame")
         return nm.value, assigned, blocked
 
+    # ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): ORBmatcher.cc:388-492
+    def SearchForInitialization(self, f1: FrameView, f2: FrameView, prev_matched: np.ndarray, windowSize: int = 10):
+        """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        prev = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+        m12 = np.full(f1.n, -1, np.int32)
+        nm = C.c_int(0)
+        _lib.check(self._L.orbfe_search_for_initialization(C.byref(f1.c), C.byref(f2.c), _lib.ptr(prev), int(windowSize),
+                                                           self.mfNNratio, int(self.mbCheckOrientation), _lib.ptr(m12),
+                                                           C.byref(nm)), "orbfe_search_for_initialization")
+        return nm.value, m12, prev
+
     # ---- SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&): ORBmatcher.cc:161-273
     def SearchByBoW(self, descA, angleA, validA, groupsA: dict, descB, angleB, groupsB: dict):
         """groupsA/groupsB: {node_id: [feature indices]} (DBoW2::FeatureVector).  Distances of every

@@ -298,6 +298,15 @@ class OracleFrame:
         return nm, assigned, blocked
 
 
+def search_for_initialization(keys1, desc1, frame2: "OracleFrame", prev_xy, window, nnratio, check_orientation=True):
+    keys1 = np.ascontiguousarray(keys1, KP_DTYPE); desc1 = np.ascontiguousarray(desc1, np.uint8)
+    prev = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2).copy()
+    m12 = np.full(len(keys1), -1, np.int32)
+    nm = lib().oo_search_for_initialization(_p(keys1), _p(desc1), len(keys1), C.byref(frame2.f), _p(prev), int(window),
+                                            nnratio, int(check_orientation), _p(m12))
+    return nm, m12, prev
+
+
 def featvec_arrays(groups: dict):
     """{node_id: [indices]} -> (nodes array of FeatVecNode, idx int32 array), nodes sorted by id."""
     ids = sorted(groups)

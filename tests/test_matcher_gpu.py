@@ -348,3 +348,24 @@ def test_bench_pipeline_matches_oracle():
         np.testing.assert_array_equal(assigned[f].cpu().numpy()[:n], oa)
         np.testing.assert_array_equal(blocked[f].cpu().numpy()[:n], ob)
         assert onm > 500
+
+
+@pytest.mark.parametrize("window,ratio", [(100, 0.9), (30, 0.9), (100, 0.6)])
+def test_search_for_initialization(window, ratio):
+    """mono initialisation matcher incl. match stealing (vMatchedDistance) and huge windows (list overflow)"""
+    ex = ORBextractor(2000)
+    a, b = synth.sequence(640, 480, 2, seq=15)
+    (k0, d0), (k1, d1) = ex.extract_batch([a, b])
+    sf = ex.GetScaleFactors()
+    ex.close()
+    prev = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32)  # vbPrevMatched starts at F1's own keypoints
+    f1 = FrameView(k0, d0, 0, 640, 0, 480)
+    f2 = FrameView(k1, d1, 0, 640, 0, 480)
+    of2 = ol.OracleFrame(k1, d1, sf, 0, 640, 0, 480)
+    for check in (True, False):
+        nm, m12, p2 = ORBmatcher(ratio, check).SearchForInitialization(f1, f2, prev, window)
+        onm, om12, op2 = ol.search_for_initialization(k0, d0, of2, prev, window, np.float32(ratio), check)
+        assert nm == onm
+        np.testing.assert_array_equal(m12, om12)
+        np.testing.assert_array_equal(p2, op2)
+        assert nm > 100 and np.all(m12[k0["octave"] > 0] == -1)
