@@ -92,6 +92,8 @@ int orbfe_extract(orbfe_extractor* e, const uint8_t* img, int w, int h, int stri
  * Frame::ComputeStereoMatches, L/src/Frame.cc:483,567-589).  Copies the level (no border) to host. */
 int orbfe_pyramid_level(orbfe_extractor* e, int level, uint8_t* dst, int dst_stride, int* w, int* h);
 int orbfe_pyramid_level_size(const orbfe_extractor* e, int w0, int h0, int level, int* w, int* h);
+/* All levels at once (one device synchronisation): dst[level] receives level `level` with row stride dst_stride[level]. */
+int orbfe_pyramid_levels(orbfe_extractor* e, uint8_t* const* dst, const int* dst_stride);
 
 /* Batched operator(): n_images host images of identical geometry, synchronous.  imgs[i] points to image i.
  * kps: n_images x cap, desc: n_images x cap x 32, n_out: n_images. */

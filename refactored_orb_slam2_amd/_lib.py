@@ -48,7 +48,7 @@ EXPORTS = [
     "orbfe_last_error", "orbfe_device_count", "orbfe_extractor_create", "orbfe_extractor_destroy",
     "orbfe_extractor_levels", "orbfe_extractor_scale_factors", "orbfe_extractor_inv_scale_factors",
     "orbfe_extractor_sigma2", "orbfe_extractor_inv_sigma2", "orbfe_extractor_features_per_level",
-    "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_pyramid_level", "orbfe_pyramid_level_size",
+    "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_pyramid_level", "orbfe_pyramid_level_size", "orbfe_pyramid_levels",
     "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_device_pyramid", "orbfe_sync",
     "orbfe_device_status", "orbfe_debug_candidates", "orbfe_debug_blurred", "orbfe_debug_pyramid",
     "orbfe_debug_level_keypoints", "orbfe_profile_enable", "orbfe_stage_times",
@@ -96,6 +96,7 @@ def lib():
     L.orbfe_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, pi]
     L.orbfe_pyramid_level.argtypes = [vp, ci, vp, ci, pi, pi]
     L.orbfe_pyramid_level_size.argtypes = [vp, ci, ci, ci, pi, pi]
+    L.orbfe_pyramid_levels.argtypes = [vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, sz, vp, vp, ci, vp, vp]
     L.orbfe_device_pyramid.argtypes = [vp, ci, ci, C.POINTER(vp), pi, pi, pi]

@@ -90,8 +90,10 @@ struct orbfe_extractor {
   // work space for `cap_images`
   int cap_images = 0;
   DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_off, d_slots, d_gkeys, d_lvl_kp, d_lvl_n, d_err;
-  // host-API outputs
-  DevBuf d_out_kps, d_out_desc, d_out_n;
+  // host-API staging: one pinned buffer each way + device mirrors (single H2D, single D2H, one sync per call)
+  DevBuf d_out_kps, d_out_desc, d_out_n, d_in_stage;
+  void* h_in = nullptr;  size_t h_in_bytes = 0;    // pinned: caller images, packed
+  void* h_out = nullptr; size_t h_out_bytes = 0;   // pinned: [n_out[B] | err | kps | desc] / pyramid planes
   int out_cap = 0;
   int last_images = 0;
   // profiling
@@ -112,6 +114,15 @@ static int dev_alloc(DevBuf& b, size_t bytes) {
   if (bytes == 0) bytes = 256;
   HIPCHK(hipMalloc(&b.p, bytes));
   b.bytes = bytes;
+  return ORBFE_OK;
+}
+static int pinned_alloc(void*& p, size_t& have, size_t bytes) {
+  if (p && bytes <= have) return ORBFE_OK;
+  if (p) HIPCHK(hipHostFree(p));
+  p = nullptr;
+  have = 0;
+  HIPCHK(hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault));
+  have = bytes ? bytes : 256;
   return ORBFE_OK;
 }
 static void dev_free(DevBuf& b) {
@@ -521,6 +532,9 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   DevBuf* bufs[] = {&e->d_cells, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
                     &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
   for (auto b : bufs) dev_free(*b);
+  dev_free(e->d_in_stage);
+  if (e->h_in) (void)hipHostFree(e->h_in);
+  if (e->h_out) (void)hipHostFree(e->h_out);
   for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { dev_free(e->d_xt[l]); dev_free(e->d_yt[l]); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -625,36 +639,59 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
   if ((rc = build_plan(e, w, h))) return rc;
   if ((rc = ensure_workspace(e, n_images))) return rc;
   hipStream_t s = e->stream;
-  if (cap > e->out_cap || (size_t)cap * n_images * sizeof(orbfe_keypoint) > e->d_out_kps.bytes) {
+  const size_t B = (size_t)n_images;
+  const size_t img_bytes = (size_t)w * h;  // packed rows in the staging buffers
+  const size_t kp_bytes = sizeof(orbfe_keypoint) * (size_t)cap * B, desc_bytes = (size_t)32 * cap * B;
+  const size_t hdr_bytes = ((sizeof(int32_t) * (B + 1)) + 255) & ~(size_t)255;  // n_out[B], err
+  if (cap != e->out_cap || kp_bytes > e->d_out_kps.bytes || desc_bytes > e->d_out_desc.bytes || hdr_bytes > e->d_out_n.bytes) {
     HIPCHK(hipStreamSynchronize(s));
-    if ((rc = dev_alloc(e->d_out_kps, sizeof(orbfe_keypoint) * (size_t)cap * n_images))) return rc;
-    if ((rc = dev_alloc(e->d_out_desc, (size_t)32 * cap * n_images))) return rc;
+    if ((rc = dev_alloc(e->d_out_kps, kp_bytes))) return rc;
+    if ((rc = dev_alloc(e->d_out_desc, desc_bytes))) return rc;
+    if ((rc = dev_alloc(e->d_out_n, hdr_bytes))) return rc;
     e->out_cap = cap;
   }
-  if ((rc = dev_alloc(e->d_out_n, sizeof(int32_t) * (size_t)std::max(n_images, e->cap_images)))) return rc;
+  if ((rc = dev_alloc(e->d_in_stage, img_bytes * B))) return rc;
+  if ((rc = pinned_alloc(e->h_in, e->h_in_bytes, img_bytes * B))) return rc;
+  if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, hdr_bytes + kp_bytes + desc_bytes))) return rc;
+  // pack the caller's rows into pinned memory, one asynchronous H2D, device-side pitch conversion
   for (int i = 0; i < n_images; i++) {
     if (!imgs[i]) return ORBFE_ERR_INVALID;
-    HIPCHK(hipMemcpy2DAsync(level_ptr(e, e->d_pyr, 0, i), e->lg[0].pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, s));
+    uint8_t* dst = (uint8_t*)e->h_in + (size_t)i * img_bytes;
+    if (stride == w) memcpy(dst, imgs[i], img_bytes);
+    else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, imgs[i] + (size_t)y * stride, (size_t)w);
   }
-  if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap,
-                             (int32_t*)e->d_out_n.p, s)))
+  HIPCHK(hipMemcpyAsync(e->d_in_stage.p, e->h_in, img_bytes * B, hipMemcpyHostToDevice, s));
+  {
+    StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
+    orbfe_launch_copy0((const uint8_t*)e->d_in_stage.p, w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch,
+                       e->lg[0].plane, w, h, n_images, s);
+  }
+  int32_t* d_hdr = (int32_t*)e->d_out_n.p;
+  if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap, d_hdr, s)))
     return rc;
-  HIPCHK(hipMemcpyAsync(n_out, e->d_out_n.p, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, s));
-  if ((rc = check_device_error(e, s))) return rc;
-  for (int i = 0; i < n_images; i++) {
-    if (n_out[i] > cap) {
-      orbfe_set_error("image %d produced %d keypoints, capacity %d", i, n_out[i], cap);
-      return ORBFE_ERR_CAPACITY;
-    }
-    if (n_out[i] > 0) {
-      HIPCHK(hipMemcpyAsync(kps + (size_t)i * cap, (orbfe_keypoint*)e->d_out_kps.p + (size_t)i * cap,
-                            sizeof(orbfe_keypoint) * n_out[i], hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(desc + (size_t)i * cap * 32, (uint8_t*)e->d_out_desc.p + (size_t)i * cap * 32,
-                            (size_t)32 * n_out[i], hipMemcpyDeviceToHost, s));
-    }
-  }
+  // results: header (counts + device error word) and the full padded records, one sync
+  HIPCHK(hipMemcpyAsync(d_hdr + B, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  uint8_t* ho = (uint8_t*)e->h_out;
+  HIPCHK(hipMemcpyAsync(ho, d_hdr, sizeof(int32_t) * (B + 1), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(ho + hdr_bytes, e->d_out_kps.p, kp_bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(ho + hdr_bytes + kp_bytes, e->d_out_desc.p, desc_bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (e->profile) drain_events(e);
+  const int32_t* hn = (const int32_t*)ho;
+  if (hn[B] != 0) {
+    orbfe_set_error("device-side capacity error word 0x%x", hn[B]);
+    (void)hipMemsetAsync(e->d_err.p, 0, 4, s);
+    return ORBFE_ERR_CAPACITY;
+  }
+  for (int i = 0; i < n_images; i++) {
+    n_out[i] = hn[i];
+    if (hn[i] > cap) {
+      orbfe_set_error("image %d produced %d keypoints, capacity %d", i, hn[i], cap);
+      return ORBFE_ERR_CAPACITY;
+    }
+    memcpy(kps + (size_t)i * cap, ho + hdr_bytes + sizeof(orbfe_keypoint) * (size_t)i * cap, sizeof(orbfe_keypoint) * hn[i]);
+    memcpy(desc + (size_t)i * cap * 32, ho + hdr_bytes + kp_bytes + (size_t)32 * i * cap, (size_t)32 * hn[i]);
+  }
   return ORBFE_OK;
 }
 
@@ -678,9 +715,38 @@ extern "C" int orbfe_pyramid_level(orbfe_extractor* e, int level, uint8_t* dst, 
   if (h) *h = g.h;
   if (dst) {
     if (dst_stride < g.w) return ORBFE_ERR_INVALID;
-    HIPCHK(hipMemcpy2DAsync(dst, dst_stride, level_ptr(e, e->d_pyr, level, 0), g.pitch, g.w, g.h, hipMemcpyDeviceToHost,
-                            e->stream));
+    const size_t bytes = (size_t)g.pitch * g.h;
+    int rc;
+    if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, bytes))) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_out, level_ptr(e, e->d_pyr, level, 0), bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    for (int y = 0; y < g.h; y++) memcpy(dst + (size_t)y * dst_stride, (uint8_t*)e->h_out + (size_t)y * g.pitch, (size_t)g.w);
+  }
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_pyramid_levels(orbfe_extractor* e, uint8_t* const* dst, const int* dst_stride) {
+  if (!e || !dst || !dst_stride || e->plan_w == 0 || e->last_images < 1) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->device));
+  const int nl = e->prm.n_levels;
+  size_t total = 0;
+  for (int l = 0; l < nl; l++) total += (size_t)e->lg[l].pitch * e->lg[l].h;
+  int rc;
+  if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, total))) return rc;
+  size_t off = 0;
+  for (int l = 0; l < nl; l++) {  // image 0 of every level: contiguous pitched plane -> pinned, one sync for all
+    const size_t bytes = (size_t)e->lg[l].pitch * e->lg[l].h;
+    HIPCHK(hipMemcpyAsync((uint8_t*)e->h_out + off, level_ptr(e, e->d_pyr, l, 0), bytes, hipMemcpyDeviceToHost, e->stream));
+    off += bytes;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  off = 0;
+  for (int l = 0; l < nl; l++) {
+    const LevelGeom& g = e->lg[l];
+    if (!dst[l] || dst_stride[l] < g.w) return ORBFE_ERR_INVALID;
+    for (int y = 0; y < g.h; y++) memcpy(dst[l] + (size_t)y * dst_stride[l], (uint8_t*)e->h_out + off + (size_t)y * g.pitch, (size_t)g.w);
+    off += (size_t)g.pitch * g.h;
   }
   return ORBFE_OK;
 }

@@ -88,9 +88,11 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     memcpy((void*)_keypoints.data(), kps.data(), sizeof(orbfe_keypoint) * (size_t)n);
   }
   if (mbDownloadPyramid && rc == ORBFE_OK) {
+    std::vector<uint8_t*> dst((size_t)nlevels, nullptr);
+    std::vector<int> dstStride((size_t)nlevels, 0);
     for (int level = 0; level < nlevels; ++level) {
       int w = 0, h = 0;
-      if (orbfe_pyramid_level(mpImpl, level, nullptr, 0, &w, &h) != ORBFE_OK) break;
+      if (orbfe_pyramid_level_size(mpImpl, image.cols, image.rows, level, &w, &h) != ORBFE_OK) return;
       cv::Mat& temp = mvPadded[level];
       temp.create(h + 2 * EDGE_THRESHOLD, w + 2 * EDGE_THRESHOLD, cv::CV_8U);
 #ifdef ORBFE_HAVE_OPENCV
@@ -98,16 +100,25 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
 #else
       mvImagePyramid[level] = temp.roi(EDGE_THRESHOLD, EDGE_THRESHOLD, w, h);
 #endif
+      dst[level] = mvImagePyramid[level].ptr(0);
+      dstStride[level] = (int)mvImagePyramid[level].step;
+    }
+    if (orbfe_pyramid_levels(mpImpl, dst.data(), dstStride.data()) != ORBFE_OK) {
+      fprintf(stderr, "ORBextractor: orbfe_pyramid_levels failed: %s\n", orbfe_last_error());
+      return;
+    }
+    for (int level = 0; level < nlevels; ++level) {
       cv::Mat& roi = mvImagePyramid[level];
-      orbfe_pyramid_level(mpImpl, level, roi.ptr(0), (int)roi.step, &w, &h);
+      cv::Mat& temp = mvPadded[level];
+      const int w = roi.cols, h = roi.rows;
       // BORDER_REFLECT_101 frame around the level (:1057-1062)
       for (int y = -EDGE_THRESHOLD; y < h + EDGE_THRESHOLD; y++) {
         const uint8_t* src = roi.ptr(0) + (ptrdiff_t)reflect101(y, h) * (ptrdiff_t)roi.step;
-        uint8_t* dst = temp.ptr(y + EDGE_THRESHOLD);
-        if (y < 0 || y >= h) memcpy(dst + EDGE_THRESHOLD, src, (size_t)w);
+        uint8_t* dstp = temp.ptr(y + EDGE_THRESHOLD);
+        if (y < 0 || y >= h) memcpy(dstp + EDGE_THRESHOLD, src, (size_t)w);
         for (int x = 0; x < EDGE_THRESHOLD; x++) {
-          dst[x] = src[reflect101(x - EDGE_THRESHOLD, w)];
-          dst[EDGE_THRESHOLD + w + x] = src[reflect101(w + x, w)];
+          dstp[x] = src[reflect101(x - EDGE_THRESHOLD, w)];
+          dstp[EDGE_THRESHOLD + w + x] = src[reflect101(w + x, w)];
         }
       }
     }

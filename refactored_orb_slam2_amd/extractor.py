@@ -141,7 +141,12 @@ class ORBextractor:
 
     @property
     def mvImagePyramid(self):
-        return [self.pyramid_level(l) for l in range(self.nlevels)]
+        """All levels with one device synchronisation (orbfe_pyramid_levels)."""
+        outs = [np.zeros(self.level_size(l)[::-1], np.uint8) for l in range(self.nlevels)]
+        ptrs = (C.c_void_p * self.nlevels)(*[o.ctypes.data for o in outs])
+        strides = (C.c_int * self.nlevels)(*[o.strides[0] for o in outs])
+        _lib.check(self._L.orbfe_pyramid_levels(self._h, C.cast(ptrs, C.c_void_p), C.cast(strides, C.c_void_p)), "orbfe_pyramid_levels")
+        return outs
 
     # ---- stage-level outputs (parity tests)
     def debug_pyramid(self, image: int, level: int) -> np.ndarray:

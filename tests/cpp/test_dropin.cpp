@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <vector>
 
@@ -77,6 +78,22 @@ int main(int argc, char** argv) {
   std::vector<cv::KeyPoint> keys;
   cv::Mat desc;
   for (int rep = 0; rep < 2; rep++) (*ext)(im, cv::Mat(), keys, desc);
+  {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int rep = 0; rep < 20; rep++) (*ext)(im, cv::Mat(), keys, desc);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    printf("ORBextractor::operator() incl. mvImagePyramid download: %.3f ms/frame\n",
+           ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / 20);
+    ext->SetPyramidDownload(false);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int rep = 0; rep < 20; rep++) (*ext)(im, cv::Mat(), keys, desc);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    printf("ORBextractor::operator() without pyramid download:       %.3f ms/frame\n",
+           ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / 20);
+    ext->SetPyramidDownload(true);
+    (*ext)(im, cv::Mat(), keys, desc);
+  }
   std::vector<oo_keypoint> okeys(nf + 64);
   std::vector<uint8_t> odesc((size_t)(nf + 64) * 32);
   int on = 0;
