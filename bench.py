@@ -111,18 +111,26 @@ def main():
     import torch.distributed as dist
     from refactored_orb_slam2_amd import ORBextractor, synth
     from refactored_orb_slam2_amd.matcher import Matcher
-    from refactored_orb_slam2_amd.sharding import gather_records
+    from refactored_orb_slam2_amd.sharding import AsyncGather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal switches for boxes with fewer GPUs than ranks (not used by the driver): ORBFE_BENCH_SHARE_DEVICE=1 maps
+    # every rank to the visible devices round-robin, ORBFE_BENCH_BACKEND=gloo replaces RCCL for the gather
+    backend = os.environ.get("ORBFE_BENCH_BACKEND", "nccl")
+    if os.environ.get("ORBFE_BENCH_SHARE_DEVICE") == "1":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     F = args.frames
     # ---- synthetic input, resident in HBM before the timed region (each rank its own sequence)
@@ -169,10 +177,15 @@ def main():
         blocked.zero_(); assigned.fill_(-1)
         mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned,
                             n_track, stream=cur)              # SearchByProjection(cur, last, th=7)
-        if world > 1:  # the path's only exchange: gather of the per-frame keypoint records
-            gather_records(nl, kl, dl)
+        if world > 1:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
+            gatherer.launch(nl, kl, dl)
+
+    gatherer = AsyncGather(nl, kl, dl) if world > 1 else None
 
     def barrier():
+        if gatherer is not None:
+            with torch.cuda.stream(sM):
+                gatherer.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -22,6 +22,39 @@ def padded_chunk(n_frames: int, world: int) -> int:
     return (n_frames + world - 1) // world
 
 
+class AsyncGather:
+    """Overlaps the record gather of step k with the compute of step k+1: the step's outputs are snapshotted
+    (device-to-device copy on the compute stream), the collectives run asynchronously on the process group's
+    stream, and the previous gather is waited for only when its buffers are about to be reused."""
+
+    def __init__(self, n, kps, desc, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.snap = [torch.empty_like(t) for t in (n, kps, desc)]
+        self.out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                    for t in (n, kps, desc)]
+        self.pending = []
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def launch(self, n, kps, desc):
+        import torch.distributed as dist
+        self.wait()  # the snapshot / output buffers are free again
+        for s, t in zip(self.snap, (n, kps, desc)):
+            s.copy_(t, non_blocking=True)
+        self.pending = [dist.all_gather_into_tensor(o, s, group=self.group, async_op=True)
+                        for o, s in zip(self.out, self.snap)]
+
+    def result(self):
+        self.wait()
+        return tuple(self.out)
+
+
 def gather_records(n, kps, desc, group=None):
     """all_gather of fixed-size padded per-frame records {n[f]; kps[f, cap, 28]; desc[f, cap, 32]}.
 

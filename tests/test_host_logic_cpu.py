@@ -102,6 +102,12 @@ def _gather_worker(rank, world, port, n_frames, cap, tmp):
             desc[i, :c] = ((f * 3) % 253)
         n_all, k_all, d_all = sharding.gather_records(n, kps, desc)
         assert n_all.shape[0] == world * chunk
+        # the overlapped variant used by bench.py must deliver the same records (twice: buffers are recycled)
+        ag = sharding.AsyncGather(n, kps, desc)
+        for _ in range(2):
+            ag.launch(n, kps, desc)
+        a_n, a_k, a_d = ag.result()
+        assert torch.equal(a_n, n_all) and torch.equal(a_k, k_all) and torch.equal(a_d, d_all)
         # global frame order: rank r's chunk starts at r*chunk; padding frames carry n = 0
         for r in range(world):
             rb, re_ = sharding.shard_range(n_frames, r, world)
