@@ -217,6 +217,18 @@ int orbfe_search_by_projection_points(const orbfe_frame_view* frame, const orbfe
 int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_query* q, int nq,
                                      int check_orientation, uint8_t* blocked, int32_t* assigned, int* n_matches);
 
+/* SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), entirely on the device.
+ * A DBoW2::FeatureVector is passed as its nodes sorted by id, each {node_id, start, count} into an index array
+ * (nodesA/idxA = pKF->mFeatVec, nodesB/idxB = F.mFeatVec).  validA[i] != 0 <=> keyframe feature i has a map point
+ * that is not bad.  matchB[j] = keyframe feature matched to frame feature j (the caller stores
+ * vpMapPointsKF[matchB[j]] in vpMapPointMatches[j]) or -1; *n_matches = the reference's return value.
+ * HOST pointers, synchronous. */
+typedef struct orbfe_featvec_node { int32_t node_id, start, count; } orbfe_featvec_node;
+int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                        const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
+                        const float* angleB, int nB, const orbfe_featvec_node* nodesB, int n_nodesB,
+                        const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchB, int* n_matches);
+
 /* SearchForInitialization (L/src/ORBmatcher.cc:388-492), the monocular map-initialisation matcher: level-0
  * keypoints of F1 are searched in a window of `window_size` pixels around prev_matched_xy[2*i..2*i+1] in F2; a
  * closer later keypoint steals an earlier match (vMatchedDistance / vnMatches21).  matches12[i] = F2 index or -1;

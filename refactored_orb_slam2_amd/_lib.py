@@ -38,6 +38,10 @@ class Params(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class FeatVecNode(C.Structure):
+    _fields_ = [("node_id", C.c_int32), ("start", C.c_int32), ("count", C.c_int32)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
@@ -55,7 +59,7 @@ EXPORTS = [
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
-    "orbfe_search_for_initialization",
+    "orbfe_search_for_initialization", "orbfe_search_by_bow",
 ]
 
 
@@ -118,6 +122,7 @@ def lib():
     L.orbfe_proj_candidates.argtypes = [C.POINTER(FrameView), vp, ci, vp, vp, ci]
     L.orbfe_search_by_projection_points.argtypes = [C.POINTER(FrameView), vp, ci, cf, vp, vp, pi]
     L.orbfe_search_by_projection_frame.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, pi]
+    L.orbfe_search_by_bow.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_for_initialization.argtypes = [C.POINTER(FrameView), C.POINTER(FrameView), vp, ci, cf, ci, vp, pi]
     L.orbfe_stereo_match_device.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
     for name in EXPORTS:

@@ -58,6 +58,18 @@ struct StereoParams {
 #define STEREO_MAX_BUCKETS 512      // rows / 8, rows <= 4095
 #define STEREO_BUCKET_SPAN 8        // a band [y-r, y+r], r = 2*scale <= ~25 rows, overlaps at most this many buckets
 
+struct BowPair { int32_t startA, countA, startB, countB; };
+struct BowParams {
+  const BowPair* pairs;
+  const uint8_t* descA; const float* angleA; const uint8_t* validA; const int32_t* idxA;
+  const uint8_t* descB; const float* angleB; const int32_t* idxB;
+  float nnratio; int check_ori;
+  int sequential, n_pairs;  // sequential != 0: a frame feature occurs under more than one node
+  int32_t* matchB;      // [nB], pre-set to -1
+  int32_t* counters;    // [0] pushes, [1] nmatches, [2..31] rotation histogram
+  int32_t* push_idx; uint8_t* push_bin;
+};
+void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s);
 void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s);
 void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s);

@@ -541,20 +541,118 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
     q0 += len;
   }
   __syncthreads();
-  if (use_hist && tid == 0) {
-    int i1, i2, i3;
-    three_maxima(hist, ORBFE_HISTO_LENGTH, i1, i2, i3);
+  if (use_hist) {
+    // rotation consistency (:1363-1379): every recorded match whose bin is not one of the three maxima is removed
+    if (tid == 0) {
+      int i1, i2, i3;
+      three_maxima(hist, ORBFE_HISTO_LENGTH, i1, i2, i3);
+      hist[0] = i1; hist[1] = i2; hist[2] = i3;  // the histogram itself is no longer needed
+    }
+    __syncthreads();
+    const int i1 = hist[0], i2 = hist[1], i3 = hist[2];
     const int np = sh_npush;
     int removed = 0;
-    for (int k = 0; k < np; k++) {
+    for (int k = tid; k < np; k += RC_THREADS) {
       const int bin = push_bin[k];
       if (bin != i1 && bin != i2 && bin != i3) { assigned[push_idx[k]] = -1; removed++; }
     }
-    sh_nm -= removed;
+    if (removed) atomicSub(&sh_nm, removed);
   }
   __syncthreads();
   for (int i = tid; i < F.cap; i += RC_THREADS) blocked_g[i] = blocked[i];
   if (tid == 0) n_matches[f] = sh_nm;
+}
+
+// ------------------------------------------------------------------------------------------------ SearchByBoW
+// SearchByBoW(KeyFrame*, Frame&, ...) (L/src/ORBmatcher.cc:161-273).  The host merge-joins the two FeatureVectors
+// on NodeId; every common node is an independent problem (a feature belongs to exactly one node), so one wave
+// takes one node: keyframe features in vIndicesKF order, the lanes share the node's frame features (best /
+// second-best over those not matched yet, strict "<" in vIndicesF order), matches written immediately so that
+// later keyframe features skip them (:208-209).  Rotation histogram by global atomics, finished by bow_finish.
+__global__ __launch_bounds__(64) void bow_match_kernel(BowParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t taken[];  // per frame feature of this node
+  const int lane = threadIdx.x;
+  // sequential mode (a frame feature listed under several nodes -- never produced by DBoW2, but legal input): one
+  // wave walks all node pairs in NodeId order and reads the match table from memory, as the reference does
+  const int first = P.sequential ? 0 : blockIdx.x, last = P.sequential ? P.n_pairs : blockIdx.x + 1;
+  for (int pi = first; pi < last; pi++) {
+  const BowPair pr = P.pairs[pi];
+  __syncthreads();
+  for (int i = lane; i < pr.countB; i += WAVE)
+    taken[i] = P.sequential ? (uint8_t)(__hip_atomic_load(&P.matchB[P.idxB[pr.startB + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) : 0;
+  __syncthreads();
+  for (int iKF = 0; iKF < pr.countA; iKF++) {
+    const int realIdxKF = P.idxA[pr.startA + iKF];
+    if (!P.validA[realIdxKF]) continue;  // no map point, or a bad one (:191-197)
+    uint4 a0, a1;
+    load_desc(P.descA + (size_t)realIdxKF * 32, a0, a1);
+    int bestd = 256, bestj = -1, second = 256;
+    for (int iF = lane; iF < pr.countB; iF += WAVE) {
+      if (taken[iF]) continue;
+      const int realIdxF = P.idxB[pr.startB + iF];
+      uint4 b0, b1;
+      load_desc(P.descB + (size_t)realIdxF * 32, b0, b1);
+      const int d = hamming256(a0, a1, b0, b1);
+      if (d < bestd) { second = bestd; bestd = d; bestj = iF; }
+      else if (d < second) second = d;
+    }
+    // merge: first minimum in vIndicesF order, second = smallest of everything else
+    const unsigned key = bestj >= 0 ? (((unsigned)bestd << 16) | (unsigned)bestj) : 0xFFFFFFFFu;
+    const unsigned b = wave_min_u32(key);
+    if (b != 0xFFFFFFFFu) {
+      const unsigned other = (key == b) ? 0xFFFFFFFFu : key;
+      int s2 = min(second, other != 0xFFFFFFFFu ? (int)(other >> 16) : 256);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) s2 = min(s2, __shfl_xor(s2, d, WAVE));
+      const int bestDist1 = (int)(b >> 16), bestF = (int)(b & 0xffff);
+      if (bestDist1 <= ORBFE_TH_LOW && (float)bestDist1 < P.nnratio * (float)s2) {
+        if (lane == 0) {
+          const int realIdxF = P.idxB[pr.startB + bestF];
+          __hip_atomic_store(&P.matchB[realIdxF], realIdxKF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          taken[bestF] = 1;
+          if (P.sequential)  // the same feature may be listed again inside this node
+            for (int t = 0; t < pr.countB; t++)
+              if (P.idxB[pr.startB + t] == realIdxF) taken[t] = 1;
+          if (P.check_ori) {
+            float rot = P.angleA[realIdxKF] - P.angleB[realIdxF];
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
+            if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+            const int pos = atomicAdd(&P.counters[0], 1);
+            P.push_idx[pos] = realIdxF;
+            P.push_bin[pos] = (uint8_t)bin;
+            atomicAdd(&P.counters[2 + bin], 1);
+          }
+          atomicAdd(&P.counters[1], 1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  }
+}
+
+__global__ __launch_bounds__(256) void bow_finish_kernel(BowParams P) {
+  __shared__ int top[3];
+  __shared__ int removed;
+  if (threadIdx.x == 0) {
+    removed = 0;
+    int i1, i2, i3;
+    three_maxima(P.counters + 2, ORBFE_HISTO_LENGTH, i1, i2, i3);
+    top[0] = i1; top[1] = i2; top[2] = i3;
+  }
+  __syncthreads();
+  if (P.check_ori) {
+    const int np = P.counters[0];
+    int r = 0;
+    for (int k = threadIdx.x; k < np; k += 256) {
+      const int bin = P.push_bin[k];
+      if (bin != top[0] && bin != top[1] && bin != top[2]) { P.matchB[P.push_idx[k]] = -1; r++; }
+    }
+    if (r) atomicAdd(&removed, r);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) P.counters[1] -= removed;
 }
 
 // ------------------------------------------------------------------------------------------------ mono init
@@ -915,6 +1013,11 @@ void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const o
   }
   hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, nnratio,
                      check_ori, blocked, assigned, n_matches, push_idx, push_bin);
+}
+void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream_t s) {
+  if (n_pairs > 0)
+    hipLaunchKernelGGL(bow_match_kernel, dim3(p.sequential ? 1 : n_pairs), dim3(64), (size_t)((max_countB + 15) & ~15), s, p);
+  hipLaunchKernelGGL(bow_finish_kernel, dim3(1), dim3(256), 0, s, p);
 }
 void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
                                int max_cand, float nnratio, int check_ori, int32_t* matches12, float* prev_xy,

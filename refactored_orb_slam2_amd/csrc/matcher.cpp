@@ -325,6 +325,87 @@ extern "C" int orbfe_search_by_projection_frame(const orbfe_frame_view* f, const
   return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches);
 }
 
+// SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), host pointers, synchronous
+extern "C" int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                                   const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA,
+                                   const uint8_t* descB, const float* angleB, int nB, const orbfe_featvec_node* nodesB,
+                                   int n_nodesB, const int32_t* idxB, float nnratio, int check_orientation,
+                                   int32_t* matchB, int* n_matches) {
+  if (nA < 0 || nB < 0 || n_nodesA < 0 || n_nodesB < 0 || !n_matches || (nB > 0 && !matchB)) return ORBFE_ERR_INVALID;
+  *n_matches = 0;
+  for (int j = 0; j < nB; j++) matchB[j] = -1;
+  if (nA == 0 || nB == 0 || n_nodesA == 0 || n_nodesB == 0) return ORBFE_OK;
+  if (!descA || !angleA || !validA || !nodesA || !idxA || !descB || !angleB || !nodesB || !idxB) return ORBFE_ERR_INVALID;
+  // merge-join of the two FeatureVectors on NodeId (:183-253; lower_bound jumps == plain two-pointer walk on sorted ids)
+  std::vector<BowPair> pairs;
+  int ia = 0, ib = 0, totA = 0, totB = 0, maxB = 0;
+  while (ia < n_nodesA && ib < n_nodesB) {
+    if (nodesA[ia].node_id == nodesB[ib].node_id) {
+      pairs.push_back(BowPair{nodesA[ia].start, nodesA[ia].count, nodesB[ib].start, nodesB[ib].count});
+      maxB = std::max(maxB, nodesB[ib].count);
+      ia++; ib++;
+    } else if (nodesA[ia].node_id < nodesB[ib].node_id) ia++;
+    else ib++;
+  }
+  for (int i = 0; i < n_nodesA; i++) totA = std::max(totA, nodesA[i].start + nodesA[i].count);
+  for (int i = 0; i < n_nodesB; i++) totB = std::max(totB, nodesB[i].start + nodesB[i].count);
+  if (pairs.empty()) return ORBFE_OK;
+  if (maxB >= 65536 || maxB > 60000) return ORBFE_ERR_INVALID;
+  // nodes are independent only if no frame feature is listed under two of them (always true for DBoW2 output)
+  int sequential = 0;
+  {
+    std::vector<uint8_t> seen((size_t)nB, 0);
+    for (const BowPair& pr : pairs)
+      for (int t = 0; t < pr.countB && !sequential; t++) {
+        const int j = idxB[pr.startB + t];
+        if (j < 0 || j >= nB) return ORBFE_ERR_INVALID;
+        if (seen[j]) sequential = 1;
+        seen[j] = 1;
+      }
+  }
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  // one packed upload: [pairs | descA | descB | angleA | angleB | idxA | idxB | validA]
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_pairs = 0, o_dA = al(pairs.size() * sizeof(BowPair)), o_dB = o_dA + al((size_t)nA * 32),
+               o_aA = o_dB + al((size_t)nB * 32), o_aB = o_aA + al((size_t)nA * 4), o_iA = o_aB + al((size_t)nB * 4),
+               o_iB = o_iA + al((size_t)totA * 4), o_vA = o_iB + al((size_t)totB * 4), o_mB = o_vA + al((size_t)nA),
+               o_cnt = o_mB + al((size_t)nB * 4), o_pi = o_cnt + 256, o_pb = o_pi + al((size_t)nA * 4),
+               total = o_pb + al((size_t)nA);
+  if ((rc = mb_alloc(m->h_q, total))) return rc;
+  uint8_t* d = (uint8_t*)m->h_q.p;
+  HIPCHK(hipMemcpyAsync(d + o_pairs, pairs.data(), pairs.size() * sizeof(BowPair), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_dA, descA, (size_t)nA * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_dB, descB, (size_t)nB * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_aA, angleA, (size_t)nA * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_aB, angleB, (size_t)nB * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_iA, idxA, (size_t)totA * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_iB, idxB, (size_t)totB * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_vA, validA, (size_t)nA, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(d + o_mB, 0xff, (size_t)nB * 4, s));
+  HIPCHK(hipMemsetAsync(d + o_cnt, 0, 256, s));
+  BowParams p;
+  p.pairs = (const BowPair*)(d + o_pairs);
+  p.descA = d + o_dA; p.angleA = (const float*)(d + o_aA); p.validA = d + o_vA; p.idxA = (const int32_t*)(d + o_iA);
+  p.descB = d + o_dB; p.angleB = (const float*)(d + o_aB); p.idxB = (const int32_t*)(d + o_iB);
+  p.nnratio = nnratio; p.check_ori = check_orientation;
+  p.sequential = sequential; p.n_pairs = (int)pairs.size();
+  p.matchB = (int32_t*)(d + o_mB); p.counters = (int32_t*)(d + o_cnt);
+  p.push_idx = (int32_t*)(d + o_pi); p.push_bin = d + o_pb;
+  orbfe_launch_bow(p, (int)pairs.size(), maxB, s);
+  if ((rc = launch_ok())) return rc;
+  int32_t cnt[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(matchB, d + o_mB, (size_t)nB * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(cnt, d + o_cnt, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_matches = cnt[1];
+  return ORBFE_OK;
+}
+
 // SearchForInitialization (L/src/ORBmatcher.cc:388-492), host pointers, synchronous
 extern "C" int orbfe_search_for_initialization(const orbfe_frame_view* f1, const orbfe_frame_view* f2, float* prev_matched_xy,
                                                int window_size, float nnratio, int check_orientation, int32_t* matches12,

@@ -138,49 +138,34 @@ class ORBmatcher:
 
     # ---- SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&): ORBmatcher.cc:161-273
     def SearchByBoW(self, descA, angleA, validA, groupsA: dict, descB, angleB, groupsB: dict):
-        """groupsA/groupsB: {node_id: [feature indices]} (DBoW2::FeatureVector).  Distances of every
-        same-node pair come from the device; the greedy pass (a matched frame feature is skipped by later
-        keyframe features, :208-209) replays on the host in the reference's order."""
+        """groupsA/groupsB: {node_id: [feature indices]} (DBoW2::FeatureVector of the keyframe / the frame).
+        Runs entirely on the device (one wave per common vocabulary node).  Returns (nmatches, matchB)."""
         descA = np.ascontiguousarray(descA, np.uint8).reshape(-1, 32)
         descB = np.ascontiguousarray(descB, np.uint8).reshape(-1, 32)
-        D = self.DescriptorDistanceMatrix(descA, descB) if len(descA) and len(descB) else np.zeros((len(descA), len(descB)), np.int32)
+        angleA = np.ascontiguousarray(angleA, np.float32); angleB = np.ascontiguousarray(angleB, np.float32)
+        validA = np.ascontiguousarray(validA, np.uint8)
+        nA, nnA, iA = featvec_arrays(groupsA)
+        nB, nnB, iB = featvec_arrays(groupsB)
         matchB = np.full(len(descB), -1, np.int32)
-        nmatches = 0
-        rot = [[] for _ in range(HISTO_LENGTH)]
-        factor = np.float32(1.0) / np.float32(HISTO_LENGTH)
-        for nid in sorted(set(groupsA) & set(groupsB)):
-            for ia in groupsA[nid]:
-                if not validA[ia]:
-                    continue
-                best1, best2, bidx = 256, 256, -1
-                for jb in groupsB[nid]:
-                    if matchB[jb] >= 0:
-                        continue
-                    d = int(D[ia, jb])
-                    if d < best1:
-                        best2, best1, bidx = best1, d, jb
-                    elif d < best2:
-                        best2 = d
-                if best1 <= TH_LOW and np.float32(best1) < np.float32(self.mfNNratio) * np.float32(best2):
-                    matchB[bidx] = ia
-                    if self.mbCheckOrientation:
-                        r = np.float32(angleA[ia]) - np.float32(angleB[bidx])
-                        if r < 0:
-                            r = np.float32(r + np.float32(360.0))
-                        b = int(np.floor(np.float32(r * factor) + np.float32(0.5)))  # std::round, r >= 0
-                        if b == HISTO_LENGTH:
-                            b = 0
-                        rot[b].append(bidx)
-                    nmatches += 1
-        if self.mbCheckOrientation:
-            i1, i2, i3 = three_maxima([len(r) for r in rot])
-            for i in range(HISTO_LENGTH):
-                if i in (i1, i2, i3):
-                    continue
-                for j in rot[i]:
-                    matchB[j] = -1
-                    nmatches -= 1
-        return nmatches, matchB
+        nm = C.c_int(0)
+        _lib.check(self._L.orbfe_search_by_bow(
+            _lib.ptr(descA), _lib.ptr(angleA), _lib.ptr(validA), len(descA), C.cast(nA, C.c_void_p), nnA, _lib.ptr(iA),
+            _lib.ptr(descB), _lib.ptr(angleB), len(descB), C.cast(nB, C.c_void_p), nnB, _lib.ptr(iB), self.mfNNratio,
+            int(self.mbCheckOrientation), _lib.ptr(matchB), C.byref(nm)), "orbfe_search_by_bow")
+        return nm.value, matchB
+
+
+def featvec_arrays(groups: dict):
+    """{node_id: [indices]} -> (ctypes array of orbfe_featvec_node sorted by id, count, flat int32 index array)."""
+    ids = sorted(groups)
+    nodes = (_lib.FeatVecNode * max(len(ids), 1))()
+    idx = []
+    for k, nid in enumerate(ids):
+        nodes[k].node_id = nid
+        nodes[k].start = len(idx)
+        nodes[k].count = len(groups[nid])
+        idx.extend(groups[nid])
+    return nodes, len(ids), np.asarray(idx if idx else [0], np.int32)
 
 
 def three_maxima(sizes):

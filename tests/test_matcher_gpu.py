@@ -184,12 +184,17 @@ def test_search_by_bow_grouped():
     gA = {7: list(range(150)), **{k + 1000: v for k, v in gA.items()}}
     gB = {7: list(range(150)), **{k + 1000: v for k, v in gB.items()}}
     valid = (rng.random(len(dA)) < 0.9).astype(np.uint8)
-    for ratio, check in ((0.7, True), (0.9, False)):
-        nm, matchB = ORBmatcher(ratio, check).SearchByBoW(dA, k0["angle"], valid, gA, dB, k1["angle"], gB)
-        onm, omatchB = ol.search_by_bow(dA, k0["angle"], valid, gA, dB, k1["angle"], gB, np.float32(ratio), check)
-        assert nm == onm
-        np.testing.assert_array_equal(matchB, omatchB)
-    assert onm > 50
+    # (1) as built above features 0..149 are listed under node 7 AND their hash bucket: nodes depend on each other
+    #     (sequential device path); (2) a proper FeatureVector: every feature under exactly one node (parallel path)
+    gA2 = {7: list(range(150)), **{k: [i for i in v if i >= 150] for k, v in gA.items() if k != 7}}
+    gB2 = {7: list(range(150)), **{k: [i for i in v if i >= 150] for k, v in gB.items() if k != 7}}
+    for ga, gb in ((gA, gB), (gA2, gB2)):
+        for ratio, check in ((0.7, True), (0.9, False)):
+            nm, matchB = ORBmatcher(ratio, check).SearchByBoW(dA, k0["angle"], valid, ga, dB, k1["angle"], gb)
+            onm, omatchB = ol.search_by_bow(dA, k0["angle"], valid, ga, dB, k1["angle"], gb, np.float32(ratio), check)
+            assert nm == onm
+            np.testing.assert_array_equal(matchB, omatchB)
+            assert onm > 50
 
 
 @pytest.mark.parametrize("geom", [(1241, 376, 2000), (752, 480, 1200)])
