@@ -257,6 +257,32 @@ int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_ext
                               int cap, float mbf, float mb, float* d_u_right, float* d_depth, int32_t* d_n_matched,
                               void* stream);
 
+/* --------------------------------------------------------------------------------------- ORBVocabulary */
+/* Frame::ComputeBoW (L/src/Frame.cc:412-417): ORBVocabulary::transform(descriptors, BowVector&, FeatureVector&, 4)
+ * = DBoW2::TemplatedVocabulary::transform (Source/ThirdParty/DBoW2/DBoW2-local/include/DBoW2/
+ * TemplatedVocabulary.h:1125-1257).  SURVEY.md §8(f) row 2: produces the FeatureVector SearchByBoW consumes. */
+typedef struct orbfe_vocabulary orbfe_vocabulary;
+/* Tree as arrays: node 0 is the root, parent[i] < i, children keep ascending id order; is_leaf[i] marks words
+ * (word ids count leaves in id order); desc = n_nodes x 32 bytes; scoring / weighting = DBoW2::ScoringType /
+ * WeightingType values (L1_NORM = 0, TF_IDF = 0). */
+int orbfe_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                            const uint8_t* is_leaf, const uint8_t* desc, const double* weight, int device,
+                            orbfe_vocabulary** out);
+/* ORBVocabulary::loadFromTextFile (L/src/ORBVocabulary.cc:11-127), the ORBvoc.txt format. */
+int orbfe_vocabulary_load_text(const char* path, int device, orbfe_vocabulary** out);
+int orbfe_vocabulary_destroy(orbfe_vocabulary* v);
+int orbfe_vocabulary_info(const orbfe_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words);
+/* Tree descent only, DEVICE pointers, asynchronous: per descriptor the word id, the node at level L - levelsup and
+ * the word weight. */
+int orbfe_bow_transform_device(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, int32_t* d_word,
+                               int32_t* d_node, double* d_weight, void* stream);
+/* The whole transform for one frame, HOST pointers, synchronous.  BowVector as ascending (bow_ids, bow_vals) pairs,
+ * FeatureVector as ascending nodes {node_id, start, count} into fv_idx; every output array holds n entries at
+ * most.  word_id / node_id / weight (per feature) are optional. */
+int orbfe_compute_bow(orbfe_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word_id,
+                      int32_t* node_id, double* weight, int32_t* bow_ids, double* bow_vals, int* n_bow,
+                      orbfe_featvec_node* fv_nodes, int32_t* fv_idx, int* n_fv_nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1193,4 +1194,174 @@ int oo_compute_stereo_matches(const oo_keypoint* keysL, const uint8_t* descL, in
   }
   free(vDistIdx); free(rowCount); free(rowIdx);
   return nkept;
+}
+
+/* ------------------------------------------------------------------------------------- vocabulary */
+struct oo_vocab {
+  int k, L, scoring, weighting;
+  int n_nodes, n_words;
+  int32_t* parent;
+  int32_t* child_start; /* CSR of children in ascending id (= file) order */
+  int32_t* child_idx;
+  uint8_t* desc;
+  double* weight;
+  int32_t* word_id;
+};
+
+oo_vocab* oo_vocab_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                          const uint8_t* is_leaf, const uint8_t* desc, const double* weight) {
+  if (n_nodes < 1) return NULL;
+  oo_vocab* v = (oo_vocab*)calloc(1, sizeof(*v));
+  v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->n_nodes = n_nodes;
+  v->parent = (int32_t*)calloc(n_nodes, sizeof(int32_t));
+  v->child_start = (int32_t*)calloc(n_nodes + 1, sizeof(int32_t));
+  v->child_idx = (int32_t*)calloc(n_nodes, sizeof(int32_t));
+  v->desc = (uint8_t*)calloc((size_t)n_nodes, 32);
+  v->weight = (double*)calloc(n_nodes, sizeof(double));
+  v->word_id = (int32_t*)calloc(n_nodes, sizeof(int32_t));
+  for (int i = 1; i < n_nodes; i++) {
+    if (parent[i] < 0 || parent[i] >= i) { oo_vocab_destroy(v); return NULL; }
+    v->parent[i] = parent[i];
+    v->child_start[parent[i] + 1]++;
+  }
+  for (int i = 0; i < n_nodes; i++) v->child_start[i + 1] += v->child_start[i];
+  int* fill = (int*)calloc(n_nodes, sizeof(int));
+  for (int i = 1; i < n_nodes; i++) v->child_idx[v->child_start[parent[i]] + fill[parent[i]]++] = i;
+  free(fill);
+  memcpy(v->desc, desc, (size_t)n_nodes * 32);
+  memcpy(v->weight, weight, sizeof(double) * n_nodes);
+  for (int i = 1; i < n_nodes; i++)
+    if (is_leaf[i]) v->word_id[i] = v->n_words++; /* ORBVocabulary.cc:115-120: word ids in file order */
+  return v;
+}
+
+/* ORBVocabulary::loadFromTextFile, L/src/ORBVocabulary.cc:11-127 */
+oo_vocab* oo_vocab_load_text(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return NULL;
+  int k, L, n1, n2;
+  if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 ||
+      n2 < 0 || n2 > 3) { fclose(f); return NULL; }
+  int cap = 1024, n = 1;
+  int32_t* parent = (int32_t*)malloc(sizeof(int32_t) * cap);
+  uint8_t* leaf = (uint8_t*)malloc(cap);
+  uint8_t* desc = (uint8_t*)malloc((size_t)cap * 32);
+  double* weight = (double*)malloc(sizeof(double) * cap);
+  parent[0] = 0; leaf[0] = 0; weight[0] = 0; memset(desc, 0, 32);
+  for (;;) {
+    int pid, isleaf;
+    if (fscanf(f, "%d %d", &pid, &isleaf) != 2) break;
+    if (n == cap) {
+      cap *= 2;
+      parent = (int32_t*)realloc(parent, sizeof(int32_t) * cap); leaf = (uint8_t*)realloc(leaf, cap);
+      desc = (uint8_t*)realloc(desc, (size_t)cap * 32); weight = (double*)realloc(weight, sizeof(double) * cap);
+    }
+    parent[n] = pid; leaf[n] = isleaf > 0;
+    for (int i = 0; i < 32; i++) { int b; if (fscanf(f, "%d", &b) != 1) b = 0; desc[(size_t)n * 32 + i] = (uint8_t)b; }
+    if (fscanf(f, "%lf", &weight[n]) != 1) weight[n] = 0;
+    n++;
+  }
+  fclose(f);
+  oo_vocab* v = oo_vocab_create(k, L, n1, n2, n, parent, leaf, desc, weight);
+  free(parent); free(leaf); free(desc); free(weight);
+  return v;
+}
+
+void oo_vocab_destroy(oo_vocab* v) {
+  if (!v) return;
+  free(v->parent); free(v->child_start); free(v->child_idx); free(v->desc); free(v->weight); free(v->word_id);
+  free(v);
+}
+int oo_vocab_nodes(const oo_vocab* v) { return v->n_nodes; }
+int oo_vocab_words(const oo_vocab* v) { return v->n_words; }
+
+/* FORB::distance, src/FORB.cpp:77-100 (64-bit SWAR popcount; value == Hamming distance) */
+static double forb_distance(const uint8_t* a, const uint8_t* b) {
+  uint64_t ret = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t pa, pb, x;
+    memcpy(&pa, a + 8 * i, 8); memcpy(&pb, b + 8 * i, 8);
+    x = pa ^ pb;
+    x = x - ((x >> 1) & (uint64_t)~(uint64_t)0 / 3);
+    x = (x & (uint64_t)~(uint64_t)0 / 15 * 3) + ((x >> 2) & (uint64_t)~(uint64_t)0 / 15 * 3);
+    x = (x + (x >> 4)) & (uint64_t)~(uint64_t)0 / 255 * 15;
+    ret += (uint64_t)(x * ((uint64_t)~(uint64_t)0 / 255)) >> (sizeof(uint64_t) - 1) * 8;
+  }
+  return (double)ret;
+}
+
+/* transform(feature, word_id, weight, nid, levelsup): TemplatedVocabulary.h:1216-1257 */
+void oo_vocab_transform_feature(const oo_vocab* v, const uint8_t* d, int levelsup, int32_t* word_id, int32_t* node_id,
+                                double* weight) {
+  const int nid_level = v->L - levelsup;
+  int32_t nid = 0; /* root when nid_level <= 0 */
+  int final_id = 0, current_level = 0;
+  if (v->child_start[1] == v->child_start[0]) { *word_id = v->word_id[0]; *weight = v->weight[0]; *node_id = 0; return; }
+  do {
+    ++current_level;
+    const int c0 = v->child_start[final_id], c1 = v->child_start[final_id + 1];
+    final_id = v->child_idx[c0];
+    double best_d = forb_distance(d, v->desc + (size_t)final_id * 32);
+    for (int c = c0 + 1; c < c1; c++) {
+      const int id = v->child_idx[c];
+      const double dd = forb_distance(d, v->desc + (size_t)id * 32);
+      if (dd < best_d) { best_d = dd; final_id = id; }
+    }
+    if (current_level == nid_level) nid = final_id;
+  } while (v->child_start[final_id + 1] != v->child_start[final_id]); /* !isLeaf() == has children */
+  *word_id = v->word_id[final_id];
+  *weight = v->weight[final_id];
+  *node_id = nid;
+}
+
+typedef struct { int32_t key, idx; double w; } bow_tmp;
+static int bow_tmp_cmp(const void* a, const void* b) { /* stable by (key, idx) */
+  const bow_tmp *x = (const bow_tmp*)a, *y = (const bow_tmp*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* transform(features, BowVector, FeatureVector, levelsup): TemplatedVocabulary.h:1125-1192 */
+int oo_vocab_transform(const oo_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* bow_ids, double* bow_vals,
+                       int* n_bow, oo_featvec_node* fv_nodes, int32_t* fv_idx, int* n_fv) {
+  *n_bow = 0; *n_fv = 0;
+  if (v->n_nodes <= 1 || n <= 0) return 0; /* empty() */
+  bow_tmp* wt = (bow_tmp*)malloc(sizeof(bow_tmp) * n);
+  bow_tmp* nt = (bow_tmp*)malloc(sizeof(bow_tmp) * n);
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t wid, nid; double w;
+    oo_vocab_transform_feature(v, desc + (size_t)i * 32, levelsup, &wid, &nid, &w);
+    if (w > 0) { wt[m].key = wid; wt[m].idx = i; wt[m].w = w; nt[m].key = nid; nt[m].idx = i; nt[m].w = 0; m++; }
+  }
+  qsort(wt, m, sizeof(bow_tmp), bow_tmp_cmp);
+  qsort(nt, m, sizeof(bow_tmp), bow_tmp_cmp);
+  const int tf = (v->weighting == 0 /*TF_IDF*/ || v->weighting == 1 /*TF*/);
+  int nb = 0;
+  for (int i = 0; i < m;) { /* std::map<WordId, double>: addWeight sums in feature order, addIfNotExist keeps the first */
+    int j = i; double acc = wt[i].w;
+    for (j = i + 1; j < m && wt[j].key == wt[i].key; j++) if (tf) acc += wt[j].w;
+    bow_ids[nb] = wt[i].key; bow_vals[nb] = acc; nb++;
+    i = j;
+  }
+  const int must = v->scoring != 5; /* every scoring but DOT_PRODUCT normalises (ScoringObject.h:72-88) */
+  const int l2 = v->scoring == 1;   /* L2_NORM -> L2, all others L1 */
+  if (tf && nb > 0 && !must) { const double nd = (double)nb; for (int i = 0; i < nb; i++) bow_vals[i] /= nd; }
+  if (must) { /* BowVector::normalize */
+    double norm = 0.0;
+    if (!l2) for (int i = 0; i < nb; i++) norm += fabs(bow_vals[i]);
+    else { for (int i = 0; i < nb; i++) norm += bow_vals[i] * bow_vals[i]; norm = sqrt(norm); }
+    if (norm > 0.0) for (int i = 0; i < nb; i++) bow_vals[i] /= norm;
+  }
+  int nf = 0, pos = 0;
+  for (int i = 0; i < m;) { /* FeatureVector: ascending node id, features in ascending index */
+    int j = i;
+    fv_nodes[nf].node_id = nt[i].key; fv_nodes[nf].start = pos;
+    for (; j < m && nt[j].key == nt[i].key; j++) fv_idx[pos++] = nt[j].idx;
+    fv_nodes[nf].count = pos - fv_nodes[nf].start; nf++;
+    i = j;
+  }
+  free(wt); free(nt);
+  *n_bow = nb; *n_fv = nf;
+  return m;
 }

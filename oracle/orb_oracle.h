@@ -171,6 +171,25 @@ int oo_compute_stereo_matches(const oo_keypoint* keysL, const uint8_t* descL, in
                               const float* inv_scale_factors, float mbf, float mb, float* u_right,
                               float* depth);
 
+/* ---------------------------------------------------------------- vocabulary (DBoW2 + ORBVocabulary)
+ * Frame::ComputeBoW (L/src/Frame.cc:412-417) -> TemplatedVocabulary::transform(features, BowVector&,
+ * FeatureVector&, levelsup) (Source/ThirdParty/DBoW2/DBoW2-local/include/DBoW2/TemplatedVocabulary.h:1125-1257),
+ * FORB::distance (src/FORB.cpp:77-100), BowVector::addWeight/normalize (src/BowVector.cpp:34-84),
+ * FeatureVector::addFeature (src/FeatureVector.cpp:31-45); text format of L/src/ORBVocabulary.cc:11-127. */
+typedef struct oo_vocab oo_vocab;
+/* nodes 0..n_nodes-1, node 0 = root; parent[i] < i; children keep ascending id order (file order) */
+oo_vocab* oo_vocab_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                          const uint8_t* is_leaf, const uint8_t* desc, const double* weight);
+oo_vocab* oo_vocab_load_text(const char* path);
+void oo_vocab_destroy(oo_vocab* v);
+int oo_vocab_nodes(const oo_vocab* v);
+int oo_vocab_words(const oo_vocab* v);
+void oo_vocab_transform_feature(const oo_vocab* v, const uint8_t* d, int levelsup, int32_t* word_id, int32_t* node_id,
+                                double* weight);
+/* full transform: BowVector as ascending (id, value) pairs, FeatureVector as ascending nodes + index lists */
+int oo_vocab_transform(const oo_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* bow_ids, double* bow_vals,
+                       int* n_bow, oo_featvec_node* fv_nodes, int32_t* fv_idx, int* n_fv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,14 @@ def lib():
     L.oo_compute_stereo_matches.restype = ci
     L.oo_compute_stereo_matches.argtypes = [vp, vp, ci, vp, vp, ci, C.POINTER(OOPyramidView),
                                             C.POINTER(OOPyramidView), vp, vp, cf, cf, vp, vp]
+    L.oo_vocab_create.restype = vp; L.oo_vocab_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp]
+    L.oo_vocab_load_text.restype = vp; L.oo_vocab_load_text.argtypes = [C.c_char_p]
+    L.oo_vocab_destroy.argtypes = [vp]
+    L.oo_vocab_nodes.restype = ci; L.oo_vocab_nodes.argtypes = [vp]
+    L.oo_vocab_words.restype = ci; L.oo_vocab_words.argtypes = [vp]
+    L.oo_vocab_transform_feature.argtypes = [vp, vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.oo_vocab_transform.restype = ci
+    L.oo_vocab_transform.argtypes = [vp, vp, ci, ci, vp, vp, C.POINTER(ci), vp, vp, C.POINTER(ci)]
     _lib = L
     return L
 
@@ -355,3 +363,79 @@ def compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, mbf, mb):
     n = lib().oo_compute_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), C.byref(vL), C.byref(vR),
                                         _p(sf), _p(isf), mbf, mb, _p(ur), _p(depth))
     return n, ur, depth
+
+
+class OracleVocabulary:
+    """DBoW2 vocabulary tree + transform over the C oracle."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("vocabulary could not be created / loaded")
+        self.h = handle
+
+    @classmethod
+    def load_text(cls, path):
+        return cls(lib().oo_vocab_load_text(path.encode()))
+
+    @classmethod
+    def from_arrays(cls, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0):
+        parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+        return cls(lib().oo_vocab_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oo_vocab_destroy(self.h)
+            self.h = None
+
+    def info(self):
+        return lib().oo_vocab_nodes(self.h), lib().oo_vocab_words(self.h)
+
+    def transform(self, descriptors, levelsup=4):
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); weight = np.zeros(n, np.float64)
+        for i in range(n):
+            w, nd, wt = C.c_int32(), C.c_int32(), C.c_double()
+            lib().oo_vocab_transform_feature(self.h, _p(d[i]), levelsup, C.byref(w), C.byref(nd), C.byref(wt))
+            word[i], node[i], weight[i] = w.value, nd.value, wt.value
+        bow_ids = np.zeros(max(n, 1), np.int32); bow_vals = np.zeros(max(n, 1), np.float64)
+        fv_nodes = (FeatVecNode * max(n, 1))(); fv_idx = np.zeros(max(n, 1), np.int32)
+        nb, nf = C.c_int(0), C.c_int(0)
+        lib().oo_vocab_transform(self.h, _p(d), n, levelsup, _p(bow_ids), _p(bow_vals), C.byref(nb), C.cast(fv_nodes, C.c_void_p),
+                                 _p(fv_idx), C.byref(nf))
+        bow = {int(bow_ids[i]): float(bow_vals[i]) for i in range(nb.value)}
+        fv = {int(fv_nodes[i].node_id): fv_idx[fv_nodes[i].start: fv_nodes[i].start + fv_nodes[i].count].tolist() for i in range(nf.value)}
+        return bow, fv, (word, node, weight)
+
+
+def synthetic_vocabulary(k=10, L=3, seed=0, stop_fraction=0.05, ragged=False):
+    """Random k-ary tree of depth L in loadFromTextFile order (breadth first).  Returns arrays + the text lines."""
+    rng = np.random.default_rng(seed)
+    parent = [0]; leaf = [0]; depth = [0]
+    frontier = [0]
+    for lvl in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            if ragged and lvl > 1 and rng.random() < 0.15:
+                continue  # this node stays a leaf above the last level
+            kk = k if not ragged else int(rng.integers(2, k + 1))
+            for _ in range(kk):
+                parent.append(p); leaf.append(0); depth.append(lvl); nxt.append(len(parent) - 1)
+        frontier = nxt
+    n = len(parent)
+    has_child = np.zeros(n, bool)
+    for i in range(1, n):
+        has_child[parent[i]] = True
+    leaf = (~has_child).astype(np.uint8); leaf[0] = 0
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    weight = np.where(leaf > 0, rng.uniform(0.5, 9.0, n), 0.0)
+    weight[(rng.random(n) < stop_fraction) & (leaf > 0)] = 0.0  # stopped words
+    return np.array(parent, np.int32), leaf, desc, weight
+
+
+def write_vocabulary_text(path, k, L, parent, leaf, desc, weight, scoring=0, weighting=0):
+    with open(path, "w") as f:
+        f.write(f"{k} {L} {scoring} {weighting}\n")
+        for i in range(1, len(parent)):
+            f.write(f"{parent[i]} {int(leaf[i])} " + " ".join(str(int(b)) for b in desc[i]) + f" {float(weight[i])!r}\n")

@@ -374,3 +374,38 @@ def test_search_for_initialization(window, ratio):
         np.testing.assert_array_equal(m12, om12)
         np.testing.assert_array_equal(p2, op2)
         assert nm > 100 and np.all(m12[k0["octave"] > 0] == -1)
+
+
+@pytest.mark.parametrize("k,L,ragged,weighting,scoring", [(10, 3, False, 0, 0), (10, 4, False, 0, 0), (7, 5, True, 0, 0),
+                                                           (10, 3, False, 1, 1), (10, 3, False, 2, 5), (10, 3, False, 3, 0)])
+def test_compute_bow_transform(tmp_path, k, L, ragged, weighting, scoring):
+    """Frame::ComputeBoW: tree descent on the device, BowVector / FeatureVector equal to the DBoW2 restatement."""
+    from refactored_orb_slam2_amd.vocabulary import ORBVocabulary
+    parent, leaf, vdesc, weight = ol.synthetic_vocabulary(k, L, seed=k * 10 + L, ragged=ragged)
+    path = str(tmp_path / "voc.txt")
+    ol.write_vocabulary_text(path, k, L, parent, leaf, vdesc, weight, scoring, weighting)
+    voc = ORBVocabulary()
+    assert voc.loadFromTextFile(path)
+    ov = ol.OracleVocabulary.load_text(path)
+    assert voc.info()[2:] == ov.info() == (len(parent), int(leaf.sum()))
+    k0, d0, k1, d1, sf = _two_frames(640, 480, 1000)
+    # descriptors near vocabulary nodes + exact ties between sibling nodes (first child must win)
+    d = d0.copy()
+    d[:50] = vdesc[np.random.default_rng(1).integers(1, len(parent), 50)]
+    for levelsup in (4, 2, 0, L + 3):
+        bow, fv, (w, nd, wt) = voc.transform(d, levelsup)
+        obow, ofv, (ow, ond, owt) = ov.transform(d, levelsup)
+        np.testing.assert_array_equal(w, ow); np.testing.assert_array_equal(nd, ond); np.testing.assert_array_equal(wt, owt)
+        assert bow == obow and fv == ofv  # doubles compared exactly
+        assert sum(len(v) for v in fv.values()) == int((owt > 0).sum())
+    if scoring == 0 and weighting == 0:
+        assert abs(sum(bow.values()) - 1.0) < 1e-12  # L1-normalised
+    # the FeatureVectors feed SearchByBoW end to end
+    bow1, fv1, _ = voc.transform(d1, 4 if L > 4 else L - 1)
+    bow0, fv0, _ = voc.transform(d0, 4 if L > 4 else L - 1)
+    valid = np.ones(len(d0), np.uint8)
+    nm, mB = ORBmatcher(0.9, True).SearchByBoW(d0, k0["angle"], valid, fv0, d1, k1["angle"], fv1)
+    onm, omB = ol.search_by_bow(d0, k0["angle"], valid, fv0, d1, k1["angle"], fv1, np.float32(0.9), True)
+    assert nm == onm and np.array_equal(mB, omB)
+    assert not ORBVocabulary().loadFromTextFile(str(tmp_path / "missing.txt"))
+    voc.close()

@@ -184,3 +184,33 @@ def test_stereo_oracle_sane():
     true = 5 + 55 * kL["y"][ok] / 479.0           # synthetic disparity field of synth.stereo_pair
     assert np.median(np.abs(disp - true)) < 1.0
     np.testing.assert_allclose(depth[ok], np.float32(386.1448) / disp.astype(np.float32), rtol=1e-6)
+
+
+def test_vocabulary_transform_hand_example(tmp_path):
+    """k=2, L=2 tree with hand-checked descent, word ids in file order, TF-IDF sums, L1 norm, FeatureVector order."""
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 255, np.uint8)
+    h = z.copy(); h[:16] = 255            # half ones
+    q = z.copy(); q[:8] = 255             # quarter ones
+    #          root  n1(z-ish) n2(f-ish)  n3     n4     n5     n6
+    parent = [0,    0,        0,         1,     1,     2,     2]
+    leaf =   [0,    0,        0,         1,     1,     1,     1]
+    desc = np.stack([z, q, f, z, h, f, h])            # children of n1: n3=z, n4=h; of n2: n5=f, n6=h
+    weight = [0.0, 0.0, 0.0, 2.0, 3.0, 5.0, 0.0]      # word ids: n3->0, n4->1, n5->2, n6->3 (stopped: weight 0)
+    path = str(tmp_path / "v.txt")
+    ol.write_vocabulary_text(path, 2, 2, parent, leaf, desc, weight)
+    v = ol.OracleVocabulary.load_text(path)
+    assert v.info() == (7, 4)
+    feats = np.stack([z, z, h, f, q])
+    # z -> n1 (dist 64 vs 256) -> n3 (0 vs 128): word 0.  h -> n1 (dist |h^q| = 64) vs n2 (128) -> n1; then n3 (128) vs
+    # n4 (0) -> word 1.  f -> n2 -> n5: word 2.  q -> n1 (0) -> n3 (64) vs n4 (64): tie, first child wins -> word 0.
+    bow, fv, (w, nd, wt) = v.transform(feats, levelsup=1)
+    assert w.tolist() == [0, 0, 1, 2, 0] and nd.tolist() == [1, 1, 1, 2, 1] and wt.tolist() == [2, 2, 3, 5, 2]
+    tot = 6.0 + 3.0 + 5.0
+    assert bow == {0: 6.0 / tot, 1: 3.0 / tot, 2: 5.0 / tot}
+    assert fv == {1: [0, 1, 2, 4], 2: [3]}
+    bow0, fv0, _ = v.transform(feats, levelsup=2)      # L - levelsup = 0 -> everything under the root
+    assert fv0 == {0: [0, 1, 2, 3, 4]} and bow0 == bow
+    half = np.zeros((1, 32), np.uint8); half[0, :22] = 255   # n2 (80 < 112), then n6 (48 < 80): the stopped word -> dropped
+    bow1, fv1, (w1, _, wt1) = v.transform(np.concatenate([feats, half]), 1)
+    assert w1[-1] == 3 and wt1[-1] == 0 and fv1 == fv and bow1 == bow
