@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   __shared__ uint16_t clist[(ORBFE_CELL_MAX - 6) * (ORBFE_CELL_MAX - 6)];
   __shared__ int nlist;
   __shared__ int scan_tmp[8];
+  __shared__ uint32_t bits_all[128], bits_hi[128];
 
   const int tid = threadIdx.x;
   const int img = blockIdx.y;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   const int ndw = (xo + cols + 3) >> 2;
 
   if (tid == 0) nlist = 0;
+  if (tid < 128) { bits_all[tid] = 0; bits_hi[tid] = 0; }
   // stage ROI (aligned dwords) and clear the score plane
   {
     uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
@@ -187,24 +189,32 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   // pass A1: quick reject.  A 9-arc of the 16-ring contains at least one pixel of every antipodal pair, so a
   // corner needs, in each of the pairs (0,8) (2,10) (4,12) (6,14), a pixel darker than v-t (dark arc) -- or, in
   // each of them, one brighter than v+t (bright arc).  Sign bits do the comparisons; survivors are compacted.
-  for (int p = tid; p < npix; p += 256) {
-    const int ty = (int)((p + 0.5f) * inv_tw);
-    const int tx = p - ty * tw;
-    const int x = tx + 3, y = ty + 3;
-    const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
-    const int v = c[0];
-    const int lo = v - min_th, hi = v + min_th;
-    int dark = -1, bright = -1;  // sign bit = "every pair so far has a darker / brighter member"
+  // Threads form a 32 x 8 patch that sweeps the tested region (no index division).
+  {
+    const int lx = tid & 31, ly = tid >> 5;
+    for (int by = 0; by < th; by += 8) {
+      const int ty = by + ly;
+      for (int bx = 0; bx < tw; bx += 32) {
+        const int tx = bx + lx;
+        if (ty < th && tx < tw) {
+          const int x = tx + 3, y = ty + 3;
+          const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
+          const int v = c[0];
+          const int lo = v - min_th, hi = v + min_th;
+          int dark = -1, bright = -1;  // sign bit = "every pair so far has a darker / brighter member"
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      const int qa = c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
-      const int qb = c[RDY[k + 8] * ORBFE_TILE_PITCH + RDX[k + 8]];
-      dark &= (qa - lo) | (qb - lo);
-      bright &= (hi - qa) | (hi - qb);
-    }
-    if ((dark | bright) < 0) {
-      int idx = atomicAdd(&nlist, 1);
-      clist[idx] = (uint16_t)((y << 8) | x);
+          for (int k = 0; k < 8; k += 2) {
+            const int qa = c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
+            const int qb = c[RDY[k + 8] * ORBFE_TILE_PITCH + RDX[k + 8]];
+            dark &= (qa - lo) | (qb - lo);
+            bright &= (hi - qa) | (hi - qb);
+          }
+          if ((dark | bright) < 0) {
+            int idx = atomicAdd(&nlist, 1);
+            clist[idx] = (uint16_t)((y << 8) | x);
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -224,53 +234,48 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   }
   __syncthreads();
 
-  // pass B: NMS + ordered compaction.  Thread t owns the row-major pixel range [t*K, (t+1)*K).
-  const int K = (npix + 255) >> 8;
-  uint32_t surv = 0, survhi = 0;
-  const int p0 = tid * K;
-  int ty0 = 0, tx0 = 0;
-  if (p0 < npix) {
-    ty0 = (int)((p0 + 0.5f) * inv_tw);
-    tx0 = p0 - ty0 * tw;
-  }
-  {
-    int tx = tx0, ty = ty0;
-    for (int i = 0; i < K && p0 + i < npix; i++) {
-      const uint8_t* s = sc + (ty + 3) * ORBFE_TILE_PITCH + (tx + 3);
-      const int v = s[0];
-      if (v > 0) {
-        const bool keep = v > s[-1] && v > s[1] && v > s[-ORBFE_TILE_PITCH - 1] && v > s[-ORBFE_TILE_PITCH] &&
-                          v > s[-ORBFE_TILE_PITCH + 1] && v > s[ORBFE_TILE_PITCH - 1] && v > s[ORBFE_TILE_PITCH] &&
-                          v > s[ORBFE_TILE_PITCH + 1];
-        if (keep) {
-          surv |= 1u << i;
-          if (v >= ini_th) survhi |= 1u << i;
-        }
+  // pass B: strict 3x3 NMS of the scored pixels only (out-of-region neighbours are 0); survivors set one bit per
+  // tested pixel (row-major index p = ty*tw + tx), th=ini survivors a second bit.
+  for (int i = tid; i < nl; i += 256) {
+    const int e = clist[i];
+    const int x = e & 0xff, y = e >> 8;
+    const uint8_t* s = sc + y * ORBFE_TILE_PITCH + x;
+    const int v = s[0];
+    if (v > 0) {
+      const bool keep = v > s[-1] && v > s[1] && v > s[-ORBFE_TILE_PITCH - 1] && v > s[-ORBFE_TILE_PITCH] &&
+                        v > s[-ORBFE_TILE_PITCH + 1] && v > s[ORBFE_TILE_PITCH - 1] && v > s[ORBFE_TILE_PITCH] &&
+                        v > s[ORBFE_TILE_PITCH + 1];
+      if (keep) {
+        const int p = (y - 3) * tw + (x - 3);
+        atomicOr(&bits_all[p >> 5], 1u << (p & 31));
+        if (v >= ini_th) atomicOr(&bits_hi[p >> 5], 1u << (p & 31));
       }
-      if (++tx == tw) { tx = 0; ty++; }
     }
   }
+  __syncthreads();
+
+  // ordered emission: one 32-pixel word per thread, one block scan, cv::FAST(ini) result if non-empty else cv::FAST(min)
+  const int nwords = (npix + 31) >> 5;  // <= 113 (60 x 60 tested pixels)
+  const uint32_t wall = tid < nwords ? bits_all[tid] : 0u, whi = tid < nwords ? bits_hi[tid] : 0u;
   int total;
-  const int packed = (__popc(survhi) << 16) | __popc(surv);
+  const int packed = (__popc(whi) << 16) | __popc(wall);
   const int incl = block_incl_scan256(packed, scan_tmp, &total);
   const int excl = incl - packed;
   const bool use_hi = (total >> 16) != 0;
-  const uint32_t mask = use_hi ? survhi : surv;
+  uint32_t mask = use_hi ? whi : wall;
   int off = use_hi ? (excl >> 16) : (excl & 0xffff);
   const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
   uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
-  if (mask) {
-    int tx = tx0, ty = ty0;
-    for (int i = 0; i < K; i++) {
-      if (mask & (1u << i)) {
-        const int x = tx + 3, y = ty + 3;
-        const uint32_t s = sc[y * ORBFE_TILE_PITCH + x];
-        const uint32_t rx = (uint32_t)(x + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(y + cd.y0 - ORBFE_EDGE);
-        if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (s << 24);
-        off++;
-      }
-      if (++tx == tw) { tx = 0; ty++; }
-    }
+  while (mask) {
+    const int b = __ffs((int)mask) - 1;
+    mask &= mask - 1;
+    const int p = tid * 32 + b;
+    const int ty = (int)((p + 0.5f) * inv_tw);
+    const int x = p - ty * tw + 3, y = ty + 3;
+    const uint32_t sv = sc[y * ORBFE_TILE_PITCH + x];
+    const uint32_t rx = (uint32_t)(x + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(y + cd.y0 - ORBFE_EDGE);
+    if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
+    off++;
   }
   if (tid == 0) cell_cnt[(size_t)img * total_cells + blockIdx.x] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
 }
