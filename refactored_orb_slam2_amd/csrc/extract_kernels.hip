@@ -350,7 +350,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   }
   const int C = running;
   if (C > L.key_cap || C > 0xFFFFFF) {  // cannot happen: key_cap = sum of slot caps
-    if (tid == 0) { atomicOr(P.err, 1); P.lvl_n[(size_t)img * P.n_levels + level] = 0; }
+    if (tid == 0) { atomicOr(P.err, 1); P.lvl_n[(size_t)img * ORBFE_MAX_LEVELS + level] = 0; }
     return;
   }
   unsigned long long* keys = (C <= P.lds_keys) ? lkeys : (P.gkeys + (size_t)img * P.gkeys_per_image + L.key_off);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     }
     const int newsize = K + S;
     if (newsize > M) {  // cannot happen: M >= max(N + 3, 4 * nIni)
-      if (tid == 0) { atomicOr(P.err, 2); P.lvl_n[(size_t)img * P.n_levels + level] = 0; }
+      if (tid == 0) { atomicOr(P.err, 2); P.lvl_n[(size_t)img * ORBFE_MAX_LEVELS + level] = 0; }
       return;
     }
     __syncthreads();
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   }
   if (tid == 0) {
     if (size > L.kp_cap) atomicOr(P.err, 4);
-    P.lvl_n[(size_t)img * P.n_levels + level] = size < L.kp_cap ? size : L.kp_cap;
+    P.lvl_n[(size_t)img * ORBFE_MAX_LEVELS + level] = size < L.kp_cap ? size : L.kp_cap;
   }
 }
 
@@ -772,19 +772,37 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const int lane = threadIdx.x & (WAVE - 1);
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.y;
-  const int32_t* ln = P.lvl_n + (size_t)img * P.n_levels;
+  // per-level keypoint counts of this image: 16 ints, four independent 16-byte loads
+  int cnt[ORBFE_MAX_LEVELS];
+  {
+    const int4* ln4 = reinterpret_cast<const int4*>(P.lvl_n + (size_t)img * ORBFE_MAX_LEVELS);
+#pragma unroll
+    for (int k = 0; k < ORBFE_MAX_LEVELS / 4; k++) {
+      const int4 t = ln4[k];
+      cnt[4 * k] = t.x; cnt[4 * k + 1] = t.y; cnt[4 * k + 2] = t.z; cnt[4 * k + 3] = t.w;
+    }
+  }
+  // the four pattern entries of this lane (rounds 0..3): issued early, consumed after the orientation
+  int pk[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const int*>(&g_pattern[(r * 64 + lane) * 4]);
   if (slot == 0 && lane == 0) {
     int tot = 0;
-    for (int l = 0; l < P.n_levels; l++) tot += ln[l];
+#pragma unroll
+    for (int l = 0; l < ORBFE_MAX_LEVELS; l++) tot += l < P.n_levels ? cnt[l] : 0;
     P.out_n[img] = tot;
   }
   if (slot >= P.kp_per_image) return;
   int level = 0;
   while (level + 1 < P.n_levels && slot >= P.kp_off[level + 1]) level++;
   const int idx = slot - P.kp_off[level];
-  if (idx >= ln[level]) return;
-  int out = idx;
-  for (int l = 0; l < level; l++) out += ln[l];
+  int out = idx, nlev = 0;
+#pragma unroll
+  for (int l = 0; l < ORBFE_MAX_LEVELS; l++) {
+    out += l < level ? cnt[l] : 0;
+    nlev = l == level ? cnt[l] : nlev;
+  }
+  if (idx >= nlev) return;
   if (out >= P.cap) return;
 
   const uint32_t e = P.lvl_kp[(size_t)img * P.kp_per_image + slot];
@@ -792,7 +810,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const int score = (int)(e >> 24);
 
   // --- stage both patches of this keypoint in the wave's LDS slice with aligned dword loads:
-  //     un-blurred 31x31 (orientation) and blurred 37x37 (rotated pattern offsets reach +-18)
+  //     un-blurred 31x31 (orientation) and blurred 37x37 (rotated pattern offsets reach +-18).
+  //     All 11 loads of a lane are issued before the first LDS store (one memory round trip, not eleven).
   uint8_t* ori = &patch[threadIdx.x >> 6][0];
   uint8_t* dsc = ori + ORI_BYTES;
   const int pitch = P.pyr.pitch[level];
@@ -801,15 +820,30 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const uint8_t* bplane = P.blur.base[level] + (size_t)img * P.blur.img_stride[level];
   const int ax_o = (cx - 15) & ~3, ax_d = (cx - 18) & ~3;
   constexpr int ndw_o = 9, ndw_d = 10;  // enough for any alignment; the extra dword stays inside the row pitch + slack
-  for (int i = lane; i < 31 * ndw_o; i += WAVE) {
+  uint32_t vo[5], vd[6];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int i = lane + WAVE * k;
     const int r = i / ndw_o, c = i - r * ndw_o;
-    reinterpret_cast<uint32_t*>(ori)[r * (ORI_PITCH / 4) + c] =
-        *reinterpret_cast<const uint32_t*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 4 * c);
+    vo[k] = i < 31 * ndw_o ? *reinterpret_cast<const uint32_t*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 4 * c) : 0u;
   }
-  for (int i = lane; i < 37 * ndw_d; i += WAVE) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int i = lane + WAVE * k;
     const int r = i / ndw_d, c = i - r * ndw_d;
-    reinterpret_cast<uint32_t*>(dsc)[r * (DSC_PITCH / 4) + c] =
-        *reinterpret_cast<const uint32_t*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 4 * c);
+    vd[k] = i < 37 * ndw_d ? *reinterpret_cast<const uint32_t*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 4 * c) : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int i = lane + WAVE * k;
+    const int r = i / ndw_o, c = i - r * ndw_o;
+    if (i < 31 * ndw_o) reinterpret_cast<uint32_t*>(ori)[r * (ORI_PITCH / 4) + c] = vo[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int i = lane + WAVE * k;
+    const int r = i / ndw_d, c = i - r * ndw_d;
+    if (i < 37 * ndw_d) reinterpret_cast<uint32_t*>(dsc)[r * (DSC_PITCH / 4) + c] = vd[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -849,10 +883,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int pi = r * 64 + lane;
-    const int pk = *reinterpret_cast<const int*>(&g_pattern[pi * 4]);
-    const float x0 = (float)(int8_t)(pk & 0xff), y0 = (float)(int8_t)((pk >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((pk >> 16) & 0xff), y1 = (float)(int8_t)((pk >> 24) & 0xff);
+    const float x0 = (float)(int8_t)(pk[r] & 0xff), y0 = (float)(int8_t)((pk[r] >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pk[r] >> 16) & 0xff), y1 = (float)(int8_t)((pk[r] >> 24) & 0xff);
     const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
     const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
     const int t0 = bc[ry0 * DSC_PITCH + rx0];

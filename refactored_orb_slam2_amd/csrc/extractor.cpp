@@ -329,9 +329,10 @@ static int ensure_workspace(orbfe_extractor* e, int n_images) {
   if ((rc = dev_alloc(e->d_slots, sizeof(uint32_t) * e->slots_per_image * B))) return rc;
   if ((rc = dev_alloc(e->d_gkeys, sizeof(uint64_t) * e->gkeys_per_image * B))) return rc;
   if ((rc = dev_alloc(e->d_lvl_kp, sizeof(uint32_t) * e->kp_per_image * B))) return rc;
-  if ((rc = dev_alloc(e->d_lvl_n, sizeof(int32_t) * e->prm.n_levels * B))) return rc;
+  if ((rc = dev_alloc(e->d_lvl_n, sizeof(int32_t) * ORBFE_MAX_LEVELS * B))) return rc;  // 16 per image (aligned 64 B)
   if ((rc = dev_alloc(e->d_err, 256))) return rc;
   HIPCHK(hipMemsetAsync(e->d_err.p, 0, 256, e->stream));
+  HIPCHK(hipMemsetAsync(e->d_lvl_n.p, 0, sizeof(int32_t) * ORBFE_MAX_LEVELS * B, e->stream));  // unused level slots stay 0
   HIPCHK(hipStreamSynchronize(e->stream));
   e->cap_images = n_images;
   return ORBFE_OK;
@@ -836,7 +837,7 @@ extern "C" int orbfe_debug_level_keypoints(orbfe_extractor* e, int image, int le
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   int32_t cnt = 0;
-  HIPCHK(hipMemcpy(&cnt, (int32_t*)e->d_lvl_n.p + (size_t)image * e->prm.n_levels + level, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&cnt, (int32_t*)e->d_lvl_n.p + (size_t)image * ORBFE_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
   std::vector<uint32_t> tmp(std::max(cnt, 1));
   if (cnt > 0)
     HIPCHK(hipMemcpy(tmp.data(), (uint32_t*)e->d_lvl_kp.p + (size_t)image * e->kp_per_image + e->oct[level].kp_off,
