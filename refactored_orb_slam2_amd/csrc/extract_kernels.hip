@@ -616,15 +616,33 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   const bool interior = ox >= 4 && ox + BT_W + 3 < w && oy >= 3 && oy + BT_H + 3 <= h;
   if (interior) {
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
-    for (int i = tid; i < (BT_H + 6) * 18; i += 256) {
+    uint32_t v[3];  // (32+6)*18 = 684 dwords: three per thread, all issued before the first LDS store
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int i = tid + 256 * k;
       const int r = i / 18, c = i - r * 18;
-      in32[r * (BT_INP / 4) + c] = *reinterpret_cast<const uint32_t*>(S + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c);
+      v[k] = i < (BT_H + 6) * 18 ? *reinterpret_cast<const uint32_t*>(S + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int i = tid + 256 * k;
+      const int r = i / 18, c = i - r * 18;
+      if (i < (BT_H + 6) * 18) in32[r * (BT_INP / 4) + c] = v[k];
     }
   } else {
-    for (int i = tid; i < (BT_H + 6) * 70; i += 256) {
+    uint8_t v[11];  // (32+6)*70 = 2660 bytes with REFLECT_101 indexing: eleven per thread, loads first
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const int i = tid + 256 * k;
       const int r = i / 70, c = i - r * 70;  // c <-> x = ox - 3 + c  <-> column j = c + 1
       const int gy = reflect101(oy + r - 3, h), gx = reflect101(ox + c - 3, w);
-      in[r * BT_INP + c + 1] = S[(size_t)gy * pitch + gx];
+      v[k] = i < (BT_H + 6) * 70 ? S[(size_t)gy * pitch + gx] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const int i = tid + 256 * k;
+      const int r = i / 70, c = i - r * 70;
+      if (i < (BT_H + 6) * 70) in[r * BT_INP + c + 1] = v[k];
     }
   }
   __syncthreads();

@@ -807,6 +807,9 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const int pair = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1);
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float s_r[ORBFE_MAX_LEVELS];  // r = 2 * scale[octave] of a right keypoint (L/src/Frame.cc:496)
+  if (threadIdx.x < ORBFE_MAX_LEVELS) s_r[threadIdx.x] = 2.0f * P.scale[threadIdx.x];
+  __syncthreads();
   if (iL >= P.cap) return;
   float* out_ur = P.u_right + (size_t)pair * P.cap;
   float* out_depth = P.depth + (size_t)pair * P.cap;
@@ -819,10 +822,11 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const uint8_t* dl = P.descL + (size_t)pair * P.cap * 32;
   const uint8_t* dr = P.descR + (size_t)pair * P.cap * 32;
   const orbfe_keypoint kpL = kl[iL];
-  const int levelL = kpL.octave;
+  // every lane read the same record: tell the compiler, so that the per-level parameters become scalar loads
+  const int levelL = __builtin_amdgcn_readfirstlane(kpL.octave);
   const float vL = kpL.y, uL = kpL.x;
   const int nRows = P.pyrL.h[0];
-  const int row = (int)vL;
+  const int row = __builtin_amdgcn_readfirstlane((int)vL);
   if (row < 0 || row >= nRows) return;
   const float minD = 0, maxD = P.maxD;
   const float minU = uL - maxD, maxU = uL - minD;
@@ -833,18 +837,39 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
   const int32_t* bidx = P.bucket_idx + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
   const int e0 = bs[row >> 3], e1 = bs[(row >> 3) + 1];
-  for (int e = e0 + lane; e < e1; e += WAVE) {
-    const int iR = bidx[e];
-    const orbfe_keypoint kpR = kr[iR];
-    const float r = 2.0f * P.scale[kpR.octave];
-    const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
-    if (row < minr || row > maxr) continue;
-    if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
-    if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
-    uint4 b0, b1;
-    load_desc(dr + (size_t)iR * 32, b0, b1);
-    const unsigned key = ((unsigned)hamming256(a0, a1, b0, b1) << 16) | (unsigned)iR;
-    if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) best = key;  // (dist, index) minimum among dist < TH_HIGH
+  // two 64-entry chunks of the bucket in flight: indices, then keypoint records, then (for the survivors of the
+  // band / level / disparity tests) descriptors -- three memory round trips for up to 128 candidates
+  for (int eb = e0; eb < e1; eb += 2 * WAVE) {
+    int iR[2];
+    orbfe_keypoint kpR[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int e = eb + u * WAVE + lane;
+      iR[u] = e < e1 ? bidx[e] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (iR[u] >= 0) kpR[u] = kr[iR[u]];
+      else { kpR[u].x = 0; kpR[u].y = 0; kpR[u].octave = 0; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const float r = s_r[kpR[u].octave & (ORBFE_MAX_LEVELS - 1)];
+      const int maxr = (int)ceilf(kpR[u].y + r), minr = (int)floorf(kpR[u].y - r);
+      ok[u] = iR[u] >= 0 && !(row < minr || row > maxr) && !(kpR[u].octave < levelL - 1 || kpR[u].octave > levelL + 1) &&
+              (kpR[u].x >= minU && kpR[u].x <= maxU);
+    }
+    uint4 b0[2], b1[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (ok[u]) load_desc(dr + (size_t)iR[u] * 32, b0[u], b1[u]);
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (ok[u]) {
+        const unsigned key = ((unsigned)hamming256(a0, a1, b0[u], b1[u]) << 16) | (unsigned)iR[u];
+        if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) best = key;  // (dist, index) minimum among dist < TH_HIGH
+      }
   }
   // first minimum in index order
   {
