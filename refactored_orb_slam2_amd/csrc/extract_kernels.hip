@@ -98,6 +98,62 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
   *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
 }
 
+// LDS-staged variant: a workgroup produces a 256 x 4 destination tile; the source window it needs (at most
+// RS_ROWS rows x RS_COLS bytes for scale factors up to 2) is fetched with aligned 16-byte loads, the per-pixel taps
+// then gather single bytes from LDS instead of issuing byte loads to HBM/L2.  Same arithmetic, same tables.
+#define RS_ROWS 10
+#define RS_COLS 560
+__global__ __launch_bounds__(256) void pyr_resize_lds_kernel(const uint8_t* __restrict__ src, int spitch,
+                                                              unsigned long long simg, uint8_t* __restrict__ dst,
+                                                              int dpitch, unsigned long long dimg, int dw, int dh,
+                                                              const ResizeTap* __restrict__ xt,
+                                                              const ResizeTap* __restrict__ yt) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[RS_ROWS * RS_COLS];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * 4;
+  const int xl = min(x0 + 255, dw - 1), yl = min(y0 + 3, dh - 1);
+  const int sxa = xt[x0].s0 & ~15;
+  const int ncols16 = ((xt[xl].s1 - sxa) >> 4) + 1;
+  const int sy_first = yt[y0].s0;
+  const int nrows = yt[yl].s1 - sy_first + 1;
+  const uint8_t* S = src + (size_t)blockIdx.z * simg;
+  {
+    const int total = nrows * ncols16;  // <= 10 * 35
+    uint4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int i = tid + 256 * k;
+      const int r = i / ncols16, c = i - r * ncols16;
+      v[k] = i < total ? *reinterpret_cast<const uint4*>(S + (size_t)(sy_first + r) * spitch + sxa + 16 * c) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int i = tid + 256 * k;
+      const int r = i / ncols16, c = i - r * ncols16;
+      if (i < total) *reinterpret_cast<uint4*>(tile + r * RS_COLS + 16 * c) = v[k];
+    }
+  }
+  __syncthreads();
+  const int x4 = x0 + threadIdx.x * 4;
+  const int y = y0 + threadIdx.y;
+  if (x4 >= dw || y >= dh) return;
+  const ResizeTap ty = yt[y];
+  const uint8_t* S0 = tile + (ty.s0 - sy_first) * RS_COLS - sxa;
+  const uint8_t* S1 = tile + (ty.s1 - sy_first) * RS_COLS - sxa;
+  const int b0 = ty.c0, b1 = ty.c1;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int dx = x4 + i < dw ? x4 + i : dw - 1;
+    const ResizeTap tx = xt[dx];
+    const int t0 = S0[tx.s0] * tx.c0 + S0[tx.s1] * tx.c1;
+    const int t1 = S1[tx.s0] * tx.c0 + S1[tx.s1] * tx.c1;
+    const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+    out |= (uint32_t)(v & 0xff) << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
+}
+
 // ------------------------------------------------------------------------------------------------ FAST
 // ring offsets of FAST-9/16 (OpenCV makeOffsets, patternSize 16)
 __device__ constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -941,10 +997,14 @@ void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* d
 }
 
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
-                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, hipStream_t s) {
+                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s) {
   dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
-  hipLaunchKernelGGL(pyr_resize_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
-                     (unsigned long long)dimg, dw, dh, xt, yt);
+  if (lds_ok)
+    hipLaunchKernelGGL(pyr_resize_lds_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
+                       (unsigned long long)dimg, dw, dh, xt, yt);
+  else  // source window of a tile exceeds the staged size (scale factor > 2): direct byte gathers
+    hipLaunchKernelGGL(pyr_resize_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
+                       (unsigned long long)dimg, dw, dh, xt, yt);
 }
 
 void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,

@@ -87,6 +87,7 @@ struct orbfe_extractor {
   size_t oct_lds = 0;
   // device tables
   DevBuf d_cells, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];
+  bool resize_lds_ok[ORBFE_MAX_LEVELS]{};  // every 256x4 destination tile's source window fits the LDS stage
   // work space for `cap_images`
   int cap_images = 0;
   DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_off, d_slots, d_gkeys, d_lvl_kp, d_lvl_n, d_err;
@@ -299,6 +300,18 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     std::vector<ResizeTap> xt, yt;
     build_taps(e->lg[l - 1].w, e->lg[l].w, true, xt);
     build_taps(e->lg[l - 1].h, e->lg[l].h, false, yt);
+    // does the source window of every 256 x 4 destination tile fit the staged 10 rows x 560 bytes?
+    bool ok = true;
+    for (int x0 = 0; x0 < (int)xt.size() && ok; x0 += 256) {
+      const int xl = std::min<int>(x0 + 255, (int)xt.size() - 1);
+      const int sxa = xt[x0].s0 & ~15;
+      if ((((xt[xl].s1 - sxa) >> 4) + 1) * 16 > 560) ok = false;
+    }
+    for (int y0 = 0; y0 < (int)yt.size() && ok; y0 += 4) {
+      const int yl = std::min<int>(y0 + 3, (int)yt.size() - 1);
+      if (yt[yl].s1 - yt[y0].s0 + 1 > 10) ok = false;
+    }
+    e->resize_lds_ok[l] = ok;
     if ((rc = upload(e->d_xt[l], xt.data(), xt.size() * sizeof(ResizeTap), e->stream))) return rc;
     if ((rc = upload(e->d_yt[l], yt.data(), yt.size() * sizeof(ResizeTap), e->stream))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));  // xt/yt go out of scope
@@ -404,7 +417,7 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     for (int l = 1; l < nl; l++)
       orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], e->lg[l - 1].plane, const_cast<uint8_t*>(pv.base[l]),
                           pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
-                          (const ResizeTap*)e->d_yt[l].p, n_images, s);
+                          (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_lds_ok[l], s);
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);

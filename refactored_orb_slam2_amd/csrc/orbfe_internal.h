@@ -89,7 +89,7 @@ struct BlurTile {
 
 // launchers (extract_kernels.hip)
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
-                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, hipStream_t s);
+                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s);
 void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
                        unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
