@@ -10,6 +10,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../oracle/orb_oracle.h"
@@ -112,6 +113,33 @@ int main(int argc, char** argv) {
     oo_copy_make_border_reflect101(op, lw, lh, st, bordered.data(), lw + 38, 19);
     for (int y = -19; y < lh + 19; y++)
       CHECK(memcmp(m.ptr(0) + (ptrdiff_t)y * (ptrdiff_t)m.step - 19, &bordered[(size_t)(y + 19) * (lw + 38)], lw + 38) == 0);
+  }
+  // --- two extractor instances on two threads, as Frame::Frame does for stereo (L/src/Frame.cc:87-90)
+  {
+    std::vector<uint8_t> flipped(raw.size());
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) flipped[(size_t)y * w + x] = raw[(size_t)y * w + (w - 1 - x)];
+    cv::Mat imR(h, w, cv::CV_8U, flipped.data());
+    ORB_SLAM2::ORBextractor* extR = new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> keysL2, keysR2;
+    cv::Mat descL2, descR2;
+    for (int rep = 0; rep < 5; rep++) {
+      std::thread tl([&] { (*ext)(im, cv::Mat(), keysL2, descL2); });
+      std::thread tr([&] { (*extR)(imR, cv::Mat(), keysR2, descR2); });
+      tl.join();
+      tr.join();
+      CHECK((int)keysL2.size() == on && memcmp(keysL2.data(), okeys.data(), sizeof(oo_keypoint) * on) == 0);
+      for (int i = 0; i < on; i++) CHECK(memcmp(descL2.ptr(i), &odesc[(size_t)i * 32], 32) == 0);
+    }
+    oo_extractor* orcR = oo_extractor_create(nf, 1.2f, 8, 20, 7);
+    std::vector<oo_keypoint> okR(nf + 64);
+    std::vector<uint8_t> odR((size_t)(nf + 64) * 32);
+    int onR = 0;
+    CHECK(oo_extract(orcR, flipped.data(), w, h, w, okR.data(), odR.data(), nf + 64, &onR) == 0);
+    CHECK((int)keysR2.size() == onR && memcmp(keysR2.data(), okR.data(), sizeof(oo_keypoint) * onR) == 0);
+    for (int i = 0; i < onR; i++) CHECK(memcmp(descR2.ptr(i), &odR[(size_t)i * 32], 32) == 0);
+    oo_extractor_destroy(orcR);
+    delete extR;
   }
   // --- ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) through the adapter vs the oracle
   MockFrame F;
