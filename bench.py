@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=128, help="stereo frames per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="stereo frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=160, help="stereo frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
                     help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
     args = ap.parse_args()
@@ -237,6 +237,15 @@ def main():
             per_launch_ms[k] = ms / max(cnt, 1)
         dom = max(per_launch_ms, key=lambda k: per_launch_ms[k])
         achieved = alg[dom] * F / (per_launch_ms[dom] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed PMC pass (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
+        # runs: profiles/r01_pmc_counters.md), scaled to this launch's image count; null if no pass covers the kernel
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fast.json")))
+            if pmc["kernel"].startswith(dom):
+                traffic = int((pmc["fetch_kb"] + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
+        except Exception:
+            traffic = None
         value = world * F * args.steps / dt
         out = {
             "metric": "frames/s (extract+match) at KITTI 1241×376, 2000 feat; 1/2/4/8 GPU + CPU ref",
@@ -249,7 +258,7 @@ def main():
                        "keypoints_per_image": round(n_kp / (2 * F), 1), "stereo_matches_per_frame": round(n_st / F, 1),
                        "tracked_per_frame": round(n_tr / F, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
