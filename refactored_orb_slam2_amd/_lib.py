@@ -84,6 +84,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same soname as /opt/rocm's).  Whichever is
+    # loaded first serves both; torch cannot find the GPU if the system copy got there first, so when torch is
+    # installed let it load its runtime before liborbfe.so pulls in libamdhip64.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -10,6 +10,8 @@
 //
 // All arithmetic that decides an output bit is integer, or float/double evaluated exactly as the x86-64
 // reference build does (no FMA contraction: this file is compiled with -ffp-contract=off; IEEE divide).
+#include <stdlib.h>
+
 #include "orbfe_internal.h"
 #include "../../include/orb_pattern_data.h"
 
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
                                                           int total_cells, int32_t* __restrict__ cell_cnt,
                                                           uint32_t* __restrict__ slots,
                                                           unsigned long long slots_per_image, int ini_th,
-                                                          int min_th) {
+                                                          int min_th, int xcd_run_shift) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[ORBFE_CELL_MAX * ORBFE_TILE_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t sc[ORBFE_CELL_MAX * ORBFE_TILE_PITCH];
   __shared__ uint16_t clist[(ORBFE_CELL_MAX - 6) * (ORBFE_CELL_MAX - 6)];
@@ -211,7 +213,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
 
   const int tid = threadIdx.x;
   const int img = blockIdx.y;
-  const CellDesc cd = cells[blockIdx.x];
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own
+  // L2), so consecutive cells -- which share 6-pixel halos -- would be fetched by different L2s.  Hand every XCD
+  // runs of 16 consecutive cells instead (runs interleave over the XCDs, so all levels stay balanced).
+  // (the last partial group of 8 runs keeps the identity order, so the grid needs no padding blocks)
+  const int q = blockIdx.x >> 3;
+  const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
+  const int cell_id = (xcd_run_shift < 0 || (int)blockIdx.x >= (total_cells / unit) * unit)
+                          ? (int)blockIdx.x
+                          : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
+                                (q & ((1 << xcd_run_shift) - 1));
+  const CellDesc cd = cells[cell_id];
   const int lvl = cd.level;
   const int pitch = pyr.pitch[lvl];
   const uint8_t* plane = pyr.base[lvl] + (size_t)img * pyr.img_stride[lvl];
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
     if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
     off++;
   }
-  if (tid == 0) cell_cnt[(size_t)img * total_cells + blockIdx.x] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
+  if (tid == 0) cell_cnt[(size_t)img * total_cells + cell_id] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
 }
 
 // ------------------------------------------------------------------------------------------------ octree
@@ -659,11 +671,14 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 #define BT_H 32
 #define BT_INP 80   // LDS pitch (bytes) of the input window: column j <-> level x = ox - 4 + j
 #define BT_HP 68    // LDS pitch (dwords) of one row PAIR of the horizontal-pass result (two u16 rows interleaved)
-__global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles) {
+__global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
   __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
   const int tid = threadIdx.x;
-  const BlurTile t = tiles[blockIdx.x];
+  // XCD-aware mapping (see fast_cells): runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
+  const int q = blockIdx.x >> 3;
+  const int tile_id = (int)blockIdx.x >= (n_tiles / 64) * 64 ? (int)blockIdx.x : (q >> 3) * 64 + (blockIdx.x & 7) * 8 + (q & 7);
+  const BlurTile t = tiles[tile_id];
   const int lvl = t.level;
   const int w = src.w[lvl], h = src.h[lvl], pitch = src.pitch[lvl];
   const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
@@ -1010,9 +1025,14 @@ void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* d
 void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
                        unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s) {
   if (total_cells == 0) return;
+  static int run_shift = -2;
+  if (run_shift == -2) {
+    const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order
+    run_shift = ev ? atoi(ev) : 4;
+  }
   dim3 block(256), grid(total_cells, n_images);
   hipLaunchKernelGGL(fast_cells_kernel, grid, block, 0, s, pyr, cells, total_cells, cell_cnt, slots, slots_per_image,
-                     ini_th, min_th);
+                     ini_th, min_th, run_shift);
 }
 
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s) {
@@ -1023,7 +1043,7 @@ void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hip
 void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
                        hipStream_t s) {
   dim3 block(256), grid(n_tiles, n_images);
-  hipLaunchKernelGGL(gauss_blur7_kernel, grid, block, 0, s, src, dst, tiles);
+  hipLaunchKernelGGL(gauss_blur7_kernel, grid, block, 0, s, src, dst, tiles, n_tiles);
 }
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
