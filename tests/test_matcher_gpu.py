@@ -409,3 +409,25 @@ def test_compute_bow_transform(tmp_path, k, L, ragged, weighting, scoring):
     assert nm == onm and np.array_equal(mB, omB)
     assert not ORBVocabulary().loadFromTextFile(str(tmp_path / "missing.txt"))
     voc.close()
+
+
+def test_sequence_driver_on_kitti_layout(tmp_path):
+    """examples/stereo_kitti.py on a synthetic sequence written in the KITTI directory layout (PNG + times.txt)."""
+    import subprocess, sys, os
+    from PIL import Image
+    seq = tmp_path / "00"
+    (seq / "image_0").mkdir(parents=True); (seq / "image_1").mkdir()
+    pairs = synth.sequence(1241, 376, 5, seq=20, stereo=True)
+    with open(seq / "times.txt", "w") as f:
+        for i, (L, R) in enumerate(pairs):
+            Image.fromarray(L).save(seq / "image_0" / f"{i:06d}.png")
+            Image.fromarray(R).save(seq / "image_1" / f"{i:06d}.png")
+            f.write(f"{i * 0.1:e}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--batch", "4"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "stereo_kitti.py"), str(seq)] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "median tracking time" in r.stdout and "Images in the sequence: 5" in r.stdout
+        kp = float(r.stdout.split("keypoints/left image: ")[1].split(",")[0])
+        st = float(r.stdout.split("stereo matches/frame: ")[1].split(",")[0])
+        assert 1990 < kp < 2030 and st > 800
