@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -71,6 +72,8 @@ struct orbfe_extractor {
   orbfe_params prm{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // the blur runs here, concurrently with FAST + quadtree (it only needs the pyramid)
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
   // constructor tables
   float scale[ORBFE_MAX_LEVELS]{}, inv_scale[ORBFE_MAX_LEVELS]{}, sigma2[ORBFE_MAX_LEVELS]{}, inv_sigma2[ORBFE_MAX_LEVELS]{};
   int feat_per_level[ORBFE_MAX_LEVELS]{};
@@ -98,6 +101,7 @@ struct orbfe_extractor {
   int out_cap = 0;
   int last_images = 0;
   // profiling
+  bool overlap_blur = false;  // measured: FAST and the blur are both issue-bound, running them concurrently is 2 % slower
   bool profile = false;
   float stage_ms[ORBFE_STAGE_COUNT]{};
   int stage_launches[ORBFE_STAGE_COUNT]{};
@@ -419,6 +423,19 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
                           pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
                           (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_lds_ok[l], s);
   }
+  // fork: the blur depends only on the pyramid, so it runs on the handle's second stream while FAST and the
+  // quadtree (VALU / latency bound) occupy the first; join before the descriptors
+  const bool fork = e->overlap_blur;
+  hipStream_t sb = fork ? e->stream2 : s;
+  if (fork) {
+    (void)hipEventRecord(e->ev_pyr, s);
+    (void)hipStreamWaitEvent(sb, e->ev_pyr, 0);
+  }
+  {
+    StageTimer t(e, sb, ORBFE_STAGE_BLUR);
+    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), n_images, sb);
+  }
+  if (fork) (void)hipEventRecord(e->ev_blur, sb);
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
     orbfe_launch_fast(pv, (const CellDesc*)e->d_cells.p, e->total_cells, (int32_t*)e->d_cell_cnt.p,
@@ -446,10 +463,7 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     op.lds_keys = e->lds_keys;
     orbfe_launch_octree(op, n_images, e->oct_lds, s);
   }
-  {
-    StageTimer t(e, s, ORBFE_STAGE_BLUR);
-    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), n_images, s);
-  }
+  if (fork) (void)hipStreamWaitEvent(s, e->ev_blur, 0);
   {
     StageTimer t(e, s, ORBFE_STAGE_DESCRIBE);
     DescribeParams dp;
@@ -528,11 +542,15 @@ extern "C" int orbfe_extractor_create(const orbfe_params* p, int device, orbfe_e
   }
   e->feat_per_level[p->n_levels - 1] = std::max(p->n_features - sum, 0);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming);
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming);
   if (he != hipSuccess) {
     orbfe_set_error("hipStreamCreate: %s", hipGetErrorString(he));
     delete e;
     return ORBFE_ERR_HIP;
   }
+  if (const char* ev = getenv("ORBFE_OVERLAP_BLUR")) e->overlap_blur = atoi(ev) != 0;  // experiment knob
   *out = e;
   return ORBFE_OK;
 }
@@ -551,6 +569,9 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   if (e->h_out) (void)hipHostFree(e->h_out);
   for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { dev_free(e->d_xt[l]); dev_free(e->d_yt[l]); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
+  if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
+  if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
   delete e;
   return ORBFE_OK;
 }
