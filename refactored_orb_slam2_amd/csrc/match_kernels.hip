@@ -230,41 +230,56 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
   const float* ur = F.u_right ? F.u_right + (size_t)f * F.cap : nullptr;
   const int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
   const int32_t* ci = F.cell_idx + (size_t)f * F.cap;
+  // The window's cells of one grid column (ix, nMinCellY..nMaxCellY) are adjacent in CSR order.  Lane c fetches
+  // column c's range; the ranges are concatenated (prefix sum) into one flat candidate sequence -- column-major, then
+  // cell row, then ascending index: the reference's enumeration order -- that the wave consumes 64 entries at a time.
+  const int ncol = nMaxCellX - nMinCellX + 1;  // <= 64
+  int e0c = 0, cntc = 0;
+  if (lane < ncol) {
+    const int ix = nMinCellX + lane;
+    e0c = cs[ix * ORBFE_GRID_ROWS + nMinCellY];
+    cntc = cs[ix * ORBFE_GRID_ROWS + nMaxCellY + 1] - e0c;
+  }
+  const int inclc = wave_incl_scan_i(cntc);
+  const int exclc = inclc - cntc;
+  const int n_entries = __shfl(inclc, WAVE - 1, WAVE);
   int rank0 = 0;
-  for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-    // cells (ix, nMinCellY..nMaxCellY) are adjacent in CSR order
-    const int e0 = cs[ix * ORBFE_GRID_ROWS + nMinCellY], e1 = cs[ix * ORBFE_GRID_ROWS + nMaxCellY + 1];
-    for (int base = e0; base < e1; base += WAVE) {
-      const int ent = base + lane;
-      bool ok = false;
-      int idx = 0;
-      if (ent < e1) {
-        idx = ci[ent];
-        const orbfe_keypoint kp = keys[idx];
-        ok = true;
-        if (bCheckLevels) {
-          if (kp.octave < q.min_level) ok = false;
-          if (q.max_level >= 0 && kp.octave > q.max_level) ok = false;
-        }
-        const float distx = kp.x - x, disty = kp.y - y;
-        if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
-        if (ok && ur) {
-          const float u = ur[idx];
-          if (u > 0) {
-            const float er = fabsf(q.u_r - u);
-            if (er > r) ok = false;
-          }
-        }
-      }
-      const unsigned long long m = __ballot(ok);
-      if (ok) {
-        uint4 d0, d1;
-        load_desc(desc + (size_t)idx * 32, d0, d1);
-        const int rank = rank0 + __popcll(m & ((1ull << lane) - 1ull));
-        fn(rank, idx, hamming256(q0, q1, d0, d1));
-      }
-      rank0 += __popcll(m);
+  for (int base = 0; base < n_entries; base += WAVE) {
+    const int t = base + lane;
+    int ent = -1;
+    for (int c = 0; c < ncol; c++) {
+      const int oc = __shfl(exclc, c, WAVE), nc = __shfl(cntc, c, WAVE), ec = __shfl(e0c, c, WAVE);
+      if (t >= oc && t < oc + nc) ent = ec + (t - oc);
     }
+    bool ok = false;
+    int idx = 0, oct = 0;
+    if (ent >= 0) {
+      idx = ci[ent];
+      const orbfe_keypoint kp = keys[idx];
+      oct = kp.octave;
+      ok = true;
+      if (bCheckLevels) {
+        if (kp.octave < q.min_level) ok = false;
+        if (q.max_level >= 0 && kp.octave > q.max_level) ok = false;
+      }
+      const float distx = kp.x - x, disty = kp.y - y;
+      if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+      if (ok && ur) {
+        const float u = ur[idx];
+        if (u > 0) {
+          const float er = fabsf(q.u_r - u);
+          if (er > r) ok = false;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      uint4 d0, d1;
+      load_desc(desc + (size_t)idx * 32, d0, d1);
+      const int rank = rank0 + __popcll(m & ((1ull << lane) - 1ull));
+      fn(rank, idx, hamming256(q0, q1, d0, d1), oct);
+    }
+    rank0 += __popcll(m);
   }
   return rank0;
 }
@@ -282,9 +297,8 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, Quer
   if (q.valid) {
     uint4 q0, q1;
     load_desc4(qp->desc, q0, q1);
-    const orbfe_keypoint* keys_oct = F.keys + (size_t)f * F.cap;
-    total = enumerate_window(F, f, q, q0, q1, [&](int rank, int idx, int dist) {
-      if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist | (keys_oct[idx].octave << 16); }
+    total = enumerate_window(F, f, q, q0, q1, [&](int rank, int idx, int dist, int oct) {
+      if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist | (oct << 16); }
     });
   }
   if ((threadIdx.x & 63) == 0) n_cand[(size_t)f * Q.cap + qi] = total;
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
         load_desc4(qp->desc, d0, d1);
         unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
         int i1 = -1, i2 = -1;
-        enumerate_window(F, f, q, d0, d1, [&](int rank, int idx, int dist) {
+        enumerate_window(F, f, q, d0, d1, [&](int rank, int idx, int dist, int) {
           if (blocked[idx]) return;
           const unsigned key = ((unsigned)dist << 16) | (unsigned)min(rank, 0xffff);
           if (key < k1) { k2 = k1; i2 = i1; k1 = key; i1 = idx; }
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameBatch F, QueryBat
     if (total == 0) continue;
     unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
     int i1b = -1;
-    auto consider = [&](int rank, int idx, int dist) {
+    auto consider = [&](int rank, int idx, int dist, int = 0) {
       if (matchedDist[idx] <= dist) return;
       const unsigned key = ((unsigned)dist << 16) | (unsigned)min(rank, 0xffff);
       if (key < k1) { k2 = k1; k1 = key; i1b = idx; }
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameBatch F, QueryBat
     };
     if (total <= max_cand) {
       const orbfe_cand* cl = cand + (size_t)i1 * max_cand;
-      for (int c = lane; c < total; c += WAVE) consider(c, cl[c].idx, cl[c].dist & 0xffff);
+      for (int c = lane; c < total; c += WAVE) consider(c, cl[c].idx, cl[c].dist & 0xffff, 0);
     } else {
       const orbfe_query q = *qp;
       uint4 d0, d1;
