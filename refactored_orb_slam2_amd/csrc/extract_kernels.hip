@@ -373,8 +373,9 @@ struct OctNode {
 };
 
 size_t orbfe_octree_lds_bytes(int M, int lds_keys) {
-  // nodeA, nodeB (12 B), cnt4 (16 B), childpos (8 B: 4 x uint16), aux (4 B), aux2 (4 B), sortkey (8 B), sorted (8 B)
-  return (size_t)M * (12 + 12 + 16 + 8 + 4 + 4 + 8 + 8) + (size_t)lds_keys * 8 + 64 * 4 + ORBFE_MAX_INI * 8 + 256;
+  // nodeA, nodeB (12 B), cnt4 (16 B), childpos (8 B: 4 x uint16), aux (4 B), aux2 (4 B); the phase-2 sort buffers
+  // alias childpos (sort keys) and nodeB (sorted keys), which are dead while the sort runs
+  return (size_t)M * (12 + 12 + 16 + 8 + 4 + 4) + (size_t)lds_keys * 8 + 64 * 4 + ORBFE_MAX_INI * 8 + 256;
 }
 
 __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctParams P) {
@@ -386,13 +387,11 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 
   // carve dynamic LDS
   uint8_t* sp = smem;
-  unsigned long long* sortkey = reinterpret_cast<unsigned long long*>(sp); sp += (size_t)M * 8;
-  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(sp);  sp += (size_t)M * 8;
   unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(sp);   sp += (size_t)P.lds_keys * 8;
-  OctNode* nodeA = reinterpret_cast<OctNode*>(sp); sp += (size_t)M * 12;
+  uint16_t* childpos = reinterpret_cast<uint16_t*>(sp); sp += (size_t)M * 8;
+  OctNode* nodeA = reinterpret_cast<OctNode*>(sp); sp += (size_t)M * 12;   // M is a multiple of 64: 8-byte aligned
   OctNode* nodeB = reinterpret_cast<OctNode*>(sp); sp += (size_t)M * 12;
   int* cnt4 = reinterpret_cast<int*>(sp);          sp += (size_t)M * 16;
-  uint16_t* childpos = reinterpret_cast<uint16_t*>(sp); sp += (size_t)M * 8;
   int* aux = reinterpret_cast<int*>(sp);           sp += (size_t)M * 4;   // childbase / flags
   int* aux2 = reinterpret_cast<int*>(sp);          sp += (size_t)M * 4;   // staypos
   int* ini_cnt = reinterpret_cast<int*>(sp);       sp += ORBFE_MAX_INI * 4;
@@ -514,6 +513,8 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       // phase 2 (:651-707): expandable leaves sorted by (size, address) ascending, walked from the back:
       // larger first, among equal sizes the later-created (= smaller list position) first; stop as soon as
       // the list holds >= N nodes.
+      unsigned long long* sortkey = reinterpret_cast<unsigned long long*>(childpos);  // dead until the rebuild below
+      unsigned long long* sorted = reinterpret_cast<unsigned long long*>(nodeB);      // previous generation: dead
       int nE = 0;
       for (int base = 0; base < size; base += 256) {
         const int p = base + tid;

@@ -278,10 +278,11 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     orbfe_set_error("nFeatures too large for the octree node table (%d nodes)", e->max_nodes);
     return ORBFE_ERR_INVALID;
   }
-  // LDS budget: node tables + as many keys as fit in 64 KiB (more keys spill to HBM, same results)
+  // LDS budget: node tables + as many keys as fit in 40 KiB, so that four workgroups share a CU (a 128-image batch =
+  // 1024 workgroups is then resident at once); levels with more candidates spill their keys to HBM, same results
   {
     const size_t fixed = orbfe_octree_lds_bytes(e->max_nodes, 0);
-    const size_t budget = 64 * 1024;
+    const size_t budget = 40 * 1024;
     e->lds_keys = fixed + 8 * 512 <= budget ? (int)((budget - fixed) / 8) : 512;
     e->oct_lds = orbfe_octree_lds_bytes(e->max_nodes, e->lds_keys);
     if (e->oct_lds > 160 * 1024) {
