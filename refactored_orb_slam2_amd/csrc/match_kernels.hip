@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void stereo_bucket_kernel(StereoParams P) {
   const int nb = P.n_buckets;
   const orbfe_keypoint* kr = P.kpsR + (size_t)pair * P.cap;
   int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
-  int32_t* bi = P.bucket_idx + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
+  int4* bi = reinterpret_cast<int4*>(P.bucket_idx) + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
   for (int b = tid; b < nb; b += 256) cnt[b] = 0;
   __syncthreads();
   for (int pass = 0; pass < 2; pass++) {
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void stereo_bucket_kernel(StereoParams P) {
       if (b1 - b0 >= STEREO_BUCKET_SPAN) b1 = b0 + STEREO_BUCKET_SPAN - 1;  // cannot happen for scale <= 12
       for (int b = b0; b <= b1; b++) {
         const int pos = atomicAdd(&cnt[b], 1);
-        if (pass == 1) bi[start[b] + pos] = iR;
+        if (pass == 1) bi[start[b] + pos] = make_int4(iR, __float_as_int(kp.x), __float_as_int(kp.y), kp.octave);
       }
     }
     __syncthreads();
@@ -828,14 +828,16 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   float* out_ur = P.u_right + (size_t)pair * P.cap;
   float* out_depth = P.depth + (size_t)pair * P.cap;
   int32_t* out_sad = P.sad + (size_t)pair * P.cap;
-  const int nL = P.nL[pair];
-  if (lane == 0) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
-  if (iL >= nL) return;
   const orbfe_keypoint* kl = P.kpsL + (size_t)pair * P.cap;
-  const orbfe_keypoint* kr = P.kpsR + (size_t)pair * P.cap;
   const uint8_t* dl = P.descL + (size_t)pair * P.cap * 32;
   const uint8_t* dr = P.descR + (size_t)pair * P.cap * 32;
+  // first round trip: count, left keypoint record and left descriptor together (slot iL < cap is always readable)
+  const int nL = P.nL[pair];
   const orbfe_keypoint kpL = kl[iL];
+  uint4 a0, a1;
+  load_desc(dl + (size_t)iL * 32, a0, a1);
+  if (lane == 0) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
+  if (iL >= nL) return;
   // every lane read the same record: tell the compiler, so that the per-level parameters become scalar loads
   const int levelL = __builtin_amdgcn_readfirstlane(kpL.octave);
   const float vL = kpL.y, uL = kpL.x;
@@ -845,59 +847,58 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const float minD = 0, maxD = P.maxD;
   const float minU = uL - maxD, maxU = uL - minD;
   if (maxU < 0) return;
-  uint4 a0, a1;
-  load_desc(dl + (size_t)iL * 32, a0, a1);
   unsigned best = ((unsigned)ORBFE_TH_HIGH << 16) | 0xffffu;  // bestDist starts at TH_HIGH; strict <
+  float best_x = 0.f;                                         // x of this lane's best candidate
   const int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
-  const int32_t* bidx = P.bucket_idx + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
+  const int4* bent = reinterpret_cast<const int4*>(P.bucket_idx) + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
   const int e0 = bs[row >> 3], e1 = bs[(row >> 3) + 1];
-  // two 64-entry chunks of the bucket in flight: indices, then keypoint records, then (for the survivors of the
-  // band / level / disparity tests) descriptors -- three memory round trips for up to 128 candidates
+  // two 64-entry chunks of the bucket in flight: bucket records (index, x, y, octave), then -- for the survivors of
+  // the band / level / disparity tests -- descriptors: two memory round trips for up to 128 candidates
   for (int eb = e0; eb < e1; eb += 2 * WAVE) {
-    int iR[2];
-    orbfe_keypoint kpR[2];
+    int4 rec[2];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int e = eb + u * WAVE + lane;
-      iR[u] = e < e1 ? bidx[e] : -1;
+      rec[u] = e < e1 ? bent[e] : make_int4(-1, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      if (iR[u] >= 0) kpR[u] = kr[iR[u]];
-      else { kpR[u].x = 0; kpR[u].y = 0; kpR[u].octave = 0; }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float r = s_r[kpR[u].octave & (ORBFE_MAX_LEVELS - 1)];
-      const int maxr = (int)ceilf(kpR[u].y + r), minr = (int)floorf(kpR[u].y - r);
-      ok[u] = iR[u] >= 0 && !(row < minr || row > maxr) && !(kpR[u].octave < levelL - 1 || kpR[u].octave > levelL + 1) &&
-              (kpR[u].x >= minU && kpR[u].x <= maxU);
+      const float rx = __int_as_float(rec[u].y), ry = __int_as_float(rec[u].z);
+      const int roct = rec[u].w;
+      const float r = s_r[roct & (ORBFE_MAX_LEVELS - 1)];
+      const int maxr = (int)ceilf(ry + r), minr = (int)floorf(ry - r);
+      ok[u] = rec[u].x >= 0 && !(row < minr || row > maxr) && !(roct < levelL - 1 || roct > levelL + 1) &&
+              (rx >= minU && rx <= maxU);
     }
     uint4 b0[2], b1[2];
 #pragma unroll
     for (int u = 0; u < 2; u++)
-      if (ok[u]) load_desc(dr + (size_t)iR[u] * 32, b0[u], b1[u]);
+      if (ok[u]) load_desc(dr + (size_t)rec[u].x * 32, b0[u], b1[u]);
 #pragma unroll
     for (int u = 0; u < 2; u++)
       if (ok[u]) {
-        const unsigned key = ((unsigned)hamming256(a0, a1, b0[u], b1[u]) << 16) | (unsigned)iR[u];
-        if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) best = key;  // (dist, index) minimum among dist < TH_HIGH
+        const unsigned key = ((unsigned)hamming256(a0, a1, b0[u], b1[u]) << 16) | (unsigned)rec[u].x;
+        if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) {  // (dist, index) minimum among dist < TH_HIGH
+          best = key;
+          best_x = __int_as_float(rec[u].y);
+        }
       }
   }
-  // first minimum in index order
+  // first minimum in index order; the winning lane also holds the right keypoint's x
+  float uR0;
   {
-    unsigned k = ((best >> 16) < (unsigned)ORBFE_TH_HIGH) ? best : 0xFFFFFFFFu;
+    const unsigned k = ((best >> 16) < (unsigned)ORBFE_TH_HIGH) ? best : 0xFFFFFFFFu;
     best = wave_min_u32(k);
+    if (best == 0xFFFFFFFFu) return;
+    const unsigned long long wm = __ballot(k == best);
+    uR0 = __shfl(best_x, __ffsll((long long)wm) - 1, WAVE);
   }
-  if (best == 0xFFFFFFFFu) return;
   const int bestDist = (int)(best >> 16);
-  const int bestIdxR = (int)(best & 0xffff);
   const int thOrbDist = (ORBFE_TH_HIGH + ORBFE_TH_LOW) / 2;
   if (!(bestDist < thOrbDist)) return;
 
   // sub-pixel refinement by 11x11 SAD over 11 shifts (L/src/Frame.cc:557-631)
-  const float uR0 = kr[bestIdxR].x;
   const float sfac = P.inv_scale[levelL];
   const float scaleduL = roundf(kpL.x * sfac);
   const float scaledvL = roundf(kpL.y * sfac);

@@ -507,7 +507,7 @@ extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left
     }
   if ((rc = mb_alloc(m->sad, sizeof(int32_t) * (size_t)n_pairs * cap))) return rc;
   if ((rc = mb_alloc(m->bucket_start, sizeof(int32_t) * (size_t)n_pairs * (STEREO_MAX_BUCKETS + 1)))) return rc;
-  if ((rc = mb_alloc(m->bucket_idx, sizeof(int32_t) * (size_t)n_pairs * cap * STEREO_BUCKET_SPAN))) return rc;
+  if ((rc = mb_alloc(m->bucket_idx, 16 * (size_t)n_pairs * cap * STEREO_BUCKET_SPAN))) return rc;  // int4 records
   p.bucket_start = (int32_t*)m->bucket_start.p;
   p.bucket_idx = (int32_t*)m->bucket_idx.p;
   p.n_buckets = (p.pyrL.h[0] + 7) / 8;
