@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
 }
 
 // ------------------------------------------------------------------------------------------------ describe
-__device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {ORB_PATTERN_INT8_1024};
+// the same pattern as floats, one (x0, y0, x1, y1) record per test pair (filled at start-up by the host)
+__device__ __attribute__((aligned(16))) float g_pattern_f[1024];
 // umax of ORBextractor's constructor for HALF_PATCH_SIZE 15 (L/src/ORBextractor.cc:449-463)
 __device__ constexpr int UMAX[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
@@ -873,9 +874,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
     }
   }
   // the four pattern entries of this lane (rounds 0..3): issued early, consumed after the orientation
-  int pk[4];
+  float4 pk[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const int*>(&g_pattern[(r * 64 + lane) * 4]);
+  for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
   if (slot == 0 && lane == 0) {
     int tot = 0;
 #pragma unroll
@@ -947,15 +948,13 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const int vlim = (lane & 31) < 31 ? UMAX[u < 0 ? -u : u] : -1;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
+    // branch-free: lanes outside the disc read a (valid) LDS byte and discard it.  Row 16 (lanes 32-63, i = 15) and
+    // column 16 (lane & 31 == 31) fall inside the wave's own LDS slice.
     const int v = -15 + 2 * i + (lane >> 5);
-    {
-      const int av = v < 0 ? -v : v;
-      if (av <= vlim) {
-        const int val = center[v * ORI_PITCH + u];
-        m10 += u * val;
-        m01 += v * val;
-      }
-    }
+    const int av = v < 0 ? -v : v;
+    const int val = av <= vlim ? (int)center[v * ORI_PITCH + u] : 0;
+    m10 += u * val;
+    m01 += v * val;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -973,8 +972,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const float x0 = (float)(int8_t)(pk[r] & 0xff), y0 = (float)(int8_t)((pk[r] >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((pk[r] >> 16) & 0xff), y1 = (float)(int8_t)((pk[r] >> 24) & 0xff);
+    const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
     const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
     const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
     const int t0 = bc[ry0 * DSC_PITCH + rx0];
@@ -1050,6 +1048,13 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
   dim3 block(256), grid((p.kp_per_image + 3) / 4 > 0 ? (p.kp_per_image + 3) / 4 : 1, n_images);
   hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, p);
+}
+
+int orbfe_upload_pattern_floats() {
+  static const int8_t pat[1024] = {ORB_PATTERN_INT8_1024};
+  float f[1024];
+  for (int i = 0; i < 1024; i++) f[i] = (float)pat[i];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pattern_f), f, sizeof(f));
 }
 
 int orbfe_set_octree_lds(size_t lds_bytes) {

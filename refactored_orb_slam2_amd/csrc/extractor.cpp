@@ -23,6 +23,7 @@
 void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
                         int h, int n_images, hipStream_t s);
 int orbfe_set_octree_lds(size_t lds_bytes);
+int orbfe_upload_pattern_floats();
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -552,6 +553,14 @@ extern "C" int orbfe_extractor_create(const orbfe_params* p, int device, orbfe_e
     return ORBFE_ERR_HIP;
   }
   if (const char* ev = getenv("ORBFE_OVERLAP_BLUR")) e->overlap_blur = atoi(ev) != 0;  // experiment knob
+  {  // per-device constant: the sampling pattern as floats (the device symbol lives once per device / code object)
+    const int prc = orbfe_upload_pattern_floats();
+    if (prc != 0) {
+      orbfe_set_error("uploading the BRIEF pattern failed: %d", prc);
+      orbfe_extractor_destroy(e);
+      return ORBFE_ERR_HIP;
+    }
+  }
   *out = e;
   return ORBFE_OK;
 }
