@@ -217,6 +217,15 @@ int orbfe_search_by_projection_points(const orbfe_frame_view* frame, const orbfe
 int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_query* q, int nq,
                                      int check_orientation, uint8_t* blocked, int32_t* assigned, int* n_matches);
 
+/* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+ * (L/src/ORBmatcher.cc:1385-1504), used by Tracking::Relocalization.  One query per keyframe map point that is not
+ * bad and not in sAlreadyFound and that passes the projection / distance checks (:1408-1434): u, v, radius,
+ * min_level = nPredictedLevel-1, max_level = nPredictedLevel+1, angle = pKF->mvKeysUn[i].angle, desc, valid = 1,
+ * blocks = 1.  blocked[i2] on entry = CurrentFrame.mvpMapPoints[i2] != NULL (:1453).  No stereo gate (u_right of the
+ * view is ignored); a match needs bestDist <= max_dist (:1466).  Outputs as orbfe_search_by_projection_frame. */
+int orbfe_search_by_projection_keyframe(const orbfe_frame_view* cur, const orbfe_query* q, int nq, int check_orientation,
+                                        int max_dist, uint8_t* blocked, int32_t* assigned, int* n_matches);
+
 /* SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), entirely on the device.
  * A DBoW2::FeatureVector is passed as its nodes sorted by id, each {node_id, start, count} into an index array
  * (nodesA/idxA = pKF->mFeatVec, nodesB/idxB = F.mFeatVec).  validA[i] != 0 <=> keyframe feature i has a map point
@@ -228,6 +237,15 @@ int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t
                         const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
                         const float* angleB, int nB, const orbfe_featvec_node* nodesB, int n_nodesB,
                         const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchB, int* n_matches);
+
+/* SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (L/src/ORBmatcher.cc:494-612): both sides carry a validity mask
+ * (map point present and not bad), the acceptance is bestDist < TH_LOW (strict), and the result is per feature of the
+ * first keyframe: matchA[i] = index in the second keyframe (the caller stores vpMapPoints2[matchA[i]]) or -1. */
+int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                           const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
+                           const float* angleB, const uint8_t* validB, int nB, const orbfe_featvec_node* nodesB,
+                           int n_nodesB, const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA,
+                           int* n_matches);
 
 /* SearchForInitialization (L/src/ORBmatcher.cc:388-492), the monocular map-initialisation matcher: level-0
  * keypoints of F1 are searched in a window of `window_size` pixels around prev_matched_xy[2*i..2*i+1] in F2; a

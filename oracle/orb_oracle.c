@@ -952,6 +952,42 @@ int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq
   return nmatches;
 }
 
+/* SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist): L/src/ORBmatcher.cc:1439-1501 */
+int oo_search_by_projection_keyframe(const oo_frame* cur, const oo_query* q, int nq, int check_orientation, int orb_dist,
+                                     uint8_t* mappoint_set, int32_t* assigned) {
+  int nmatches = 0;
+  rot_hist rh; memset(&rh, 0, sizeof(rh));
+  int32_t* vIndices2 = (int32_t*)malloc(sizeof(int32_t) * (cur->n ? cur->n : 1));
+  for (int i = 0; i < nq; i++) {
+    if (!q[i].valid) continue;
+    const int nI = oo_features_in_area(cur, q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level, vIndices2);
+    if (nI == 0) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int k = 0; k < nI; k++) {
+      const int i2 = vIndices2[k];
+      if (mappoint_set[i2]) continue;                         /* :1453 */
+      const int dist = oo_descriptor_distance(q[i].desc, cur->desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= orb_dist) {                               /* :1466 */
+      mappoint_set[bestIdx2] = 1;
+      assigned[bestIdx2] = i;
+      nmatches++;
+      if (check_orientation) rh_push(&rh, rot_bin(q[i].angle, cur->keys_un[bestIdx2].angle), bestIdx2);
+    }
+  }
+  if (check_orientation) {
+    int i1, i2, i3;
+    oo_three_maxima(rh.n, OO_HISTO_LENGTH, &i1, &i2, &i3);
+    for (int i = 0; i < OO_HISTO_LENGTH; i++)
+      if (i != i1 && i != i2 && i != i3)
+        for (int j = 0; j < rh.n[i]; j++) { assigned[rh.v[i][j]] = -1; nmatches--; }
+  }
+  rh_free(&rh);
+  free(vIndices2);
+  return nmatches;
+}
+
 static int featvec_lower_bound(const oo_featvec_node* nodes, int n, int key) {
   int lo = 0, hi = n;
   while (lo < hi) { int mid = (lo + hi) / 2; if (nodes[mid].node_id < key) lo = mid + 1; else hi = mid; }
@@ -1005,6 +1041,59 @@ int oo_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* v
     }
   }
   rh_free(&rh);
+  return nmatches;
+}
+
+/* SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&): L/src/ORBmatcher.cc:494-612 */
+int oo_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                        const oo_featvec_node* nodesA, int nA_nodes, const int32_t* idxA, const uint8_t* descB,
+                        const float* angleB, const uint8_t* validB, int nB, const oo_featvec_node* nodesB, int nB_nodes,
+                        const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA) {
+  int nmatches = 0;
+  rot_hist rh; memset(&rh, 0, sizeof(rh));
+  uint8_t* vbMatched2 = (uint8_t*)calloc(nB ? nB : 1, 1);
+  for (int i = 0; i < nA; i++) matchA[i] = -1;
+  int ia = 0, ib = 0;
+  while (ia < nA_nodes && ib < nB_nodes) {
+    if (nodesA[ia].node_id == nodesB[ib].node_id) {
+      for (int i1 = 0; i1 < nodesA[ia].count; i1++) {
+        const int idx1 = idxA[nodesA[ia].start + i1];
+        if (!validA[idx1]) continue;
+        const uint8_t* d1 = descA + (size_t)idx1 * 32;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int i2 = 0; i2 < nodesB[ib].count; i2++) {
+          const int idx2 = idxB[nodesB[ib].start + i2];
+          if (vbMatched2[idx2] || !validB[idx2]) continue;
+          const int dist = oo_descriptor_distance(d1, descB + (size_t)idx2 * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < OO_TH_LOW) {
+          if ((float)bestDist1 < nnratio * (float)bestDist2) {
+            matchA[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = 1;
+            if (check_orientation) rh_push(&rh, rot_bin(angleA[idx1], angleB[bestIdx2]), idx1);
+            nmatches++;
+          }
+        }
+      }
+      ia++; ib++;
+    } else if (nodesA[ia].node_id < nodesB[ib].node_id) {
+      ia = featvec_lower_bound(nodesA, nA_nodes, nodesB[ib].node_id);
+    } else {
+      ib = featvec_lower_bound(nodesB, nB_nodes, nodesA[ia].node_id);
+    }
+  }
+  if (check_orientation) {
+    int i1, i2, i3;
+    oo_three_maxima(rh.n, OO_HISTO_LENGTH, &i1, &i2, &i3);
+    for (int i = 0; i < OO_HISTO_LENGTH; i++) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int j = 0; j < rh.n[i]; j++) { matchA[rh.v[i][j]] = -1; nmatches--; }
+    }
+  }
+  rh_free(&rh);
+  free(vbMatched2);
   return nmatches;
 }
 

@@ -144,6 +144,11 @@ int oo_search_by_projection_points(const oo_frame* f, const oo_query* q, int nq,
  * argmin, TH_HIGH, rotation histogram).  Queries carry the projection.  Returns nmatches. */
 int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq, int check_orientation,
                                   uint8_t* blocked, int32_t* assigned);
+/* SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist): ORBmatcher.cc:1385-1504 from the window
+ * query onwards (q[i] = one keyframe map point that passed :1403-1434).  mappoint_set[i2] != 0 <=> the current frame's
+ * mvpMapPoints[i2] is non-NULL; assigned[i2] = query index.  Returns nmatches. */
+int oo_search_by_projection_keyframe(const oo_frame* cur, const oo_query* q, int nq, int check_orientation, int orb_dist,
+                                     uint8_t* mappoint_set, int32_t* assigned);
 /* SearchByBoW(KeyFrame*, Frame&, ...): ORBmatcher.cc:161-273 with feature vectors as sorted node lists.
  * nodeA/nodeB: n_nodes entries {node_id, start, count} into idxA/idxB.  validA[i]!=0 <=> KF feature i has
  * a good map point.  matchB[j] = KF index matched to frame feature j, or -1.  Returns nmatches. */
@@ -152,6 +157,12 @@ int oo_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* v
                      const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
                      const float* angleB, int nB, const oo_featvec_node* nodesB, int n_nodesB,
                      const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchB);
+/* SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&): ORBmatcher.cc:494-612.  validA/validB: the keyframe feature has
+ * a map point that is not bad.  matchA[i] = index in B matched to feature i of A, or -1.  Returns nmatches. */
+int oo_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                        const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
+                        const float* angleB, const uint8_t* validB, int nB, const oo_featvec_node* nodesB, int n_nodesB,
+                        const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA);
 /* SearchForInitialization: ORBmatcher.cc:388-492 */
 int oo_search_for_initialization(const oo_keypoint* keys1, const uint8_t* desc1, int n1, const oo_frame* f2,
                                  float* prev_matched_xy, int window, float nnratio, int check_orientation,

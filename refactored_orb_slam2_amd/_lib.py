@@ -59,7 +59,7 @@ EXPORTS = [
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
-    "orbfe_search_for_initialization", "orbfe_search_by_bow",
+    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_by_projection_keyframe",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow",
 ]
@@ -131,12 +131,14 @@ def lib():
     L.orbfe_proj_candidates.argtypes = [C.POINTER(FrameView), vp, ci, vp, vp, ci]
     L.orbfe_search_by_projection_points.argtypes = [C.POINTER(FrameView), vp, ci, cf, vp, vp, pi]
     L.orbfe_search_by_projection_frame.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, pi]
+    L.orbfe_search_by_projection_keyframe.argtypes = [C.POINTER(FrameView), vp, ci, ci, ci, vp, vp, pi]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_destroy.argtypes = [vp]
     L.orbfe_vocabulary_info.argtypes = [vp, pi, pi, pi, pi]
     L.orbfe_bow_transform_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.orbfe_compute_bow.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, pi, vp, vp, pi]
+    L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_for_initialization.argtypes = [C.POINTER(FrameView), C.POINTER(FrameView), vp, ci, cf, ci, vp, pi]
     L.orbfe_stereo_match_device.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]

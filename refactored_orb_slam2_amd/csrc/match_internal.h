@@ -65,6 +65,9 @@ struct BowParams {
   const uint8_t* descB; const float* angleB; const int32_t* idxB;
   float nnratio; int check_ori;
   int sequential, n_pairs;  // sequential != 0: a frame feature occurs under more than one node
+  int kf_mode;              // SearchByBoW(KF,KF): validB mask, strict TH_LOW, result per A feature
+  const uint8_t* validB;
+  int32_t* matchA;          // [nA], pre-set to -1 (kf_mode)
   int32_t* matchB;      // [nB], pre-set to -1
   int32_t* counters;    // [0] pushes, [1] nmatches, [2..31] rotation histogram
   int32_t* push_idx; uint8_t* push_bin;
@@ -76,8 +79,9 @@ void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s);
 void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
                                   int max_cand, int n_frames, hipStream_t s);
 void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
-                               int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
-                               int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s);
+                               int max_cand, int mode, int th_high, float nnratio, int check_ori, uint8_t* blocked,
+                               int32_t* assigned, int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames,
+                               hipStream_t s);
 void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
                                int max_cand, float nnratio, int check_ori, int32_t* matches12, float* prev_xy,
                                int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, hipStream_t s);

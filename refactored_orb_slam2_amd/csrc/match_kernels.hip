@@ -326,11 +326,12 @@ __device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& in
 // conflicts are rare.  A query whose candidate list was truncated (> max_cand) ends the chunk and is handled
 // alone by wave 0, which re-enumerates its window.
 // mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)   -- best/second with the same-level ratio test
-// mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, TH_HIGH, rotation histogram
+// mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, th_high = TH_HIGH, rotation histogram;
+//         SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist) is the same walk with th_high = ORBdist (:1385-1504)
 #define RC_THREADS 1024
 #define RC_LIST_CAP 16384  // staged candidate entries per chunk (64 KiB)
 __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
-                                                           const int32_t* __restrict__ n_cand, int max_cand, int mode,
+                                                           const int32_t* __restrict__ n_cand, int max_cand, int mode, int th_high,
                                                            float nnratio, int check_ori, uint8_t* __restrict__ blocked_all,
                                                            int32_t* __restrict__ assigned_all, int32_t* __restrict__ n_matches,
                                                            int32_t* __restrict__ push_idx_all, uint8_t* __restrict__ push_bin_all) {
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
               bestLevel2 = keys[__shfl(mine_i, sl, WAVE)].octave;
             }
             const int bestLevel = keys[bestIdx].octave;
-            if (bestDist <= ORBFE_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2))
+            if (bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2))
               accept = true;
           } else {
-            accept = bestDist <= ORBFE_TH_HIGH;
+            accept = bestDist <= th_high;
           }
           if (accept && lane == 0) {
             assigned[bestIdx] = q0;
@@ -507,9 +508,9 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
         if (has) {
           if (mode == 0) {
             const int bestLevel = (int)((e1 >> 16) & 0xf), bestLevel2 = has2 ? (int)((e2 >> 16) & 0xf) : -1;
-            accept = bestDist <= ORBFE_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+            accept = bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
           } else {
-            accept = bestDist <= ORBFE_TH_HIGH;
+            accept = bestDist <= th_high;
           }
         }
       }
@@ -593,7 +594,8 @@ __global__ __launch_bounds__(64) void bow_match_kernel(BowParams P) {
   const BowPair pr = P.pairs[pi];
   __syncthreads();
   for (int i = lane; i < pr.countB; i += WAVE)
-    taken[i] = P.sequential ? (uint8_t)(__hip_atomic_load(&P.matchB[P.idxB[pr.startB + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) : 0;
+    taken[i] = (uint8_t)((P.sequential && __hip_atomic_load(&P.matchB[P.idxB[pr.startB + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) ||
+                         (P.validB && !P.validB[P.idxB[pr.startB + i]]));  // KF-KF: pMP2 missing or bad (:543-549)
   __syncthreads();
   for (int iKF = 0; iKF < pr.countA; iKF++) {
     const int realIdxKF = P.idxA[pr.startA + iKF];
@@ -619,10 +621,12 @@ __global__ __launch_bounds__(64) void bow_match_kernel(BowParams P) {
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) s2 = min(s2, __shfl_xor(s2, d, WAVE));
       const int bestDist1 = (int)(b >> 16), bestF = (int)(b & 0xffff);
-      if (bestDist1 <= ORBFE_TH_LOW && (float)bestDist1 < P.nnratio * (float)s2) {
+      // KF-Frame accepts bestDist <= TH_LOW (:224), KF-KF only bestDist < TH_LOW (:564)
+      if ((P.kf_mode ? bestDist1 < ORBFE_TH_LOW : bestDist1 <= ORBFE_TH_LOW) && (float)bestDist1 < P.nnratio * (float)s2) {
         if (lane == 0) {
           const int realIdxF = P.idxB[pr.startB + bestF];
           __hip_atomic_store(&P.matchB[realIdxF], realIdxKF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (P.kf_mode) P.matchA[realIdxKF] = realIdxF;
           taken[bestF] = 1;
           if (P.sequential)  // the same feature may be listed again inside this node
             for (int t = 0; t < pr.countB; t++)
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(64) void bow_match_kernel(BowParams P) {
             int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
             if (bin == ORBFE_HISTO_LENGTH) bin = 0;
             const int pos = atomicAdd(&P.counters[0], 1);
-            P.push_idx[pos] = realIdxF;
+            P.push_idx[pos] = P.kf_mode ? realIdxKF : realIdxF;  // rotHist holds idx1 in the KF-KF variant (:579)
             P.push_bin[pos] = (uint8_t)bin;
             atomicAdd(&P.counters[2 + bin], 1);
           }
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(BowParams P) {
     int r = 0;
     for (int k = threadIdx.x; k < np; k += 256) {
       const int bin = P.push_bin[k];
-      if (bin != top[0] && bin != top[1] && bin != top[2]) { P.matchB[P.push_idx[k]] = -1; r++; }
+      if (bin != top[0] && bin != top[1] && bin != top[2]) { (P.kf_mode ? P.matchA : P.matchB)[P.push_idx[k]] = -1; r++; }
     }
     if (r) atomicAdd(&removed, r);
   }
@@ -1042,8 +1046,9 @@ void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbf
   hipLaunchKernelGGL(proj_candidates_kernel, grid, dim3(256), 0, s, f, q, cand, n_cand, max_cand);
 }
 void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
-                               int max_cand, int mode, float nnratio, int check_ori, uint8_t* blocked, int32_t* assigned,
-                               int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames, hipStream_t s) {
+                               int max_cand, int mode, int th_high, float nnratio, int check_ori, uint8_t* blocked,
+                               int32_t* assigned, int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames,
+                               hipStream_t s) {
   const size_t dyn = (size_t)(((f.cap + 15) & ~15) + 8 * (size_t)f.cap);
   static size_t dyn_allowed = 0;  // this kernel's static LDS alone is ~69 KiB: always raise the limit
   if (dyn > dyn_allowed) {
@@ -1051,8 +1056,8 @@ void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const o
                               hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024);
     dyn_allowed = 88 * 1024;
   }
-  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, nnratio,
-                     check_ori, blocked, assigned, n_matches, push_idx, push_bin);
+  hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, th_high,
+                     nnratio, check_ori, blocked, assigned, n_matches, push_idx, push_bin);
 }
 void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream_t s) {
   if (n_pairs > 0)

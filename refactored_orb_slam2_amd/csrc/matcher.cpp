@@ -171,7 +171,7 @@ static int proj_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_
                         const int32_t* d_n, const float* d_ur, int cap, float min_x, float max_x, float min_y,
                         float max_y, const orbfe_query* d_q, const int32_t* d_nq, int q_cap, int mode, float nnratio,
                         int check_ori, uint8_t* d_blocked, int32_t* d_assigned, int32_t* d_nm, bool resolve,
-                        hipStream_t s) {
+                        hipStream_t s, int th_high = ORBFE_TH_HIGH) {
   if (cap > 9500) {  // blocked[] + two claim buffers (9 bytes per keypoint) live in LDS next to the 64 KiB staging area
     orbfe_set_error("frame capacity %d too large for the LDS-resident resolver state (cap <= 9500)", cap);
     return ORBFE_ERR_INVALID;
@@ -189,7 +189,7 @@ static int proj_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_
   orbfe_launch_proj_candidates(fb, qb, (orbfe_cand*)m->cand.p, (int32_t*)m->n_cand.p, ORBFE_MAX_CAND, n_frames, s);
   if (resolve)
     orbfe_launch_proj_resolve(fb, qb, (const orbfe_cand*)m->cand.p, (const int32_t*)m->n_cand.p, ORBFE_MAX_CAND, mode,
-                              nnratio, check_ori, d_blocked, d_assigned, d_nm, (int32_t*)m->push_idx.p,
+                              th_high, nnratio, check_ori, d_blocked, d_assigned, d_nm, (int32_t*)m->push_idx.p,
                               (uint8_t*)m->push_bin.p, n_frames, s);
   return launch_ok();
 }
@@ -288,7 +288,8 @@ extern "C" int orbfe_proj_candidates(const orbfe_frame_view* f, const orbfe_quer
 }
 
 static int search_host(const orbfe_frame_view* f, const orbfe_query* q, int nq, int mode, float nnratio, int check_ori,
-                       uint8_t* blocked, int32_t* assigned, int* n_matches) {
+                       uint8_t* blocked, int32_t* assigned, int* n_matches, int th_high = ORBFE_TH_HIGH,
+                       bool stereo_gate = true) {
   if (!frame_ok(f) || nq < 0 || (nq > 0 && !q) || !blocked || !assigned || !n_matches) return ORBFE_ERR_INVALID;
   *n_matches = 0;
   if (nq == 0 || f->n == 0) return ORBFE_OK;
@@ -302,9 +303,9 @@ static int search_host(const orbfe_frame_view* f, const orbfe_query* q, int nq, 
   HIPCHK(hipMemcpyAsync(m->h_blocked.p, blocked, f->n, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(m->h_assigned.p, assigned, sizeof(int32_t) * f->n, hipMemcpyHostToDevice, s));
   rc = proj_enqueue(m, 1, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
-                    f->u_right ? (const float*)m->h_ur.p : nullptr, f->n, f->min_x, f->max_x, f->min_y, f->max_y,
-                    (const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, nq, mode, nnratio, check_ori,
-                    (uint8_t*)m->h_blocked.p, (int32_t*)m->h_assigned.p, (int32_t*)m->h_nm.p, true, s);
+                    (f->u_right && stereo_gate) ? (const float*)m->h_ur.p : nullptr, f->n, f->min_x, f->max_x, f->min_y,
+                    f->max_y, (const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, nq, mode, nnratio, check_ori,
+                    (uint8_t*)m->h_blocked.p, (int32_t*)m->h_assigned.p, (int32_t*)m->h_nm.p, true, s, th_high);
   if (rc) return rc;
   int32_t nm = 0;
   HIPCHK(hipMemcpyAsync(blocked, m->h_blocked.p, f->n, hipMemcpyDeviceToHost, s));
@@ -325,15 +326,26 @@ extern "C" int orbfe_search_by_projection_frame(const orbfe_frame_view* f, const
   return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches);
 }
 
+// SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) (L/src/ORBmatcher.cc:1385-1504): the
+// frame-to-frame walk without the stereo gate and with the caller's distance bound
+extern "C" int orbfe_search_by_projection_keyframe(const orbfe_frame_view* f, const orbfe_query* q, int nq,
+                                                   int check_orientation, int max_dist, uint8_t* blocked,
+                                                   int32_t* assigned, int* n_matches) {
+  if (max_dist < 0 || max_dist > 255) return ORBFE_ERR_INVALID;
+  return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches, max_dist, false);
+}
+
 // SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), host pointers, synchronous
-extern "C" int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
-                                   const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA,
-                                   const uint8_t* descB, const float* angleB, int nB, const orbfe_featvec_node* nodesB,
-                                   int n_nodesB, const int32_t* idxB, float nnratio, int check_orientation,
-                                   int32_t* matchB, int* n_matches) {
+static int bow_impl(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                    const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
+                    const float* angleB, const uint8_t* validB, int nB, const orbfe_featvec_node* nodesB, int n_nodesB,
+                    const int32_t* idxB, float nnratio, int check_orientation, int kf_mode, int32_t* matchA_out,
+                    int32_t* matchB, int* n_matches) {
   if (nA < 0 || nB < 0 || n_nodesA < 0 || n_nodesB < 0 || !n_matches || (nB > 0 && !matchB)) return ORBFE_ERR_INVALID;
   *n_matches = 0;
   for (int j = 0; j < nB; j++) matchB[j] = -1;
+  if (kf_mode)
+    for (int i = 0; i < nA; i++) matchA_out[i] = -1;
   if (nA == 0 || nB == 0 || n_nodesA == 0 || n_nodesB == 0) return ORBFE_OK;
   if (!descA || !angleA || !validA || !nodesA || !idxA || !descB || !angleB || !nodesB || !idxB) return ORBFE_ERR_INVALID;
   // merge-join of the two FeatureVectors on NodeId (:183-253; lower_bound jumps == plain two-pointer walk on sorted ids)
@@ -375,7 +387,7 @@ extern "C" int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, co
                o_aA = o_dB + al((size_t)nB * 32), o_aB = o_aA + al((size_t)nA * 4), o_iA = o_aB + al((size_t)nB * 4),
                o_iB = o_iA + al((size_t)totA * 4), o_vA = o_iB + al((size_t)totB * 4), o_mB = o_vA + al((size_t)nA),
                o_cnt = o_mB + al((size_t)nB * 4), o_pi = o_cnt + 256, o_pb = o_pi + al((size_t)nA * 4),
-               total = o_pb + al((size_t)nA);
+               o_vB = o_pb + al((size_t)nA), o_mA = o_vB + al((size_t)nB), total = o_mA + al((size_t)nA * 4);
   if ((rc = mb_alloc(m->h_q, total))) return rc;
   uint8_t* d = (uint8_t*)m->h_q.p;
   HIPCHK(hipMemcpyAsync(d + o_pairs, pairs.data(), pairs.size() * sizeof(BowPair), hipMemcpyHostToDevice, s));
@@ -388,22 +400,50 @@ extern "C" int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, co
   HIPCHK(hipMemcpyAsync(d + o_vA, validA, (size_t)nA, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(d + o_mB, 0xff, (size_t)nB * 4, s));
   HIPCHK(hipMemsetAsync(d + o_cnt, 0, 256, s));
+  if (kf_mode) {
+    HIPCHK(hipMemcpyAsync(d + o_vB, validB, (size_t)nB, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d + o_mA, 0xff, (size_t)nA * 4, s));
+  }
   BowParams p;
   p.pairs = (const BowPair*)(d + o_pairs);
   p.descA = d + o_dA; p.angleA = (const float*)(d + o_aA); p.validA = d + o_vA; p.idxA = (const int32_t*)(d + o_iA);
   p.descB = d + o_dB; p.angleB = (const float*)(d + o_aB); p.idxB = (const int32_t*)(d + o_iB);
   p.nnratio = nnratio; p.check_ori = check_orientation;
   p.sequential = sequential; p.n_pairs = (int)pairs.size();
+  p.kf_mode = kf_mode; p.validB = kf_mode ? d + o_vB : nullptr; p.matchA = (int32_t*)(d + o_mA);
   p.matchB = (int32_t*)(d + o_mB); p.counters = (int32_t*)(d + o_cnt);
   p.push_idx = (int32_t*)(d + o_pi); p.push_bin = d + o_pb;
   orbfe_launch_bow(p, (int)pairs.size(), maxB, s);
   if ((rc = launch_ok())) return rc;
   int32_t cnt[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(matchB, d + o_mB, (size_t)nB * 4, hipMemcpyDeviceToHost, s));
+  if (kf_mode) HIPCHK(hipMemcpyAsync(matchA_out, d + o_mA, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(cnt, d + o_cnt, 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   *n_matches = cnt[1];
   return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_bow(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                                   const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA,
+                                   const uint8_t* descB, const float* angleB, int nB, const orbfe_featvec_node* nodesB,
+                                   int n_nodesB, const int32_t* idxB, float nnratio, int check_orientation,
+                                   int32_t* matchB, int* n_matches) {
+  return bow_impl(descA, angleA, validA, nA, nodesA, n_nodesA, idxA, descB, angleB, nullptr, nB, nodesB, n_nodesB, idxB,
+                  nnratio, check_orientation, 0, nullptr, matchB, n_matches);
+}
+
+// SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (L/src/ORBmatcher.cc:494-612)
+extern "C" int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t* validA, int nA,
+                                      const orbfe_featvec_node* nodesA, int n_nodesA, const int32_t* idxA,
+                                      const uint8_t* descB, const float* angleB, const uint8_t* validB, int nB,
+                                      const orbfe_featvec_node* nodesB, int n_nodesB, const int32_t* idxB, float nnratio,
+                                      int check_orientation, int32_t* matchA, int* n_matches) {
+  if (!matchA && nA > 0) return ORBFE_ERR_INVALID;
+  if (nB > 0 && !validB) return ORBFE_ERR_INVALID;
+  std::vector<int32_t> matchB((size_t)std::max(nB, 1));
+  return bow_impl(descA, angleA, validA, nA, nodesA, n_nodesA, idxA, descB, angleB, validB, nB, nodesB, n_nodesB, idxB,
+                  nnratio, check_orientation, 1, matchA, matchB.data(), n_matches);
 }
 
 // SearchForInitialization (L/src/ORBmatcher.cc:388-492), host pointers, synchronous

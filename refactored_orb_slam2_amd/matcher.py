@@ -125,6 +125,18 @@ class ORBmatcher:
                    "orbfe_search_by_projection_frame")
         return nm.value, assigned, blocked
 
+    # ---- SearchByProjection(Frame& cur, KeyFrame* pKF, sAlreadyFound, th, ORBdist): ORBmatcher.cc:1385-1504
+    def SearchByProjectionKeyFrame(self, cur: FrameView, queries: np.ndarray, ORBdist: int, blocked=None):
+        """blocked[i2] = cur.mvpMapPoints[i2] is not None; queries carry blocks=1.  Returns (nmatches, assigned, blocked)."""
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        blocked = np.zeros(cur.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        assigned = np.full(cur.n, -1, np.int32)
+        nm = C.c_int(0)
+        _lib.check(self._L.orbfe_search_by_projection_keyframe(C.byref(cur.c), _lib.ptr(q), len(q), int(self.mbCheckOrientation),
+                                                               int(ORBdist), _lib.ptr(blocked), _lib.ptr(assigned), C.byref(nm)),
+                   "orbfe_search_by_projection_keyframe")
+        return nm.value, assigned, blocked
+
     # ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): ORBmatcher.cc:388-492
     def SearchForInitialization(self, f1: FrameView, f2: FrameView, prev_matched: np.ndarray, windowSize: int = 10):
         """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
@@ -153,6 +165,23 @@ class ORBmatcher:
             _lib.ptr(descB), _lib.ptr(angleB), len(descB), C.cast(nB, C.c_void_p), nnB, _lib.ptr(iB), self.mfNNratio,
             int(self.mbCheckOrientation), _lib.ptr(matchB), C.byref(nm)), "orbfe_search_by_bow")
         return nm.value, matchB
+
+
+def search_by_bow_kf(descA, angleA, validA, groupsA, descB, angleB, validB, groupsB, nnratio=0.8, check_orientation=True):
+    """SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:494-612) on the device.  Returns (nmatches, matchA)."""
+    L = _lib.lib()
+    descA = np.ascontiguousarray(descA, np.uint8).reshape(-1, 32); descB = np.ascontiguousarray(descB, np.uint8).reshape(-1, 32)
+    angleA = np.ascontiguousarray(angleA, np.float32); angleB = np.ascontiguousarray(angleB, np.float32)
+    validA = np.ascontiguousarray(validA, np.uint8); validB = np.ascontiguousarray(validB, np.uint8)
+    nA, nnA, iA = featvec_arrays(groupsA)
+    nB, nnB, iB = featvec_arrays(groupsB)
+    matchA = np.full(len(descA), -1, np.int32)
+    nm = C.c_int(0)
+    _lib.check(L.orbfe_search_by_bow_kf(_lib.ptr(descA), _lib.ptr(angleA), _lib.ptr(validA), len(descA), C.cast(nA, C.c_void_p), nnA,
+                                        _lib.ptr(iA), _lib.ptr(descB), _lib.ptr(angleB), _lib.ptr(validB), len(descB),
+                                        C.cast(nB, C.c_void_p), nnB, _lib.ptr(iB), float(np.float32(nnratio)), int(check_orientation),
+                                        _lib.ptr(matchA), C.byref(nm)), "orbfe_search_by_bow_kf")
+    return nm.value, matchA
 
 
 def featvec_arrays(groups: dict):

@@ -105,10 +105,14 @@ def lib():
     L.oo_features_in_area.argtypes = [C.POINTER(OOFrame), cf, cf, cf, ci, ci, vp]
     L.oo_search_by_projection_points.restype = ci
     L.oo_search_by_projection_points.argtypes = [C.POINTER(OOFrame), vp, ci, cf, vp, vp]
+    L.oo_search_by_projection_keyframe.restype = ci
+    L.oo_search_by_projection_keyframe.argtypes = [C.POINTER(OOFrame), vp, ci, ci, ci, vp, vp]
     L.oo_search_by_projection_frame.restype = ci
     L.oo_search_by_projection_frame.argtypes = [C.POINTER(OOFrame), vp, ci, ci, vp, vp]
     L.oo_search_by_bow.restype = ci
     L.oo_search_by_bow.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp]
+    L.oo_search_by_bow_kf.restype = ci
+    L.oo_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp]
     L.oo_search_for_initialization.restype = ci
     L.oo_search_for_initialization.argtypes = [vp, vp, ci, C.POINTER(OOFrame), vp, ci, cf, ci, vp]
     L.oo_three_maxima.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
@@ -306,6 +310,17 @@ class OracleFrame:
         return nm, assigned, blocked
 
 
+def _kf(self, queries, check_orientation=True, orb_dist=100, blocked=None):
+    q = np.ascontiguousarray(queries, QUERY_DTYPE)
+    blocked = np.zeros(self.f.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+    assigned = np.full(self.f.n, -1, np.int32)
+    nm = lib().oo_search_by_projection_keyframe(C.byref(self.f), _p(q), len(q), int(check_orientation), int(orb_dist), _p(blocked), _p(assigned))
+    return nm, assigned, blocked
+
+
+OracleFrame.search_by_projection_keyframe = _kf
+
+
 def search_for_initialization(keys1, desc1, frame2: "OracleFrame", prev_xy, window, nnratio, check_orientation=True):
     keys1 = np.ascontiguousarray(keys1, KP_DTYPE); desc1 = np.ascontiguousarray(desc1, np.uint8)
     prev = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2).copy()
@@ -337,6 +352,19 @@ def search_by_bow(descA, angleA, validA, groupsA, descB, angleB, groupsB, nnrati
                                 _p(descB), _p(angleB), len(descB), C.cast(nB, C.c_void_p), nnB, _p(iB),
                                 nnratio, int(check_orientation), _p(matchB))
     return nm, matchB
+
+
+def search_by_bow_kf(descA, angleA, validA, groupsA, descB, angleB, validB, groupsB, nnratio=0.8, check_orientation=True):
+    descA = np.ascontiguousarray(descA, np.uint8); descB = np.ascontiguousarray(descB, np.uint8)
+    angleA = np.ascontiguousarray(angleA, np.float32); angleB = np.ascontiguousarray(angleB, np.float32)
+    validA = np.ascontiguousarray(validA, np.uint8); validB = np.ascontiguousarray(validB, np.uint8)
+    nA, nnA, iA = featvec_arrays(groupsA)
+    nB, nnB, iB = featvec_arrays(groupsB)
+    matchA = np.full(len(descA), -1, np.int32)
+    nm = lib().oo_search_by_bow_kf(_p(descA), _p(angleA), _p(validA), len(descA), C.cast(nA, C.c_void_p), nnA, _p(iA), _p(descB),
+                                   _p(angleB), _p(validB), len(descB), C.cast(nB, C.c_void_p), nnB, _p(iB), nnratio,
+                                   int(check_orientation), _p(matchA))
+    return nm, matchA
 
 
 def pyramid_view(planes):
