@@ -226,6 +226,55 @@ int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_qu
 int orbfe_search_by_projection_keyframe(const orbfe_frame_view* cur, const orbfe_query* q, int nq, int check_orientation,
                                         int max_dist, uint8_t* blocked, int32_t* assigned, int* n_matches);
 
+/* ---- Frame::isInFrustum + Tracking::SearchLocalPoints -------------------------------------------
+ * The Frame members Frame::isInFrustum reads (L/src/Frame.cc:284-339). */
+typedef struct orbfe_frustum {
+  float Rcw[9], tcw[3], Ow[3];        /* mRcw (row-major), mtcw, mOw */
+  float fx, fy, cx, cy, mbf;
+  float min_x, max_x, min_y, max_y;   /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+  float log_scale_factor;             /* mfLogScaleFactor */
+  int32_t n_levels;                   /* mnScaleLevels (<= 8) */
+  float scale_factors[8];             /* mvScaleFactors */
+} orbfe_frustum;                      /* 136 bytes */
+
+/* The MapPoint members the path reads (L/include/MapPoint.h); 72 bytes */
+typedef struct orbfe_map_point {
+  float pos[3], normal[3];            /* GetWorldPos(), GetNormal() */
+  float min_distance, max_distance;   /* mfMinDistance, mfMaxDistance (un-scaled; 0.8 / 1.2 are applied as in MapPoint.cc:383-391) */
+  int32_t skip;                       /* mnLastFrameSeen == mCurrentFrame.mnId || isBad()  (L/src/Tracking.cc:1057-1060) */
+  int32_t observed;                   /* Observations() > 0 */
+  uint8_t desc[32];                   /* GetDescriptor() */
+} orbfe_map_point;
+
+/* What isInFrustum leaves in the MapPoint (L/src/Frame.cc:329-335); 24 bytes.  in_view != 0 also means
+ * pMP->IncreaseVisible() (L/src/Tracking.cc:1063). */
+typedef struct orbfe_track {
+  int32_t in_view;                    /* mbTrackInView */
+  float proj_x, proj_y, proj_xr;      /* mTrackProjX, mTrackProjY, mTrackProjXR */
+  int32_t level;                      /* mnTrackScaleLevel */
+  float view_cos;                     /* mTrackViewCos */
+} orbfe_track;
+
+/* Second half of Tracking::SearchLocalPoints (L/src/Tracking.cc:1050-1078): isInFrustum(pMP, 0.5) for every local map
+ * point, then ORBmatcher(nnratio).SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) (L/src/ORBmatcher.cc:45-128).
+ * HOST pointers, synchronous.  track[i] is written for every point; blocked / assigned as in
+ * orbfe_search_by_projection_points (assigned[idx] = index into mp[]); *n_to_match = nToMatch. */
+int orbfe_search_local_points(const orbfe_frame_view* frame, const orbfe_frustum* frustum, const orbfe_map_point* mp,
+                              int n_points, float th, float nnratio, orbfe_track* track, uint8_t* blocked,
+                              int32_t* assigned, int* n_to_match, int* n_matches);
+
+/* Batched, device-resident form: frame f owns keypoint rows [f*cap, f*cap + d_n[f]) and map points
+ * d_points[f*p_cap .. f*p_cap + d_n_points[f]) with its own d_frustum[f].  The queries never leave HBM.  d_track
+ * [n_frames][p_cap], d_blocked [n_frames][cap] (in/out), d_assigned [n_frames][cap] (in/out), d_n_to_match and
+ * d_n_matches [n_frames].  Asynchronous on `stream` (NULL = the handle's stream). */
+int orbfe_search_local_points_batch_device(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps,
+                                           const uint8_t* d_desc, const int32_t* d_n, const float* d_u_right, int cap,
+                                           float min_x, float max_x, float min_y, float max_y,
+                                           const orbfe_frustum* d_frustum, const orbfe_map_point* d_points,
+                                           const int32_t* d_n_points, int p_cap, float th, float nnratio,
+                                           orbfe_track* d_track, uint8_t* d_blocked, int32_t* d_assigned,
+                                           int32_t* d_n_to_match, int32_t* d_n_matches, void* stream);
+
 /* SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), entirely on the device.
  * A DBoW2::FeatureVector is passed as its nodes sorted by id, each {node_id, start, count} into an index array
  * (nodesA/idxA = pKF->mFeatVec, nodesB/idxB = F.mFeatVec).  validA[i] != 0 <=> keyframe feature i has a map point

@@ -780,6 +780,40 @@ int oo_level_keypoints(const oo_extractor* e, int level, const oo_keypoint** kps
 
 /* ------------------------------------------------------------------------------------------ matcher */
 /* DescriptorDistance: L/src/ORBmatcher.cc:1542-1556 (SWAR popcount on 8 int32 words) */
+/* glibc 2.35 logf (sysdeps/ieee754/flt-32/e_logf.c, table __logf_data, LOGF_TABLE_BITS = 4, poly order 4), positive
+ * normal inputs only -- MapPoint::PredictScale and Frame::mfLogScaleFactor call std::log(float) = logf on this image
+ * (L/src/MapPoint.cc:416, L/src/Frame.cc:80).  Constants read from this image's libm.so.6; checked against libm over
+ * every positive normal float by tests/c/logf_exhaustive.c. */
+static const struct { double invc, logc; } oo_logf_tab[16] = {
+  {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+  {0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2}, {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+  {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3},
+  {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+  {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1.0000000000000p+0, 0x0.0p+0},
+  {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4},
+  {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3},
+  {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+float oo_logf(float x) {
+  uint32_t ix;
+  memcpy(&ix, &x, 4);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x); /* zero, subnormal, negative, inf, nan: not restated */
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) % 16u);
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+  float zf;
+  memcpy(&zf, &iz, 4);
+  const double z = (double)zf;
+  const double r = z * oo_logf_tab[i].invc - 1.0;
+  const double y0 = oo_logf_tab[i].logc + (double)k * 0x1.62e42fefa39efp-1;
+  const double r2 = r * r;
+  double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+  y = -0x1.00ea348b88334p-2 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+
 int oo_descriptor_distance(const uint8_t* a, const uint8_t* b) {
   int dist = 0;
   for (int i = 0; i < 8; i++) {
@@ -950,6 +984,94 @@ int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq
   rh_free(&rh);
   free(vIndices);
   return nmatches;
+}
+
+/* MapPoint::PredictScale(const float&, Frame*): L/src/MapPoint.cc:409-423.  `using namespace ::std` (:25) makes
+ * log(float) -> logf and ceil(float) -> ceilf. */
+int oo_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels) {
+  const float ratio = max_distance / current_dist;
+  int nScale = (int)ceilf(oo_logf(ratio) / log_scale_factor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= n_levels) nScale = n_levels - 1;
+  return nScale;
+}
+
+/* Frame::isInFrustum: L/src/Frame.cc:284-339.  The cv::Mat expressions, as OpenCV 4.5 evaluates them for CV_32F 3x3 /
+ * 3x1 operands (generic build, no FMA contraction):
+ *   mRcw*P + mtcw -> one gemm(A,B,1,C,1): float t = a0*b0 + a1*b1 + a2*b2, d = (float)(t*1.0 + c*1.0)   (small-matrix path)
+ *   P - mOw       -> float subtraction per element
+ *   cv::norm(PO)  -> sqrt of a double sum of squares, accumulated in element order
+ *   PO.dot(Pn)    -> double sum of products in element order */
+int oo_is_in_frustum(const oo_frustum* fr, const oo_map_point* mp, float viewingCosLimit, oo_track* out) {
+  memset(out, 0, sizeof(*out));                    /* pMP->mbTrackInView = false */
+  const float* P = mp->pos;
+  float Pc[3];
+  for (int r = 0; r < 3; r++) {
+    const float* a = fr->Rcw + 3 * r;
+    const float t = a[0] * P[0] + a[1] * P[1] + a[2] * P[2];
+    Pc[r] = (float)((double)t * 1.0 + (double)fr->tcw[r] * 1.0);
+  }
+  const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+  if (PcZ < 0.0f) return 0;
+  const float invz = 1.0f / PcZ;
+  const float u = fr->fx * PcX * invz + fr->cx;
+  const float v = fr->fy * PcY * invz + fr->cy;
+  if (u < fr->min_x || u > fr->max_x) return 0;
+  if (v < fr->min_y || v > fr->max_y) return 0;
+  const float maxDistance = 1.2f * mp->max_distance;   /* GetMaxDistanceInvariance, MapPoint.cc:383-386 */
+  const float minDistance = 0.8f * mp->min_distance;   /* GetMinDistanceInvariance, MapPoint.cc:378-381 */
+  float PO[3];
+  for (int k = 0; k < 3; k++) PO[k] = P[k] - fr->Ow[k];
+  double s = 0;
+  for (int k = 0; k < 3; k++) { const double e = (double)PO[k]; s += e * e; }
+  const float dist = (float)sqrt(s);
+  if (dist < minDistance || dist > maxDistance) return 0;
+  double dot = 0;
+  for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)mp->normal[k];
+  const float viewCos = (float)(dot / (double)dist);
+  if (viewCos < viewingCosLimit) return 0;
+  const int nPredictedLevel = oo_predict_scale(mp->max_distance, dist, fr->log_scale_factor, fr->n_levels);
+  out->in_view = 1;
+  out->proj_x = u;
+  out->proj_xr = u - fr->mbf * invz;
+  out->proj_y = v;
+  out->level = nPredictedLevel;
+  out->view_cos = viewCos;
+  return 1;
+}
+
+/* L/src/ORBmatcher.cc:52-71 (+ RadiusByViewingCos :130-135, which compares the float with the double 0.998) */
+void oo_local_point_query(const oo_frustum* fr, const oo_map_point* mp, const oo_track* tr, float th, oo_query* q) {
+  memset(q, 0, sizeof(*q));
+  if (!tr->in_view || mp->skip) return;   /* skip covers isBad(); a point seen in this frame keeps mbTrackInView = false (Tracking.cc:1044) */
+  const int bFactor = (double)th != 1.0;
+  float r = ((double)tr->view_cos > 0.998) ? 2.5f : 4.0f;
+  if (bFactor) r *= th;
+  q->u = tr->proj_x; q->v = tr->proj_y; q->u_r = tr->proj_xr;
+  q->radius = r * fr->scale_factors[tr->level];
+  q->min_level = tr->level - 1;
+  q->max_level = tr->level;
+  q->valid = 1;
+  q->blocks = mp->observed != 0;
+  memcpy(q->desc, mp->desc, 32);
+}
+
+/* Tracking::SearchLocalPoints: L/src/Tracking.cc:1050-1078 */
+int oo_search_local_points(const oo_frame* f, const oo_frustum* fr, const oo_map_point* mp, int n, float th, float nnratio,
+                           oo_track* track, uint8_t* blocked, int32_t* assigned, int* n_to_match) {
+  int nToMatch = 0;
+  for (int i = 0; i < n; i++) {
+    memset(&track[i], 0, sizeof(oo_track));
+    if (mp[i].skip) continue;
+    if (oo_is_in_frustum(fr, &mp[i], 0.5f, &track[i])) nToMatch++;
+  }
+  *n_to_match = nToMatch;
+  if (nToMatch == 0) return 0;
+  oo_query* q = (oo_query*)malloc(sizeof(oo_query) * (size_t)(n ? n : 1));
+  for (int i = 0; i < n; i++) oo_local_point_query(fr, &mp[i], &track[i], th, &q[i]);
+  const int nm = oo_search_by_projection_points(f, q, n, nnratio, blocked, assigned);
+  free(q);
+  return nm;
 }
 
 /* SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist): L/src/ORBmatcher.cc:1439-1501 */

@@ -47,6 +47,7 @@ int oo_cvroundf(float v);
 float oo_fast_atan2(float y, float x);    /* P5: cv::fastAtan2, degrees */
 float oo_sinf(float x);                   /* restatement of glibc 2.35 sinf for |x| < 120 */
 float oo_cosf(float x);
+float oo_logf(float x);                   /* restatement of glibc 2.35 logf for positive normal x */
 void oo_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
                          int dstride);    /* P2 */
 /* coefficient tables of P2 for one axis: ofs[d], coef[2*d..2*d+1] */
@@ -140,6 +141,38 @@ typedef struct oo_query {
  * assigned[idx] = query index written to F.mvpMapPoints[idx] (or left unchanged).  Returns nmatches. */
 int oo_search_by_projection_points(const oo_frame* f, const oo_query* q, int nq, float nnratio, uint8_t* blocked,
                                    int32_t* assigned);
+/* ---- Frame::isInFrustum + Tracking::SearchLocalPoints */
+typedef struct oo_frustum {      /* the Frame members isInFrustum reads (L/include/Frame.h) */
+  float Rcw[9], tcw[3], Ow[3];   /* mRcw (row-major), mtcw, mOw */
+  float fx, fy, cx, cy, mbf;
+  float min_x, max_x, min_y, max_y;   /* mnMinX .. mnMaxY */
+  float log_scale_factor;        /* mfLogScaleFactor */
+  int32_t n_levels;              /* mnScaleLevels */
+  float scale_factors[8];        /* mvScaleFactors */
+} oo_frustum;
+typedef struct oo_map_point {    /* the MapPoint members the path reads (L/include/MapPoint.h) */
+  float pos[3], normal[3];       /* mWorldPos, mNormalVector */
+  float min_distance, max_distance;   /* mfMinDistance, mfMaxDistance (GetMin/MaxDistanceInvariance scale them) */
+  int32_t skip;                  /* mnLastFrameSeen == frame id || isBad()   (Tracking.cc:1057-1060) */
+  int32_t observed;              /* Observations() > 0 */
+  uint8_t desc[32];              /* GetDescriptor() */
+} oo_map_point;
+typedef struct oo_track {        /* what isInFrustum leaves in the MapPoint (Frame.cc:329-335) */
+  int32_t in_view;               /* mbTrackInView */
+  float proj_x, proj_y, proj_xr; /* mTrackProjX, mTrackProjY, mTrackProjXR */
+  int32_t level;                 /* mnTrackScaleLevel */
+  float view_cos;                /* mTrackViewCos */
+} oo_track;
+int oo_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels); /* MapPoint.cc:409-423 */
+int oo_is_in_frustum(const oo_frustum* fr, const oo_map_point* mp, float viewing_cos_limit, oo_track* out); /* Frame.cc:284-339 */
+/* query SearchByProjection(F, vpMapPoints, th) forms from one tracked point (ORBmatcher.cc:52-71) */
+void oo_local_point_query(const oo_frustum* fr, const oo_map_point* mp, const oo_track* tr, float th, oo_query* q);
+/* Tracking::SearchLocalPoints second half (Tracking.cc:1053-1078): isInFrustum(pMP, 0.5) for every local point that is
+ * not skipped, then SearchByProjection(F, points, th) when anything is visible.  track[] per point; *n_to_match =
+ * nToMatch.  Returns nmatches (0 when nToMatch == 0). */
+int oo_search_local_points(const oo_frame* f, const oo_frustum* fr, const oo_map_point* mp, int n, float th, float nnratio,
+                           oo_track* track, uint8_t* blocked, int32_t* assigned, int* n_to_match);
+
 /* SearchByProjection(Frame& cur, const Frame& last, th, bMono): ORBmatcher.cc:1247-1383 (window,
  * argmin, TH_HIGH, rotation histogram).  Queries carry the projection.  Returns nmatches. */
 int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq, int check_orientation,

@@ -24,6 +24,20 @@ QUERY_DTYPE = np.dtype(
      ("max_level", "<i4"), ("valid", "<i4"), ("blocks", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))]
 )
 CAND_DTYPE = np.dtype([("idx", "<i4"), ("dist", "<i4")])
+# orbfe_frustum / orbfe_map_point / orbfe_track (include/orbfe.h)
+FRUSTUM_DTYPE = np.dtype(
+    [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("Ow", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"),
+     ("cy", "<f4"), ("mbf", "<f4"), ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"),
+     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("scale_factors", "<f4", (8,))]
+)
+MAP_POINT_DTYPE = np.dtype(
+    [("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"), ("skip", "<i4"),
+     ("observed", "<i4"), ("desc", "u1", (32,))]
+)
+TRACK_DTYPE = np.dtype(
+    [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
+)
+assert FRUSTUM_DTYPE.itemsize == 136 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
 BF_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_dist", "<i4")])
 
 
@@ -59,7 +73,8 @@ EXPORTS = [
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
-    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_by_projection_keyframe",
+    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
+    "orbfe_search_local_points_batch_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow",
 ]
@@ -131,6 +146,9 @@ def lib():
     L.orbfe_proj_candidates.argtypes = [C.POINTER(FrameView), vp, ci, vp, vp, ci]
     L.orbfe_search_by_projection_points.argtypes = [C.POINTER(FrameView), vp, ci, cf, vp, vp, pi]
     L.orbfe_search_by_projection_frame.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, pi]
+    L.orbfe_search_local_points.argtypes = [C.POINTER(FrameView), vp, vp, ci, cf, cf, vp, vp, vp, pi, pi]
+    L.orbfe_search_local_points_batch_device.argtypes = [vp, ci, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, ci, cf, cf,
+                                                         vp, vp, vp, vp, vp, vp]
     L.orbfe_search_by_projection_keyframe.argtypes = [C.POINTER(FrameView), vp, ci, ci, ci, vp, vp, pi]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, ci, C.POINTER(vp)]

@@ -1,0 +1,168 @@
+// frustum_kernels.hip -- Frame::isInFrustum + MapPoint::PredictScale + the query SearchByProjection(F, vpMapPoints, th)
+// forms from each tracked local map point (L/src/Frame.cc:284-339, L/src/MapPoint.cc:409-423, L/src/ORBmatcher.cc:52-71,
+// driver loop L/src/Tracking.cc:1053-1067).  SURVEY 8(f) row 3: the queries are produced in HBM and consumed by
+// proj_candidates / proj_resolve without a host pass.
+#include <hip/hip_runtime.h>
+
+#include "match_internal.h"
+
+#define FQ_THREADS 256
+#define WAVE 64
+#define MP_DW (int)(sizeof(orbfe_map_point) / 4)   // 18
+#define Q_DW (int)(sizeof(orbfe_query) / 4)        // 17
+#define TR_DW (int)(sizeof(orbfe_track) / 4)       // 6
+static_assert(sizeof(orbfe_map_point) == 72 && sizeof(orbfe_query) == 68 && sizeof(orbfe_track) == 24, "record layout");
+
+// glibc 2.35 logf (__logf_data, LOGF_TABLE_BITS = 4): {invc, logc} pairs.  Same constants as the oracle's oo_logf; the
+// arithmetic below is the same double sequence (compiled with -ffp-contract=off).
+__device__ const double g_logf_tab[32] = {
+    0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2, 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2,
+    0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2, 0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3,
+    0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3, 0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3,
+    0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4, 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4,
+    0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5, 0x1.0000000000000p+0, 0x0.0p+0,
+    0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5,  0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4,
+    0x1.b2036576afce6p-1, 0x1.526e57720db08p-3,  0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3,
+    0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2};
+
+// MapPoint::PredictScale.  Inputs logf does not map to a finite value (ratio 0, subnormal, inf, nan, negative) make the
+// reference's float->int conversion produce INT_MIN on x86-64 (cvttss2si), hence level 0 after the clamp.
+__device__ __forceinline__ int predict_scale(float max_distance, float dist, float log_scale_factor, int n_levels) {
+  const float ratio = max_distance / dist;
+  const uint32_t ix = __float_as_uint(ratio);
+  float l;
+  if (ix == 0x3f800000u) {
+    l = 0.0f;
+  } else if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    return 0;
+  } else {
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    const double z = (double)__uint_as_float(iz);
+    const double r = z * g_logf_tab[2 * i] - 1.0;
+    const double y0 = g_logf_tab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    l = (float)y;
+  }
+  const float c = ceilf(l / log_scale_factor);
+  if (!(c >= -2147483648.0f && c < 2147483648.0f)) return 0;  // INT_MIN -> clamped to 0
+  int nScale = (int)c;
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= n_levels) nScale = n_levels - 1;
+  return nScale;
+}
+
+// One thread per local map point; a block stages its 256 records through LDS so that the 72-byte inputs and the 68-byte
+// queries move as coalesced dwords.
+__global__ __launch_bounds__(FQ_THREADS) void frustum_queries_kernel(const orbfe_frustum* __restrict__ frustums,
+                                                                     const orbfe_map_point* __restrict__ points,
+                                                                     const int32_t* __restrict__ n_points, int p_cap, float th,
+                                                                     float viewing_cos_limit, orbfe_track* __restrict__ track,
+                                                                     orbfe_query* __restrict__ queries,
+                                                                     int32_t* __restrict__ n_to_match) {
+  __shared__ uint32_t rec[FQ_THREADS * MP_DW];  // map points in, queries out (in place: 17 of each thread's 18 dwords)
+  __shared__ uint32_t trk[FQ_THREADS * TR_DW];
+  __shared__ orbfe_frustum fr;
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const int np = n_points[f];
+  const int p0 = blockIdx.x * FQ_THREADS;
+  if (p0 >= np) return;
+  const int cnt = min(FQ_THREADS, np - p0);
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(points + (size_t)f * p_cap + p0);
+    for (int i = tid; i < cnt * MP_DW; i += FQ_THREADS) rec[i] = src[i];
+    const uint32_t* fs = reinterpret_cast<const uint32_t*>(frustums + f);
+    if (tid < (int)(sizeof(orbfe_frustum) / 4)) reinterpret_cast<uint32_t*>(&fr)[tid] = fs[tid];
+  }
+  __syncthreads();
+  bool in_view = false;
+  if (tid < cnt) {
+    orbfe_map_point mp;
+    uint32_t* mpw = reinterpret_cast<uint32_t*>(&mp);
+#pragma unroll
+    for (int j = 0; j < MP_DW; j++) mpw[j] = rec[tid * MP_DW + j];
+    orbfe_track tr;
+    tr.in_view = 0; tr.proj_x = 0.f; tr.proj_y = 0.f; tr.proj_xr = 0.f; tr.level = 0; tr.view_cos = 0.f;
+    if (!mp.skip) {   // Tracking.cc:1057-1060
+      // ---- Frame::isInFrustum (Frame.cc:284-339); every early `return false` of the reference is a fall-through here
+      float Pc[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float t = fr.Rcw[3 * r] * mp.pos[0] + fr.Rcw[3 * r + 1] * mp.pos[1] + fr.Rcw[3 * r + 2] * mp.pos[2];
+        Pc[r] = (float)((double)t * 1.0 + (double)fr.tcw[r] * 1.0);  // cv::gemm small-matrix path: float dot, double epilogue
+      }
+      if (!(Pc[2] < 0.0f)) {
+        const float invz = 1.0f / Pc[2];
+        const float u = fr.fx * Pc[0] * invz + fr.cx;
+        const float v = fr.fy * Pc[1] * invz + fr.cy;
+        if (!(u < fr.min_x || u > fr.max_x) && !(v < fr.min_y || v > fr.max_y)) {
+          const float maxDistance = 1.2f * mp.max_distance, minDistance = 0.8f * mp.min_distance;
+          float PO[3];
+          double s = 0.0, dot = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            PO[k] = mp.pos[k] - fr.Ow[k];
+            s += (double)PO[k] * (double)PO[k];          // cv::norm: double accumulation in element order
+            dot += (double)PO[k] * (double)mp.normal[k]; // Mat::dot: the same
+          }
+          const float dist = (float)sqrt(s);
+          if (!(dist < minDistance || dist > maxDistance)) {
+            const float viewCos = (float)(dot / (double)dist);
+            if (!(viewCos < viewing_cos_limit)) {
+              tr.in_view = 1;
+              tr.proj_x = u;
+              tr.proj_xr = u - fr.mbf * invz;
+              tr.proj_y = v;
+              tr.level = predict_scale(mp.max_distance, dist, fr.log_scale_factor, fr.n_levels);
+              tr.view_cos = viewCos;
+              in_view = true;
+            }
+          }
+        }
+      }
+    }
+    // ---- the query of SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:52-71)
+    orbfe_query q;
+    uint32_t* qw = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+    for (int j = 0; j < Q_DW; j++) qw[j] = 0u;
+    if (in_view) {
+      float r = ((double)tr.view_cos > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos (:130-135)
+      if ((double)th != 1.0) r *= th;
+      q.u = tr.proj_x; q.v = tr.proj_y; q.u_r = tr.proj_xr;
+      q.radius = r * fr.scale_factors[tr.level];
+      q.min_level = tr.level - 1;
+      q.max_level = tr.level;
+      q.valid = 1;
+      q.blocks = mp.observed != 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) reinterpret_cast<uint32_t*>(q.desc)[j] = reinterpret_cast<const uint32_t*>(mp.desc)[j];
+    }
+#pragma unroll
+    for (int j = 0; j < Q_DW; j++) rec[tid * MP_DW + j] = qw[j];
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(&tr);
+#pragma unroll
+    for (int j = 0; j < TR_DW; j++) trk[tid * TR_DW + j] = tw[j];
+  }
+  const unsigned long long bal = __ballot(in_view);
+  if ((tid & (WAVE - 1)) == 0 && bal) atomicAdd(&n_to_match[f], __popcll(bal));
+  __syncthreads();
+  uint32_t* qdst = reinterpret_cast<uint32_t*>(queries + (size_t)f * p_cap + p0);
+  for (int o = tid; o < cnt * Q_DW; o += FQ_THREADS) qdst[o] = rec[(o / Q_DW) * MP_DW + (o % Q_DW)];
+  uint32_t* tdst = reinterpret_cast<uint32_t*>(track + (size_t)f * p_cap + p0);
+  for (int o = tid; o < cnt * TR_DW; o += FQ_THREADS) tdst[o] = trk[o];
+}
+
+void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,
+                                  int p_cap, float th, float viewing_cos_limit, orbfe_track* track, orbfe_query* queries,
+                                  int32_t* n_to_match, int n_frames, hipStream_t s) {
+  if (p_cap < 1 || n_frames < 1) return;
+  dim3 grid((p_cap + FQ_THREADS - 1) / FQ_THREADS, n_frames);
+  hipLaunchKernelGGL(frustum_queries_kernel, grid, dim3(FQ_THREADS), 0, s, frustums, points, n_points, p_cap, th,
+                     viewing_cos_limit, track, queries, n_to_match);
+}

@@ -11,6 +11,9 @@
 //   Frame:    N, mvKeysUn, mDescriptors, mvuRight, mvpMapPoints, mvScaleFactors, mnMinX/mnMaxX/mnMinY/mnMaxY
 //   MapPoint: mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel, mTrackViewCos,
 //             isBad(), Observations(), GetDescriptor()
+//   SearchLocalPoints additionally -- Frame: mnId, mRcw, mtcw, mOw, fx, fy, cx, cy, mbf, mfLogScaleFactor, mnScaleLevels;
+//             MapPoint: mnLastFrameSeen, GetWorldPos(), GetNormal(), IncreaseVisible() and two trivial accessors the
+//             reference lacks, GetMinDistance() / GetMaxDistance() returning mfMinDistance / mfMaxDistance
 #pragma once
 #include <stdio.h>
 #include <string.h>
@@ -95,6 +98,75 @@ int SearchByProjectionPoints(FrameT& F, const std::vector<MapPointT*>& vpMapPoin
   }
   for (int i = 0; i < F.N; i++)
     if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[(size_t)assigned[i]];  // :122
+  return nmatches;
+}
+
+// Row r of a CV_32F cv::Mat with one column (3x1) or three (3x3)
+template <class MatT>
+inline const float* FloatRow(const MatT& M, int r) { return reinterpret_cast<const float*>(M.ptr(r)); }
+
+// Second half of Tracking::SearchLocalPoints (L/src/Tracking.cc:1050-1078): replaces the isInFrustum loop and the
+// SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) call.  Projection, frustum tests, scale prediction, window
+// search and assignment all run on the GPU; the MapPoint fields isInFrustum writes, IncreaseVisible() and
+// F.mvpMapPoints are updated here from the results.  Returns nmatches; *nToMatch as the reference counts it.
+template <class FrameT, class MapPointT>
+int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints, float th, float nnratio,
+                      int* nToMatch = nullptr) {
+  const size_t n = vpLocalMapPoints.size();
+  orbfe_frustum fr;
+  memset(&fr, 0, sizeof(fr));
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) fr.Rcw[3 * r + c] = FloatRow(F.mRcw, r)[c];
+    fr.tcw[r] = FloatRow(F.mtcw, r)[0];
+    fr.Ow[r] = FloatRow(F.mOw, r)[0];
+  }
+  fr.fx = F.fx; fr.fy = F.fy; fr.cx = F.cx; fr.cy = F.cy; fr.mbf = F.mbf;
+  fr.min_x = F.mnMinX; fr.max_x = F.mnMaxX; fr.min_y = F.mnMinY; fr.max_y = F.mnMaxY;
+  fr.log_scale_factor = F.mfLogScaleFactor;
+  fr.n_levels = F.mnScaleLevels;
+  for (int l = 0; l < F.mnScaleLevels && l < 8; l++) fr.scale_factors[l] = F.mvScaleFactors[l];
+  std::vector<orbfe_map_point> mp(n);
+  for (size_t i = 0; i < n; i++) {
+    MapPointT* pMP = vpLocalMapPoints[i];
+    orbfe_map_point& e = mp[i];
+    memset(&e, 0, sizeof(e));
+    e.skip = (pMP->mnLastFrameSeen == F.mnId) || pMP->isBad();  // :1057-1060
+    if (e.skip) continue;
+    const auto P = pMP->GetWorldPos();
+    const auto Pn = pMP->GetNormal();
+    for (int r = 0; r < 3; r++) { e.pos[r] = FloatRow(P, r)[0]; e.normal[r] = FloatRow(Pn, r)[0]; }
+    e.min_distance = pMP->GetMinDistance();
+    e.max_distance = pMP->GetMaxDistance();
+    e.observed = pMP->Observations() > 0;
+    const auto d = pMP->GetDescriptor();
+    memcpy(e.desc, d.ptr(0), 32);
+  }
+  std::vector<orbfe_track> track(n);
+  std::vector<uint8_t> blocked = BlockedFromFrame(F);
+  std::vector<int32_t> assigned((size_t)F.N, -1);
+  const orbfe_frame_view v = MakeFrameView(F);
+  int ntm = 0, nmatches = 0;
+  const int rc = orbfe_search_local_points(&v, &fr, mp.data(), (int)n, th, nnratio, track.data(), blocked.data(),
+                                           assigned.data(), &ntm, &nmatches);
+  if (rc != ORBFE_OK) {
+    fprintf(stderr, "Tracking::SearchLocalPoints: liborbfe error %d: %s\n", rc, orbfe_last_error());
+    return 0;
+  }
+  for (size_t i = 0; i < n; i++) {
+    if (mp[i].skip) continue;
+    MapPointT* pMP = vpLocalMapPoints[i];
+    pMP->mbTrackInView = track[i].in_view != 0;       // Frame.cc:285,329
+    if (!track[i].in_view) continue;
+    pMP->mTrackProjX = track[i].proj_x;
+    pMP->mTrackProjXR = track[i].proj_xr;
+    pMP->mTrackProjY = track[i].proj_y;
+    pMP->mnTrackScaleLevel = track[i].level;
+    pMP->mTrackViewCos = track[i].view_cos;
+    pMP->IncreaseVisible();                           // Tracking.cc:1063
+  }
+  for (int i = 0; i < F.N; i++)
+    if (assigned[i] >= 0) F.mvpMapPoints[i] = vpLocalMapPoints[(size_t)assigned[i]];  // ORBmatcher.cc:122
+  if (nToMatch) *nToMatch = ntm;
   return nmatches;
 }
 

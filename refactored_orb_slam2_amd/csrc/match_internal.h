@@ -72,6 +72,9 @@ struct BowParams {
   int32_t* counters;    // [0] pushes, [1] nmatches, [2..31] rotation histogram
   int32_t* push_idx; uint8_t* push_bin;
 };
+void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,
+                                  int p_cap, float th, float viewing_cos_limit, orbfe_track* track, orbfe_query* queries,
+                                  int32_t* n_to_match, int n_frames, hipStream_t s);
 void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s);
 void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s);

@@ -53,6 +53,8 @@ struct orbfe_matcher {
   MBuf cell_start, cell_idx, cand, n_cand, push_idx, push_bin, sad, bucket_start, bucket_idx;
   // staging for the host-pointer entry points
   MBuf h_keys, h_desc, h_ur, h_q, h_n, h_nq, h_blocked, h_assigned, h_nm;
+  // SearchLocalPoints: generated queries (device) and staging of the host entry point
+  MBuf lp_q, lp_pts, lp_fr, lp_track, lp_cnt;
   std::mutex mu;
 };
 
@@ -84,7 +86,8 @@ extern "C" int orbfe_matcher_destroy(orbfe_matcher* m) {
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->bucket_start, &m->bucket_idx, &m->h_keys,
-                  &m->h_desc, &m->h_ur, &m->h_q, &m->h_n, &m->h_nq, &m->h_blocked, &m->h_assigned, &m->h_nm};
+                  &m->h_desc, &m->h_ur, &m->h_q, &m->h_n, &m->h_nq, &m->h_blocked, &m->h_assigned, &m->h_nm,
+                  &m->lp_q, &m->lp_pts, &m->lp_fr, &m->lp_track, &m->lp_cnt};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -324,6 +327,88 @@ extern "C" int orbfe_search_by_projection_frame(const orbfe_frame_view* f, const
                                                 int check_orientation, uint8_t* blocked, int32_t* assigned,
                                                 int* n_matches) {
   return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches);
+}
+
+// ---- Tracking::SearchLocalPoints (L/src/Tracking.cc:1050-1078): isInFrustum -> queries (in HBM) -> SearchByProjection
+static int local_points_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                                const int32_t* d_n, const float* d_ur, int cap, float min_x, float max_x, float min_y,
+                                float max_y, const orbfe_frustum* d_fr, const orbfe_map_point* d_pts, const int32_t* d_np,
+                                int p_cap, float th, float nnratio, orbfe_track* d_track, uint8_t* d_blocked,
+                                int32_t* d_assigned, int32_t* d_ntm, int32_t* d_nm, hipStream_t s) {
+  int rc;
+  if ((rc = mb_alloc(m->lp_q, (size_t)n_frames * p_cap * sizeof(orbfe_query)))) return rc;
+  HIPCHK(hipMemsetAsync(d_ntm, 0, sizeof(int32_t) * n_frames, s));
+  orbfe_launch_frustum_queries(d_fr, d_pts, d_np, p_cap, th, 0.5f, d_track, (orbfe_query*)m->lp_q.p, d_ntm, n_frames, s);
+  return proj_enqueue(m, n_frames, d_kps, d_desc, d_n, d_ur, cap, min_x, max_x, min_y, max_y, (const orbfe_query*)m->lp_q.p,
+                      d_np, p_cap, 0, nnratio, 0, d_blocked, d_assigned, d_nm, true, s);
+}
+
+extern "C" int orbfe_search_local_points_batch_device(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps,
+                                                      const uint8_t* d_desc, const int32_t* d_n, const float* d_u_right,
+                                                      int cap, float min_x, float max_x, float min_y, float max_y,
+                                                      const orbfe_frustum* d_frustum, const orbfe_map_point* d_points,
+                                                      const int32_t* d_n_points, int p_cap, float th, float nnratio,
+                                                      orbfe_track* d_track, uint8_t* d_blocked, int32_t* d_assigned,
+                                                      int32_t* d_n_to_match, int32_t* d_n_matches, void* stream) {
+  if (!m || !d_kps || !d_desc || !d_n || !d_frustum || !d_points || !d_n_points || !d_track || !d_blocked || !d_assigned ||
+      !d_n_to_match || !d_n_matches || n_frames < 1 || cap < 1 || p_cap < 1 || !(max_x > min_x) || !(max_y > min_y))
+    return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_frustum & 3) || ((uintptr_t)d_points & 3) || ((uintptr_t)d_track & 3)) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+  return local_points_enqueue(m, n_frames, d_kps, d_desc, d_n, d_u_right, cap, min_x, max_x, min_y, max_y, d_frustum,
+                              d_points, d_n_points, p_cap, th, nnratio, d_track, d_blocked, d_assigned, d_n_to_match,
+                              d_n_matches, s);
+}
+
+extern "C" int orbfe_search_local_points(const orbfe_frame_view* f, const orbfe_frustum* fr, const orbfe_map_point* mp,
+                                         int n_points, float th, float nnratio, orbfe_track* track, uint8_t* blocked,
+                                         int32_t* assigned, int* n_to_match, int* n_matches) {
+  if (!frame_ok(f) || !fr || n_points < 0 || (n_points > 0 && (!mp || !track)) || !blocked || !assigned || !n_to_match ||
+      !n_matches || fr->n_levels < 1 || fr->n_levels > ORBFE_MAX_LEVELS)
+    return ORBFE_ERR_INVALID;
+  *n_to_match = 0;
+  *n_matches = 0;
+  if (n_points == 0) return ORBFE_OK;
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  if ((rc = mb_alloc(m->lp_pts, sizeof(orbfe_map_point) * (size_t)n_points))) return rc;
+  if ((rc = mb_alloc(m->lp_track, sizeof(orbfe_track) * (size_t)n_points))) return rc;
+  if ((rc = mb_alloc(m->lp_fr, sizeof(orbfe_frustum)))) return rc;
+  if ((rc = mb_alloc(m->lp_cnt, 16))) return rc;
+  HIPCHK(hipMemcpyAsync(m->lp_pts.p, mp, sizeof(orbfe_map_point) * (size_t)n_points, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(m->lp_fr.p, fr, sizeof(orbfe_frustum), hipMemcpyHostToDevice, s));
+  if ((rc = stage_host(m, f, nullptr, 0, s))) return rc;
+  const int32_t np = n_points;
+  HIPCHK(hipMemcpyAsync(m->h_nq.p, &np, 4, hipMemcpyHostToDevice, s));
+  const int cap = std::max(f->n, 1);
+  if (f->n > 0) {
+    HIPCHK(hipMemcpyAsync(m->h_blocked.p, blocked, f->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->h_assigned.p, assigned, sizeof(int32_t) * f->n, hipMemcpyHostToDevice, s));
+  }
+  rc = local_points_enqueue(m, 1, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
+                            f->u_right ? (const float*)m->h_ur.p : nullptr, cap, f->min_x, f->max_x, f->min_y, f->max_y,
+                            (const orbfe_frustum*)m->lp_fr.p, (const orbfe_map_point*)m->lp_pts.p, (const int32_t*)m->h_nq.p,
+                            n_points, th, nnratio, (orbfe_track*)m->lp_track.p, (uint8_t*)m->h_blocked.p,
+                            (int32_t*)m->h_assigned.p, (int32_t*)m->lp_cnt.p, (int32_t*)m->h_nm.p, s);
+  if (rc) return rc;
+  int32_t nm = 0, ntm = 0;
+  HIPCHK(hipMemcpyAsync(track, m->lp_track.p, sizeof(orbfe_track) * (size_t)n_points, hipMemcpyDeviceToHost, s));
+  if (f->n > 0) {
+    HIPCHK(hipMemcpyAsync(blocked, m->h_blocked.p, f->n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(assigned, m->h_assigned.p, sizeof(int32_t) * f->n, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipMemcpyAsync(&nm, m->h_nm.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&ntm, m->lp_cnt.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_matches = nm;
+  *n_to_match = ntm;
+  return ORBFE_OK;
 }
 
 // SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) (L/src/ORBmatcher.cc:1385-1504): the

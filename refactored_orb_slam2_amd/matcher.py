@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BF_DTYPE, CAND_DTYPE, KP_DTYPE, QUERY_DTYPE
+from ._lib import BF_DTYPE, CAND_DTYPE, FRUSTUM_DTYPE, KP_DTYPE, MAP_POINT_DTYPE, QUERY_DTYPE, TRACK_DTYPE
 
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
 
@@ -45,6 +45,27 @@ def make_queries(n: int) -> np.ndarray:
     q["min_level"] = -1
     q["max_level"] = -1
     return q
+
+
+def make_frustum(Rcw, tcw, fx, fy, cx, cy, mbf, bounds, scale_factor, n_levels) -> np.ndarray:
+    """The Frame members Frame::isInFrustum reads (Frame.cc:284-339), computed as Frame does: mOw = -Rcw.t()*tcw
+    (Frame.cc:274-279, float arithmetic), mfLogScaleFactor = logf(mfScaleFactor) (Frame.cc:80), mvScaleFactors from the
+    extractor (ORBextractor.cc:416-420)."""
+    fr = np.zeros(1, FRUSTUM_DTYPE)
+    R = np.asarray(Rcw, np.float32).reshape(3, 3); t = np.asarray(tcw, np.float32).reshape(3)
+    fr["Rcw"][0] = R.reshape(9); fr["tcw"][0] = t
+    Rt = R.T
+    fr["Ow"][0] = [-(np.float32(np.float32(Rt[r, 0] * t[0]) + np.float32(Rt[r, 1] * t[1])) + np.float32(Rt[r, 2] * t[2])) for r in range(3)]
+    for k, v in (("fx", fx), ("fy", fy), ("cx", cx), ("cy", cy), ("mbf", mbf)):
+        fr[k] = np.float32(v)
+    fr["min_x"], fr["max_x"], fr["min_y"], fr["max_y"] = [np.float32(b) for b in bounds]
+    fr["log_scale_factor"] = np.log(np.float32(scale_factor), dtype=np.float32)
+    fr["n_levels"] = n_levels
+    sf = np.ones(8, np.float32)
+    for i in range(1, n_levels):
+        sf[i] = np.float32(sf[i - 1] * np.float32(scale_factor))
+    fr["scale_factors"][0] = sf
+    return fr
 
 
 class ORBmatcher:
@@ -124,6 +145,21 @@ class ORBmatcher:
                                                             _lib.ptr(assigned), C.byref(nm)),
                    "orbfe_search_by_projection_frame")
         return nm.value, assigned, blocked
+
+    # ---- Tracking::SearchLocalPoints second half: isInFrustum(pMP, 0.5) + SearchByProjection(F, vpMapPoints, th)
+    def SearchLocalPoints(self, frame: FrameView, frustum: np.ndarray, points: np.ndarray, th: float = 1.0, blocked=None):
+        """points: MAP_POINT_DTYPE records (mvpLocalMapPoints).  Returns (nToMatch, nmatches, track, assigned, blocked);
+        track[i] holds what isInFrustum leaves in point i (TRACK_DTYPE)."""
+        fr = np.ascontiguousarray(frustum, FRUSTUM_DTYPE).reshape(1)
+        mp = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+        track = np.zeros(len(mp), TRACK_DTYPE)
+        blocked = np.zeros(frame.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        assigned = np.full(frame.n, -1, np.int32)
+        ntm, nm = C.c_int(0), C.c_int(0)
+        _lib.check(self._L.orbfe_search_local_points(C.byref(frame.c), _lib.ptr(fr), _lib.ptr(mp), len(mp), float(np.float32(th)),
+                                                     self.mfNNratio, _lib.ptr(track), _lib.ptr(blocked), _lib.ptr(assigned),
+                                                     C.byref(ntm), C.byref(nm)), "orbfe_search_local_points")
+        return ntm.value, nm.value, track, assigned, blocked
 
     # ---- SearchByProjection(Frame& cur, KeyFrame* pKF, sAlreadyFound, th, ORBdist): ORBmatcher.cc:1385-1504
     def SearchByProjectionKeyFrame(self, cur: FrameView, queries: np.ndarray, ORBdist: int, blocked=None):
@@ -250,6 +286,18 @@ class Matcher:
             self._h, F, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n), _lib.ptr(u_right), cap, bounds[0], bounds[1], bounds[2],
             bounds[3], _lib.ptr(queries), _lib.ptr(nq), queries.shape[1], mode, nnratio, int(check_ori), _lib.ptr(blocked),
             _lib.ptr(assigned), _lib.ptr(n_matches), s), "orbfe_proj_match_batch_device")
+
+    def search_local_points_batch(self, kps, desc, n, u_right, bounds, frustums, points, n_points, th, nnratio, track,
+                                  blocked, assigned, n_to_match, n_matches, stream=None):
+        """Tracking::SearchLocalPoints for a batch of frames, everything device-resident (torch CUDA tensors):
+        frustums (F,136) u8, points (F,pcap,72) u8, n_points (F) i32, track (F,pcap,24) u8; the rest as proj_match_batch."""
+        F, cap = desc.shape[0], desc.shape[1]
+        s = _lib.stream_handle(stream)
+        _lib.check(self._L.orbfe_search_local_points_batch_device(
+            self._h, F, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n), _lib.ptr(u_right), cap, bounds[0], bounds[1], bounds[2],
+            bounds[3], _lib.ptr(frustums), _lib.ptr(points), _lib.ptr(n_points), points.shape[1], float(np.float32(th)),
+            float(np.float32(nnratio)), _lib.ptr(track), _lib.ptr(blocked), _lib.ptr(assigned), _lib.ptr(n_to_match),
+            _lib.ptr(n_matches), s), "orbfe_search_local_points_batch_device")
 
     def stereo_match(self, ex_left, ex_right, kps_l, desc_l, n_l, kps_r, desc_r, n_r, mbf, mb, u_right, depth, n_matched,
                      stream=None):

@@ -99,3 +99,63 @@ def sequence(w: int, h: int, n: int, seq: int = 0, stereo: bool = False):
     if stereo:
         return [stereo_pair(w, h, seq, f, scene) for f in range(n)]
     return [frame(w, h, seq, f, scene) for f in range(n)]
+
+
+def camera_pose(seed: int):
+    """A seeded camera pose (Rcw, tcw): small rotation about a random axis plus a translation of a few metres."""
+    rng = np.random.default_rng(seed)
+    axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+    ang = rng.uniform(-0.3, 0.3)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    t = rng.uniform(-3, 3, 3)
+    return R.astype(np.float32), t.astype(np.float32)
+
+
+def local_map(keys, desc, frustum, seed: int, n_extra: int = 500, dup_frac: float = 0.2) -> np.ndarray:
+    """Synthetic mvpLocalMapPoints for one frame (records in the layout of orbfe_map_point): every keypoint of the frame is
+    back-projected to a random depth so that it re-projects within ~1 px of the keypoint at a predicted level that
+    contains the keypoint's octave; a fraction gets a second, noisier point (contention for the same keypoint);
+    n_extra points are placed anywhere (behind the camera, outside the image, too near/far, oblique normals).  The
+    descriptor is the keypoint's with 0..40 flipped bits; ~10 % of the points are flagged skip, ~80 % observed."""
+    from ._lib import MAP_POINT_DTYPE
+    rng = np.random.default_rng(seed)
+    fr = frustum.reshape(-1)[0]
+    R = fr["Rcw"].reshape(3, 3).astype(np.float64); t = fr["tcw"].astype(np.float64); Ow = fr["Ow"].astype(np.float64)
+    sf = float(fr["scale_factors"][1]); nl = int(fr["n_levels"])
+    n0 = len(keys)
+    src = np.concatenate([np.arange(n0), rng.choice(n0, int(dup_frac * n0), replace=False)]) if n0 else np.zeros(0, np.int64)
+    n = len(src)
+    mp = np.zeros(n + n_extra, MAP_POINT_DTYPE)
+    if n:
+        z = rng.uniform(4.0, 40.0, n)
+        u = keys["x"][src].astype(np.float64) + rng.normal(0, 0.6, n)
+        v = keys["y"][src].astype(np.float64) + rng.normal(0, 0.6, n)
+        Xc = np.stack([(u - fr["cx"]) * z / fr["fx"], (v - fr["cy"]) * z / fr["fy"], z], 1)
+        P = (Xc - t) @ R          # R^T (Xc - t), row form
+        PO = P - Ow
+        dist = np.linalg.norm(PO, axis=1)
+        # normal: viewing ray tilted by up to ~70 degrees (beyond 60 the point fails viewCos >= 0.5)
+        tilt = rng.uniform(0, 1.22, n) * (rng.random(n) < 0.5)
+        perp = np.cross(PO, rng.normal(size=(n, 3))); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+        nrm = np.cos(tilt)[:, None] * PO / dist[:, None] + np.sin(tilt)[:, None] * perp
+        e = keys["octave"][src] + rng.uniform(-0.95, 0.95, n)
+        e[::17] = np.round(e[::17])            # ratio = sf**k: the ceil() boundary
+        maxd = dist * sf ** e
+        mp["pos"][:n] = P; mp["normal"][:n] = nrm
+        mp["max_distance"][:n] = maxd; mp["min_distance"][:n] = maxd / sf ** (nl - 1)
+        d = desc[src].copy()
+        flips = rng.integers(0, 41, n)
+        for i in range(n):
+            b = rng.choice(256, flips[i], replace=False)
+            np.bitwise_xor.at(d[i], b >> 3, (1 << (b & 7)).astype(np.uint8))
+        mp["desc"][:n] = d
+    if n_extra:
+        mp["pos"][n:] = rng.uniform(-60, 60, (n_extra, 3)) + Ow
+        nrm = rng.normal(size=(n_extra, 3)); mp["normal"][n:] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+        md = rng.uniform(5, 120, n_extra)
+        mp["max_distance"][n:] = md; mp["min_distance"][n:] = md / sf ** (nl - 1)
+        mp["desc"][n:] = rng.integers(0, 256, (n_extra, 32), dtype=np.uint8)
+    mp["skip"] = rng.random(len(mp)) < 0.1
+    mp["observed"] = rng.random(len(mp)) < 0.8
+    return mp[rng.permutation(len(mp))]

@@ -29,7 +29,27 @@ struct MockMapPoint {
   int Observations() { return nObs; }
   cv::Mat GetDescriptor() { return desc.clone(); }
 };
+// float matrix stored in a cvlite byte Mat (rows x 4*cols bytes): what FloatRow() reads from a CV_32F cv::Mat
+static cv::Mat FloatMat(int rows, int cols, const float* v) {
+  cv::Mat m(rows, cols * 4, cv::CV_8U);
+  memcpy(m.data, v, sizeof(float) * rows * cols);
+  return m;
+}
+struct MockLocalPoint : MockMapPoint {
+  long unsigned int mnLastFrameSeen = 0;
+  float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 1}, minD = 0, maxD = 0;
+  int nVisible = 0;
+  cv::Mat GetWorldPos() { return FloatMat(3, 1, pos); }
+  cv::Mat GetNormal() { return FloatMat(3, 1, nrm); }
+  float GetMinDistance() { return minD; }
+  float GetMaxDistance() { return maxD; }
+  void IncreaseVisible(int n = 1) { nVisible += n; }
+};
 struct MockFrame {
+  long unsigned int mnId = 7;
+  cv::Mat mRcw, mtcw, mOw;
+  float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mfLogScaleFactor = 0;
+  int mnScaleLevels = 8;
   int N = 0;
   std::vector<cv::KeyPoint> mvKeysUn;
   cv::Mat mDescriptors;
@@ -37,6 +57,10 @@ struct MockFrame {
   std::vector<MockMapPoint*> mvpMapPoints;
   std::vector<float> mvScaleFactors;
   float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+};
+
+struct MockFrameL : MockFrame {
+  std::vector<MockLocalPoint*> mvpMapPoints;  // hides the base member: the adapter reads and writes this one
 };
 
 #define CHECK(c)                                                  \
@@ -192,6 +216,70 @@ int main(int argc, char** argv) {
   CHECK(nm == onm && nm > on / 4);
   for (int i = 0; i < on; i++) CHECK(F.mvpMapPoints[i] == (assigned[i] >= 0 ? vp[assigned[i]] : nullptr));
   CHECK(ORB_SLAM2::orbfe_host::DescriptorDistance(desc.ptr(0), desc.ptr(1)) == oo_descriptor_distance(desc.ptr(0), desc.ptr(1)));
+  {
+    // ---- Tracking::SearchLocalPoints through the adapter vs. the oracle
+    MockFrameL FL;
+    FL.N = on; FL.mvKeysUn = keys; FL.mDescriptors = desc; FL.mvuRight.assign(on, -1.f);
+    FL.mvpMapPoints.assign(on, nullptr); FL.mvScaleFactors = sf; FL.mnMaxX = (float)w; FL.mnMaxY = (float)h;
+    const float ca = cosf(0.1f), sa = sinf(0.1f);
+    const float R[9] = {ca, 0, sa, 0, 1, 0, -sa, 0, ca}, t[3] = {0.4f, -0.1f, 0.8f};
+    float Ow[3];
+    for (int r = 0; r < 3; r++) Ow[r] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
+    FL.mRcw = FloatMat(3, 3, R); FL.mtcw = FloatMat(3, 1, t); FL.mOw = FloatMat(3, 1, Ow);
+    FL.fx = 718.856f; FL.fy = 718.856f; FL.cx = 0.5f * w + 2.25f; FL.cy = 0.5f * h - 1.5f; FL.mbf = 386.1448f;
+    FL.mfLogScaleFactor = logf(1.2f);
+    oo_frustum ofr;
+    memset(&ofr, 0, sizeof(ofr));
+    memcpy(ofr.Rcw, R, sizeof(R)); memcpy(ofr.tcw, t, sizeof(t)); memcpy(ofr.Ow, Ow, sizeof(Ow));
+    ofr.fx = FL.fx; ofr.fy = FL.fy; ofr.cx = FL.cx; ofr.cy = FL.cy; ofr.mbf = FL.mbf;
+    ofr.max_x = (float)w; ofr.max_y = (float)h; ofr.log_scale_factor = FL.mfLogScaleFactor; ofr.n_levels = 8;
+    for (int l = 0; l < 8; l++) ofr.scale_factors[l] = sf[l];
+    std::vector<MockLocalPoint> lps(on);
+    std::vector<MockLocalPoint*> lvp(on);
+    std::vector<oo_map_point> omp(on);
+    for (int i = 0; i < on; i++) {
+      MockLocalPoint& p = lps[i];
+      const float z = 5.f + (float)(i % 23), u = keys[i].pt.x + 0.4f, v = keys[i].pt.y - 0.3f;
+      const float Xc[3] = {(u - FL.cx) * z / FL.fx - t[0], (v - FL.cy) * z / FL.fy - t[1], z - t[2]};
+      for (int r = 0; r < 3; r++) p.pos[r] = R[r] * Xc[0] + R[3 + r] * Xc[1] + R[6 + r] * Xc[2];  // R^T (Xc - t)
+      float PO[3], d2 = 0;
+      for (int r = 0; r < 3; r++) { PO[r] = p.pos[r] - Ow[r]; d2 += PO[r] * PO[r]; }
+      const float dist = sqrtf(d2);
+      for (int r = 0; r < 3; r++) p.nrm[r] = PO[r] / dist;
+      p.maxD = dist * powf(1.2f, (float)keys[i].octave - 0.4f);
+      p.minD = p.maxD / sf[7];
+      p.nObs = (i % 5) ? 2 : 0;
+      p.bad = (i % 29) == 0;
+      p.mnLastFrameSeen = (i % 13) ? 3 : FL.mnId;
+      p.mbTrackInView = true;  // stale value from an earlier frame
+      p.desc = desc.row(i).clone();
+      if (i % 2) p.desc.ptr(0)[i % 32] ^= 0x5a;
+      lvp[i] = &p;
+      oo_map_point& e = omp[i];
+      memset(&e, 0, sizeof(e));
+      e.skip = p.bad || p.mnLastFrameSeen == FL.mnId;
+      memcpy(e.pos, p.pos, 12); memcpy(e.normal, p.nrm, 12);
+      e.min_distance = p.minD; e.max_distance = p.maxD; e.observed = p.nObs > 0;
+      memcpy(e.desc, p.desc.ptr(0), 32);
+    }
+    int ntm = 0;
+    const int nml = ORB_SLAM2::orbfe_host::SearchLocalPoints(FL, lvp, 1.0f, 0.8f, &ntm);
+    std::vector<oo_track> otr(on);
+    std::vector<uint8_t> blk(on, 0);
+    std::vector<int32_t> asg(on, -1);
+    int ontm = 0;
+    const int onml = oo_search_local_points(&of, &ofr, omp.data(), on, 1.0f, 0.8f, otr.data(), blk.data(), asg.data(), &ontm);
+    CHECK(nml == onml && ntm == ontm && ntm > on / 2 && nml > on / 4);
+    for (int i = 0; i < on; i++) {
+      CHECK(FL.mvpMapPoints[i] == (asg[i] >= 0 ? lvp[asg[i]] : nullptr));
+      if (omp[i].skip) { CHECK(lps[i].nVisible == 0); continue; }
+      CHECK(lps[i].mbTrackInView == (otr[i].in_view != 0) && lps[i].nVisible == otr[i].in_view);
+      if (otr[i].in_view)
+        CHECK(lps[i].mTrackProjX == otr[i].proj_x && lps[i].mTrackProjY == otr[i].proj_y && lps[i].mTrackProjXR == otr[i].proj_xr &&
+              lps[i].mnTrackScaleLevel == otr[i].level && lps[i].mTrackViewCos == otr[i].view_cos);
+    }
+    printf("SearchLocalPoints ok: %d to match, %d matches\n", ntm, nml);
+  }
   oo_extractor_destroy(orc);
   delete ext;
   printf("dropin ok: %d keypoints, %d matches\n", on, nm);

@@ -26,6 +26,20 @@ QUERY_DTYPE = np.dtype(
 )
 assert QUERY_DTYPE.itemsize == 68
 
+FRUSTUM_DTYPE = np.dtype(
+    [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("Ow", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"),
+     ("cy", "<f4"), ("mbf", "<f4"), ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"),
+     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("scale_factors", "<f4", (8,))]
+)
+MAP_POINT_DTYPE = np.dtype(
+    [("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"), ("skip", "<i4"),
+     ("observed", "<i4"), ("desc", "u1", (32,))]
+)
+TRACK_DTYPE = np.dtype(
+    [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
+)
+assert FRUSTUM_DTYPE.itemsize == 136 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
+
 GRID_COLS, GRID_ROWS = 64, 48
 MAX_LEVELS = 16
 
@@ -105,6 +119,14 @@ def lib():
     L.oo_features_in_area.argtypes = [C.POINTER(OOFrame), cf, cf, cf, ci, ci, vp]
     L.oo_search_by_projection_points.restype = ci
     L.oo_search_by_projection_points.argtypes = [C.POINTER(OOFrame), vp, ci, cf, vp, vp]
+    L.oo_logf.restype = cf
+    L.oo_logf.argtypes = [cf]
+    L.oo_predict_scale.restype = ci
+    L.oo_predict_scale.argtypes = [cf, cf, cf, ci]
+    L.oo_is_in_frustum.restype = ci
+    L.oo_is_in_frustum.argtypes = [vp, vp, cf, vp]
+    L.oo_search_local_points.restype = ci
+    L.oo_search_local_points.argtypes = [C.POINTER(OOFrame), vp, vp, ci, cf, cf, vp, vp, vp, C.POINTER(C.c_int)]
     L.oo_search_by_projection_keyframe.restype = ci
     L.oo_search_by_projection_keyframe.argtypes = [C.POINTER(OOFrame), vp, ci, ci, ci, vp, vp]
     L.oo_search_by_projection_frame.restype = ci
@@ -319,6 +341,30 @@ def _kf(self, queries, check_orientation=True, orb_dist=100, blocked=None):
 
 
 OracleFrame.search_by_projection_keyframe = _kf
+
+
+def is_in_frustum(frustum, points, viewing_cos_limit=0.5):
+    fr = np.ascontiguousarray(frustum, FRUSTUM_DTYPE).reshape(1)
+    mp = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    track = np.zeros(len(mp), TRACK_DTYPE)
+    for i in range(len(mp)):
+        lib().oo_is_in_frustum(_p(fr), mp[i:i + 1].ctypes.data, viewing_cos_limit, track[i:i + 1].ctypes.data)
+    return track
+
+
+def _slp(self, frustum, points, th, nnratio, blocked=None):
+    fr = np.ascontiguousarray(frustum, FRUSTUM_DTYPE).reshape(1)
+    mp = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    track = np.zeros(len(mp), TRACK_DTYPE)
+    blocked = np.zeros(self.f.n, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+    assigned = np.full(self.f.n, -1, np.int32)
+    ntm = C.c_int(0)
+    nm = lib().oo_search_local_points(C.byref(self.f), _p(fr), _p(mp), len(mp), th, nnratio, _p(track), _p(blocked), _p(assigned),
+                                      C.byref(ntm))
+    return ntm.value, nm, track, assigned, blocked
+
+
+OracleFrame.search_local_points = _slp
 
 
 def search_for_initialization(keys1, desc1, frame2: "OracleFrame", prev_xy, window, nnratio, check_orientation=True):

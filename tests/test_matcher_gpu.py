@@ -71,9 +71,9 @@ def test_brute_force_best_second(nA, nB):
         assert (out[i]["best_idx"], out[i]["best_dist"], out[i]["second_dist"]) == (bi, b1, b2), i
 
 
-def _two_frames(w, h, nfeat, with_right=False):
+def _two_frames(w, h, nfeat, with_right=False, seed=5):
     ex = ORBextractor(nfeat)
-    seq = synth.sequence(w, h, 2, seq=5)
+    seq = synth.sequence(w, h, 2, seq=seed)
     (k0, d0), (k1, d1) = ex.extract_batch(seq)
     sf = ex.GetScaleFactors()
     ex.close()
@@ -142,6 +142,109 @@ def test_search_by_projection_frame(geom, th):
         np.testing.assert_array_equal(assigned, oassigned)
         np.testing.assert_array_equal(blocked, oblocked)
         assert nm > 0.3 * len(k1)
+
+
+def _frustum_and_map(k1, d1, w, h, seed, n_extra=500):
+    from refactored_orb_slam2_amd.matcher import make_frustum
+    from refactored_orb_slam2_amd import synth
+    R, t = synth.camera_pose(seed)
+    fr = make_frustum(R, t, 718.856, 718.856, w / 2 + 3.2, h / 2 - 1.7, 386.1448, (0, w, 0, h), 1.2, 8)
+    return fr, synth.local_map(k1, d1, fr, seed + 1, n_extra)
+
+
+@pytest.mark.parametrize("geom,th", [((1241, 376, 2000), 1.0), ((640, 480, 1000), 3.0), ((752, 480, 1200), 5.0)])
+def test_search_local_points(geom, th):
+    """Tracking::SearchLocalPoints: isInFrustum + PredictScale + SearchByProjection(F, points, th), queries built on the device"""
+    w, h, nf = geom
+    _, _, k1, d1, sf = _two_frames(w, h, nf)
+    rng = np.random.default_rng(31)
+    ur = np.where(rng.random(len(k1)) < 0.3, k1["x"] - np.float32(30.0) + rng.normal(0, 3, len(k1)).astype(np.float32), np.float32(-1)).astype(np.float32)
+    fr, mp = _frustum_and_map(k1, d1, w, h, 77)
+    blocked0 = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    fv = FrameView(k1, d1, 0, w, 0, h, ur)
+    of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, ur)
+    ntm, nm, track, assigned, blocked = ORBmatcher(0.8).SearchLocalPoints(fv, fr, mp, th, blocked0)
+    ontm, onm, otrack, oassigned, oblocked = of.search_local_points(fr, mp, np.float32(th), np.float32(0.8), blocked0)
+    assert track.tobytes() == otrack.tobytes()          # u, v, u_r, level, viewCos bit for bit
+    assert ntm == ontm and nm == onm
+    np.testing.assert_array_equal(assigned, oassigned)
+    np.testing.assert_array_equal(blocked, oblocked)
+    # the synthetic map exercises every rejection branch and the level clamp
+    assert 0.3 * len(mp) < ntm < 0.9 * len(mp) and nm > 0.2 * len(k1)
+    assert len(np.unique(track["level"][track["in_view"] == 1])) == 8
+
+
+def test_search_local_points_edge_cases():
+    w, h = 640, 480
+    _, _, k1, d1, sf = _two_frames(w, h, 1000)
+    fr, mp = _frustum_and_map(k1, d1, w, h, 5, n_extra=50)
+    fv = FrameView(k1, d1, 0, w, 0, h)
+    of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, None)
+    m = ORBmatcher(0.8)
+    # no points / all skipped / nothing in view
+    assert m.SearchLocalPoints(fv, fr, mp[:0])[:2] == (0, 0)
+    sk = mp.copy(); sk["skip"] = 1
+    r = m.SearchLocalPoints(fv, fr, sk)
+    assert r[:2] == (0, 0) and not r[2]["in_view"].any() and np.all(r[3] == -1)
+    # degenerate geometry: dist == 0 with min_distance 0, max_distance 0 / inf / nan, point on the camera plane
+    deg = mp[:8].copy(); deg["skip"] = 0
+    deg["pos"][0] = fr["Ow"][0]; deg["min_distance"][0] = 0
+    deg["max_distance"][1] = 0; deg["min_distance"][1] = 0
+    deg["max_distance"][2] = np.inf
+    deg["max_distance"][3] = np.nan
+    deg["normal"][4] = 0
+    got = m.SearchLocalPoints(fv, fr, deg)
+    exp = of.search_local_points(fr, deg, np.float32(1.0), np.float32(0.8))
+    assert got[2].tobytes() == exp[2].tobytes() and got[0] == exp[0] and got[1] == exp[1]
+    # a frame without keypoints still gets its track records
+    fv0 = FrameView(k1[:0], d1[:0], 0, w, 0, h)
+    of0 = ol.OracleFrame(k1[:0], d1[:0], sf, 0, w, 0, h, None)
+    got = m.SearchLocalPoints(fv0, fr, mp)
+    exp = of0.search_local_points(fr, mp, np.float32(1.0), np.float32(0.8))
+    assert got[2].tobytes() == exp[2].tobytes() and got[0] == exp[0] > 0 and got[1] == 0
+
+
+def test_search_local_points_batch_device():
+    """batched form: per-frame pose and map, everything resident in HBM, on a caller stream"""
+    import torch
+    from refactored_orb_slam2_amd.matcher import Matcher
+    from refactored_orb_slam2_amd._lib import TRACK_DTYPE
+    w, h, F = 752, 480, 3
+    frames = [_two_frames(w, h, 1200, seed=s)[2:] for s in range(F)]
+    cap = max(len(f[0]) for f in frames) + 5
+    maps, frs = [], []
+    for i, (k1, d1, sf) in enumerate(frames):
+        fr, mp = _frustum_and_map(k1, d1, w, h, 100 + i, n_extra=300 + 100 * i)
+        maps.append(mp); frs.append(fr)
+    pcap = max(len(m) for m in maps) + 3
+    kps = np.zeros((F, cap), ol.KP_DTYPE); desc = np.zeros((F, cap, 32), np.uint8); n = np.zeros(F, np.int32)
+    pts = np.zeros((F, pcap), maps[0].dtype); npts = np.zeros(F, np.int32)
+    for i, (k1, d1, sf) in enumerate(frames):
+        kps[i, :len(k1)] = k1; desc[i, :len(k1)] = d1; n[i] = len(k1)
+        pts[i, :len(maps[i])] = maps[i]; npts[i] = len(maps[i])
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape + (-1,)) if a.dtype.names else a).cuda()
+    t_kps, t_desc, t_n, t_pts, t_np = dev(kps), dev(desc), dev(n), dev(pts), dev(npts)
+    t_fr = dev(np.concatenate(frs))
+    t_track = torch.zeros((F, pcap, 24), dtype=torch.uint8, device="cuda")
+    t_blocked = torch.zeros((F, cap), dtype=torch.uint8, device="cuda")
+    t_assigned = torch.full((F, cap), -1, dtype=torch.int32, device="cuda")
+    t_ntm = torch.zeros(F, dtype=torch.int32, device="cuda"); t_nm = torch.zeros(F, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    m = Matcher()
+    with torch.cuda.stream(s):
+        m.search_local_points_batch(t_kps, t_desc, t_n, None, (0, w, 0, h), t_fr, t_pts, t_np, 1.0, 0.8, t_track, t_blocked,
+                                    t_assigned, t_ntm, t_nm, stream=s)
+    s.synchronize()
+    for i, (k1, d1, sf) in enumerate(frames):
+        of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, None)
+        ontm, onm, otrack, oassigned, oblocked = of.search_local_points(frs[i], maps[i], np.float32(1.0), np.float32(0.8))
+        gtrack = t_track[i].cpu().numpy().reshape(-1).view(TRACK_DTYPE)[: len(maps[i])]
+        assert gtrack.tobytes() == otrack.tobytes()
+        assert int(t_ntm[i]) == ontm and int(t_nm[i]) == onm and onm > 100
+        np.testing.assert_array_equal(t_assigned[i].cpu().numpy()[: len(k1)], oassigned)
+        np.testing.assert_array_equal(t_blocked[i].cpu().numpy()[: len(k1)], oblocked)
+    m.close()
 
 
 @pytest.mark.parametrize("th,orb_dist", [(10.0, 100), (3.0, 64), (10.0, 30)])

@@ -67,6 +67,100 @@ def test_restated_sincos_equals_libm_exhaustively(tmp_path):
     assert int(n) > 1_000_000_000 and int(bad) == 0 and r.returncode == 0
 
 
+def test_restated_logf_equals_libm_exhaustively(tmp_path):
+    """every positive normal float: oo_logf == libm logf, bit for bit (MapPoint::PredictScale's log)"""
+    exe = str(tmp_path / "lf")
+    lib = ol.build()
+    subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(os.path.dirname(__file__), "c", "logf_exhaustive.c"), lib, "-lm"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, env={**os.environ, "LD_LIBRARY_PATH": os.path.dirname(lib)})
+    n, bad = r.stdout.split()
+    assert int(n) == 0x7f7fffff - 0x00800000 + 1 and int(bad) == 0 and r.returncode == 0
+
+
+def _test_frustum(w=640, h=480):
+    fr = np.zeros(1, ol.FRUSTUM_DTYPE)
+    fr["Rcw"][0] = np.eye(3, dtype=np.float32).reshape(9)
+    fr["fx"] = 500; fr["fy"] = 500; fr["cx"] = 320; fr["cy"] = 240; fr["mbf"] = 40
+    fr["min_x"] = 0; fr["max_x"] = w; fr["min_y"] = 0; fr["max_y"] = h
+    fr["log_scale_factor"] = ol.lib().oo_logf(np.float32(1.2)); fr["n_levels"] = 8
+    fr["scale_factors"][0] = np.cumprod(np.r_[1, [np.float32(1.2)] * 7]).astype(np.float32)
+    return fr
+
+
+def test_is_in_frustum_known_answers():
+    """Frame::isInFrustum (Frame.cc:284-339) on hand-computable cases: identity pose, camera at the origin"""
+    fr = _test_frustum()
+    mp = np.zeros(8, ol.MAP_POINT_DTYPE)
+    mp["normal"] = [0, 0, 1]; mp["min_distance"] = 1; mp["max_distance"] = 20
+    mp["pos"][0] = [0, 0, 10]        # on the axis: u = cx, v = cy, viewCos = 1, ratio 2 -> ceil(ln 2 / ln 1.2) = 4
+    mp["pos"][1] = [0, 0, -1]        # behind the camera
+    mp["pos"][2] = [7, 0, 10]        # u = 670 > 640
+    mp["pos"][3] = [0, -5, 10]       # v = -10 < 0
+    mp["pos"][4] = [0, 0, 0.7]       # dist 0.7 < 0.8 * 1
+    mp["pos"][5] = [0, 0, 24.5]      # dist 24.5 > 1.2 * 20
+    mp["pos"][6] = [0, 0, 10]; mp["normal"][6] = [np.sin(1.1), 0, np.cos(1.1)]   # viewCos = cos(1.1) = 0.4536 < 0.5
+    mp["pos"][7] = [1, 2, 24]; mp["max_distance"][7] = 20.1                      # ratio < 1 -> level 0 (clamped)
+    tr = ol.is_in_frustum(fr, mp)
+    assert tr["in_view"].tolist() == [1, 0, 0, 0, 0, 0, 0, 1]
+    assert (tr["proj_x"][0], tr["proj_y"][0], tr["proj_xr"][0], tr["level"][0], tr["view_cos"][0]) == (320.0, 240.0, 316.0, 4, 1.0)
+    assert tr["level"][7] == 0
+    inv = np.float32(1) / np.float32(24)
+    assert tr["proj_x"][7] == np.float32(np.float32(np.float32(500) * np.float32(1)) * inv) + np.float32(320)
+    assert tr["proj_xr"][7] == tr["proj_x"][7] - np.float32(40) * inv
+    # level clamp at the top: ratio 1.2^9
+    mp["pos"][0] = [0, 0, 1]; mp["max_distance"][0] = 1.2 ** 9; mp["min_distance"][0] = 0.1
+    assert ol.is_in_frustum(fr, mp[:1])["level"][0] == 7
+    # PredictScale on exact powers: logf(ratio)/logf(1.2) evaluated in float, then ceilf
+    for k in range(8):
+        ratio = np.float32(1.2) ** np.float32(k)
+        lvl = ol.lib().oo_predict_scale(ratio, np.float32(1.0), fr["log_scale_factor"][0], 8)
+        exp = int(np.ceil(np.float32(ol.lib().oo_logf(ratio)) / fr["log_scale_factor"][0]))
+        assert lvl == min(max(exp, 0), 7) and abs(lvl - k) <= 1
+
+
+def test_is_in_frustum_vs_numpy_restatement():
+    """independent numpy restatement of the cv::Mat arithmetic (float gemm, double norm / dot)"""
+    rng = np.random.default_rng(12)
+    fr = _test_frustum()
+    a = 0.2
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    t = np.array([0.3, -0.2, 1.5], np.float32)
+    fr["Rcw"][0] = R.reshape(9); fr["tcw"][0] = t
+    fr["Ow"][0] = -(R.T.astype(np.float64) @ t).astype(np.float32)
+    n = 4000
+    mp = np.zeros(n, ol.MAP_POINT_DTYPE)
+    mp["pos"] = rng.uniform(-15, 15, (n, 3)) + [0, 0, 12]
+    nrm = rng.normal(size=(n, 3)) + [0, 0, 2.0]; mp["normal"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    mp["max_distance"] = rng.uniform(3, 60, n); mp["min_distance"] = mp["max_distance"] / np.float32(1.2 ** 7)
+    tr = ol.is_in_frustum(fr, mp)
+    f32, f64 = np.float32, np.float64
+    P = mp["pos"]
+    Pc = np.empty((n, 3), f32)
+    for r in range(3):
+        tt = f32(f32(R[r, 0] * P[:, 0]) + f32(R[r, 1] * P[:, 1])) + f32(R[r, 2] * P[:, 2])
+        Pc[:, r] = (tt.astype(f64) + f64(t[r])).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invz = f32(1) / Pc[:, 2]
+        u = f32(f32(fr["fx"][0] * Pc[:, 0]) * invz) + fr["cx"][0]
+        v = f32(f32(fr["fy"][0] * Pc[:, 1]) * invz) + fr["cy"][0]
+        PO = P - fr["Ow"][0]
+        s = (PO[:, 0].astype(f64) ** 2 + PO[:, 1].astype(f64) ** 2) + PO[:, 2].astype(f64) ** 2
+        dist = np.sqrt(s).astype(f32)
+        N = mp["normal"]
+        dot = (PO[:, 0].astype(f64) * N[:, 0] + PO[:, 1].astype(f64) * N[:, 1]) + PO[:, 2].astype(f64) * N[:, 2]
+        vc = (dot / dist.astype(f64)).astype(f32)
+    ok = (~(Pc[:, 2] < 0) & ~(u < 0) & ~(u > 640) & ~(v < 0) & ~(v > 480) & ~(dist < f32(0.8) * mp["min_distance"])
+          & ~(dist > f32(1.2) * mp["max_distance"]) & ~(vc < f32(0.5)))
+    np.testing.assert_array_equal(tr["in_view"] != 0, ok)
+    assert 200 < ok.sum() < 3000
+    np.testing.assert_array_equal(tr["proj_x"][ok], u[ok]); np.testing.assert_array_equal(tr["proj_y"][ok], v[ok])
+    np.testing.assert_array_equal(tr["proj_xr"][ok], (u - f32(fr["mbf"][0] * invz))[ok])
+    np.testing.assert_array_equal(tr["view_cos"][ok], vc[ok])
+    lv = np.log(mp["max_distance"][ok].astype(f64) / dist[ok]) / np.log(1.2)
+    sure = np.abs(lv - np.round(lv)) > 1e-4
+    np.testing.assert_array_equal(tr["level"][ok][sure], np.clip(np.ceil(lv[sure]), 0, 7).astype(np.int32))
+
+
 @pytest.mark.parametrize("seed,shape", [(1, (97, 131)), (2, (61, 300)), (3, (240, 33))])
 def test_primitives_vs_numpy_restatement(seed, shape):
     rng = np.random.default_rng(seed)
