@@ -337,6 +337,9 @@ int orbfe_vocabulary_create(int k, int L, int scoring, int weighting, int n_node
                             orbfe_vocabulary** out);
 /* ORBVocabulary::loadFromTextFile (L/src/ORBVocabulary.cc:11-127), the ORBvoc.txt format. */
 int orbfe_vocabulary_load_text(const char* path, int device, orbfe_vocabulary** out);
+/* ORBVocabulary::loadFromBinaryFile (L/src/ORBVocabulary.cc:152-213): the format of saveToBinaryFile (:217-243), float
+ * weights, including the duplicate of the last node the reference's eof loop appends. */
+int orbfe_vocabulary_load_binary(const char* path, int device, orbfe_vocabulary** out);
 int orbfe_vocabulary_destroy(orbfe_vocabulary* v);
 int orbfe_vocabulary_info(const orbfe_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words);
 /* Tree descent only, DEVICE pointers, asynchronous: per descriptor the word id, the node at level L - levelsup and

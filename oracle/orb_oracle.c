@@ -1478,6 +1478,39 @@ oo_vocab* oo_vocab_load_text(const char* path) {
   return v;
 }
 
+/* ORBVocabulary::loadFromBinaryFile: L/src/ORBVocabulary.cc:152-213.  m_nodes is sized nb_nodes + 1 (:167) and the
+ * `while (!f.eof())` loop (:185) body runs nb_nodes times for the nb_nodes - 1 records saveToBinaryFile wrote (:231): the
+ * last pass re-uses the unchanged buffer, i.e. node nb_nodes is a copy of node nb_nodes - 1. */
+oo_vocab* oo_vocab_load_binary(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return NULL;
+  unsigned int nb_nodes, size_node;
+  int m_k, m_L, m_scoring, m_weighting;
+  if (fread(&nb_nodes, 4, 1, f) != 1 || fread(&size_node, 4, 1, f) != 1 || fread(&m_k, 4, 1, f) != 1 ||
+      fread(&m_L, 4, 1, f) != 1 || fread(&m_scoring, 4, 1, f) != 1 || fread(&m_weighting, 4, 1, f) != 1 ||
+      size_node < 41 || size_node > 4096) { fclose(f); return NULL; }
+  const int cap = (int)nb_nodes + 1;
+  int32_t* parent = (int32_t*)calloc(cap, sizeof(int32_t));
+  uint8_t* leaf = (uint8_t*)calloc(cap, 1);
+  uint8_t* desc = (uint8_t*)calloc((size_t)cap, 32);
+  double* weight = (double*)calloc(cap, sizeof(double));
+  char* buf = (char*)calloc(size_node, 1);
+  int nid = 1, at_eof = 0;
+  while (!at_eof && nid < cap) {
+    if (fread(buf, 1, size_node, f) != size_node) at_eof = 1;   /* f.read fails, buf keeps the previous record */
+    if (at_eof && nid == 1) break;
+    parent[nid] = *(const int*)buf;
+    memcpy(desc + (size_t)nid * 32, buf + 4, 32);
+    weight[nid] = (double)*(const float*)(buf + 4 + 32);
+    leaf[nid] = buf[8 + 32] != 0;
+    nid++;
+  }
+  fclose(f);
+  oo_vocab* v = oo_vocab_create(m_k, m_L, m_scoring, m_weighting, nid, parent, leaf, desc, weight);
+  free(parent); free(leaf); free(desc); free(weight); free(buf);
+  return v;
+}
+
 void oo_vocab_destroy(oo_vocab* v) {
   if (!v) return;
   free(v->parent); free(v->child_start); free(v->child_idx); free(v->desc); free(v->weight); free(v->word_id);

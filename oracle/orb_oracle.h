@@ -225,6 +225,7 @@ typedef struct oo_vocab oo_vocab;
 oo_vocab* oo_vocab_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
                           const uint8_t* is_leaf, const uint8_t* desc, const double* weight);
 oo_vocab* oo_vocab_load_text(const char* path);
+oo_vocab* oo_vocab_load_binary(const char* path);  /* ORBVocabulary.cc:152-213, incl. the node its eof loop duplicates */
 void oo_vocab_destroy(oo_vocab* v);
 int oo_vocab_nodes(const oo_vocab* v);
 int oo_vocab_words(const oo_vocab* v);

@@ -75,7 +75,7 @@ EXPORTS = [
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
     "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
     "orbfe_search_local_points_batch_device",
-    "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
+    "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow",
 ]
 
@@ -152,6 +152,7 @@ def lib():
     L.orbfe_search_by_projection_keyframe.argtypes = [C.POINTER(FrameView), vp, ci, ci, ci, vp, vp, pi]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, ci, C.POINTER(vp)]
+    L.orbfe_vocabulary_load_binary.argtypes = [C.c_char_p, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_destroy.argtypes = [vp]
     L.orbfe_vocabulary_info.argtypes = [vp, pi, pi, pi, pi]
     L.orbfe_bow_transform_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]

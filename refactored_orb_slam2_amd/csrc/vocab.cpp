@@ -138,6 +138,57 @@ extern "C" int orbfe_vocabulary_load_text(const char* path, int device, orbfe_vo
                                  device, out);
 }
 
+// ORBVocabulary::loadFromBinaryFile (L/src/ORBVocabulary.cc:152-213), the format saveToBinaryFile writes (:217-243):
+// u32 nb_nodes (root included), u32 size_node, i32 k, i32 L, i32 scoring, i32 weighting, then nb_nodes-1 records
+// {u32 parent, u8 desc[32], f32 weight, u8 is_leaf}.  The reference's `while (!f.eof())` loop runs once more after the
+// last record with the buffer unchanged, which appends a duplicate of the last node (same parent, descriptor, weight;
+// one more word when it is a leaf); it can never win a descent (strict `<` against its twin, visited first) but it is
+// part of m_nodes / m_words, so it is reproduced here.
+extern "C" int orbfe_vocabulary_load_binary(const char* path, int device, orbfe_vocabulary** out) {
+  if (!path || !out) return ORBFE_ERR_INVALID;
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    orbfe_set_error("cannot open vocabulary %s", path);
+    return ORBFE_ERR_INVALID;
+  }
+  uint32_t hdr[2];
+  int32_t kl[4];
+  if (fread(hdr, 4, 2, f) != 2 || fread(kl, 4, 4, f) != 4 || hdr[1] < 41 || hdr[1] > 4096 || kl[0] < 0 || kl[0] > 20 ||
+      kl[1] < 1 || kl[1] > 10) {
+    fclose(f);
+    orbfe_set_error("Vocabulary loading failure: This is not a correct binary file!");
+    return ORBFE_ERR_INVALID;
+  }
+  const uint32_t size_node = hdr[1];
+  std::vector<int32_t> parent(1, 0);
+  std::vector<uint8_t> leaf(1, 0), desc(32, 0), buf(size_node);
+  std::vector<double> weight(1, 0.0);
+  bool any = false;
+  for (;;) {
+    const bool got = fread(buf.data(), 1, size_node, f) == size_node;
+    if (!got && !any) break;  // no record at all: nothing to duplicate
+    int32_t pid;
+    float w;
+    memcpy(&pid, buf.data(), 4);
+    memcpy(&w, buf.data() + 36, 4);
+    if (pid < 0 || pid >= (int32_t)parent.size()) {
+      fclose(f);
+      orbfe_set_error("binary vocabulary: node %zu has parent %d", parent.size(), pid);
+      return ORBFE_ERR_INVALID;
+    }
+    parent.push_back(pid);
+    desc.insert(desc.end(), buf.begin() + 4, buf.begin() + 36);
+    weight.push_back((double)w);
+    leaf.push_back(buf[40] != 0);
+    any = true;
+    if (!got) break;  // that was the duplicate the reference's eof loop creates
+  }
+  fclose(f);
+  return orbfe_vocabulary_create(kl[0], kl[1], kl[2], kl[3], (int)parent.size(), parent.data(), leaf.data(), desc.data(),
+                                 weight.data(), device, out);
+}
+
 extern "C" int orbfe_vocabulary_destroy(orbfe_vocabulary* v) {
   if (!v) return ORBFE_OK;
   (void)hipSetDevice(v->device);

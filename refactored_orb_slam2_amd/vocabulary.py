@@ -34,6 +34,15 @@ class ORBVocabulary:
         _lib.check(rc, "orbfe_vocabulary_load_text")
         return True
 
+    def loadFromBinaryFile(self, filename: str, device: int = -1) -> bool:
+        """ORBVocabulary::loadFromBinaryFile (ORBVocabulary.cc:152-213)"""
+        self.close()
+        rc = self._L.orbfe_vocabulary_load_binary(filename.encode(), device, C.byref(self._h))
+        if rc == _lib.ERR_INVALID:
+            return False
+        _lib.check(rc, "orbfe_vocabulary_load_binary")
+        return True
+
     @classmethod
     def from_arrays(cls, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0, device=-1):
         v = cls()

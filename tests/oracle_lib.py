@@ -143,6 +143,7 @@ def lib():
                                             C.POINTER(OOPyramidView), vp, vp, cf, cf, vp, vp]
     L.oo_vocab_create.restype = vp; L.oo_vocab_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp]
     L.oo_vocab_load_text.restype = vp; L.oo_vocab_load_text.argtypes = [C.c_char_p]
+    L.oo_vocab_load_binary.restype = vp; L.oo_vocab_load_binary.argtypes = [C.c_char_p]
     L.oo_vocab_destroy.argtypes = [vp]
     L.oo_vocab_nodes.restype = ci; L.oo_vocab_nodes.argtypes = [vp]
     L.oo_vocab_words.restype = ci; L.oo_vocab_words.argtypes = [vp]
@@ -452,6 +453,10 @@ class OracleVocabulary:
         return cls(lib().oo_vocab_load_text(path.encode()))
 
     @classmethod
+    def load_binary(cls, path):
+        return cls(lib().oo_vocab_load_binary(path.encode()))
+
+    @classmethod
     def from_arrays(cls, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0):
         parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
         desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
@@ -506,6 +511,16 @@ def synthetic_vocabulary(k=10, L=3, seed=0, stop_fraction=0.05, ragged=False):
     weight = np.where(leaf > 0, rng.uniform(0.5, 9.0, n), 0.0)
     weight[(rng.random(n) < stop_fraction) & (leaf > 0)] = 0.0  # stopped words
     return np.array(parent, np.int32), leaf, desc, weight
+
+
+def write_vocabulary_binary(path, k, L, parent, leaf, desc, weight, scoring=0, weighting=0):
+    """what ORBVocabulary::saveToBinaryFile writes (ORBVocabulary.cc:217-243)"""
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIiiii", len(parent), 4 + 32 + 4 + 1, k, L, scoring, weighting))
+        for i in range(1, len(parent)):
+            f.write(struct.pack("<I", int(parent[i])) + bytes(np.asarray(desc[i], np.uint8)) + struct.pack("<f", float(weight[i])) +
+                    struct.pack("<?", bool(leaf[i])))
 
 
 def write_vocabulary_text(path, k, L, parent, leaf, desc, weight, scoring=0, weighting=0):

@@ -541,6 +541,19 @@ def test_compute_bow_transform(tmp_path, k, L, ragged, weighting, scoring):
     assert nm == onm and np.array_equal(mB, omB)
     assert not ORBVocabulary().loadFromTextFile(str(tmp_path / "missing.txt"))
     voc.close()
+    # ---- loadFromBinaryFile: float weights and the duplicated last node of the reference's eof loop
+    bpath = str(tmp_path / "voc.bin")
+    ol.write_vocabulary_binary(bpath, k, L, parent, leaf, vdesc, weight, scoring, weighting)
+    vb = ORBVocabulary()
+    assert vb.loadFromBinaryFile(bpath)
+    ob = ol.OracleVocabulary.load_binary(bpath)
+    assert vb.info()[2:] == ob.info() == (len(parent) + 1, int(leaf.sum()) + int(leaf[-1]))
+    bow, fv, (w, nd, wt) = vb.transform(d, 4)
+    obow, ofv, (ow, ond, owt) = ob.transform(d, 4)
+    np.testing.assert_array_equal(w, ow); np.testing.assert_array_equal(nd, ond); np.testing.assert_array_equal(wt, owt)
+    assert bow == obow and fv == ofv
+    assert not ORBVocabulary().loadFromBinaryFile(str(tmp_path / "missing.bin"))
+    vb.close()
 
 
 def test_sequence_driver_on_kitti_layout(tmp_path):

@@ -305,6 +305,16 @@ def test_vocabulary_transform_hand_example(tmp_path):
     assert fv == {1: [0, 1, 2, 4], 2: [3]}
     bow0, fv0, _ = v.transform(feats, levelsup=2)      # L - levelsup = 0 -> everything under the root
     assert fv0 == {0: [0, 1, 2, 3, 4]} and bow0 == bow
+    # binary format (ORBVocabulary.cc:152-243): float weights; the loader's eof loop appends a copy of the last node
+    bpath = str(tmp_path / "v.bin")
+    wb = [0.0, 0.0, 0.0, 2.1, 3.3, 5.7, 0.0]
+    ol.write_vocabulary_binary(bpath, 2, 2, parent, leaf, desc, wb)
+    assert os.path.getsize(bpath) == 24 + 6 * 41
+    vb = ol.OracleVocabulary.load_binary(bpath)
+    assert vb.info() == (8, 5)                                     # 7 nodes + the duplicate, 4 words + its word
+    _, fvb, (wbw, _, wbt) = vb.transform(feats, levelsup=1)
+    assert wbw.tolist() == [0, 0, 1, 2, 0] and fvb == fv           # the duplicate (a twin of n6) never wins a descent
+    assert wbt.tolist() == [float(np.float32(x)) for x in (2.1, 2.1, 3.3, 5.7, 2.1)]
     half = np.zeros((1, 32), np.uint8); half[0, :22] = 255   # n2 (80 < 112), then n6 (48 < 80): the stopped word -> dropped
     bow1, fv1, (w1, _, wt1) = v.transform(np.concatenate([feats, half]), 1)
     assert w1[-1] == 3 and wt1[-1] == 0 and fv1 == fv and bow1 == bow
