@@ -348,6 +348,225 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const Cell
   if (tid == 0) cell_cnt[(size_t)img * total_cells + cell_id] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
 }
 
+// Grouped form of fast_cells_kernel: one workgroup per (run of <= 4 horizontally adjacent cells, image).  The per-pixel
+// work (quick reject, exact score) does not depend on the cell, so it runs once over the union ROI; the cell only
+// matters for the NMS neighbourhood (cv::FAST sees one cell's ROI: neighbours in another cell's tested region count as
+// 0), the two-threshold rule and the output slots.  Versus one cell per workgroup this amortises the prologue, the
+// staging and the emission scan (which was a 4-wave block scan per cell; here one wave per cell, no barrier).
+//   A1  quick reject, min/max form: a 9-arc contains a pixel of every antipodal pair, so a dark corner needs
+//       max_k min(q_k, q_k+8) < v - t over the 4 even pairs, a bright one min_k max(q_k, q_k+8) > v + t
+//   A2  exact cornerScore for the survivors;  B  per-cell strict 3x3 NMS -> bitmasks;  C  ordered emission per cell
+// 16-bit VOP2 min / max issue at twice the rate of their 32-bit forms on gfx950 (tools/valu_bench.hip).  Operands are
+// 32-bit containers whose low halves hold the value (gfx9 16-bit ops zero the high half of the destination).
+__device__ __forceinline__ unsigned min16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned max16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned mini16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned maxi16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// cornerScore<16> with 16-bit signed min / max: d[k] holds (v - q_k) in its low 16 bits (|d| <= 255)
+__device__ __forceinline__ int corner_score16_h(const unsigned d[16]) {
+  unsigned lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo2[i] = mini16(d[i], d[(i + 1) & 15]);
+    hi2[i] = maxi16(d[i], d[(i + 1) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo4[i] = mini16(lo2[i], lo2[(i + 2) & 15]);
+    hi4[i] = maxi16(hi2[i], hi2[(i + 2) & 15]);
+  }
+  unsigned A = 0x8000u, B = 0x7fffu;  // INT16_MIN, INT16_MAX
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const unsigned lo9 = mini16(mini16(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const unsigned hi9 = maxi16(maxi16(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+    A = maxi16(A, lo9);   // dark arc:   all (v - p) >= lo9
+    B = mini16(B, hi9);   // bright arc: all (p - v) >= -hi9
+  }
+  const int a = (int)(short)(A & 0xffffu), bneg = -(int)(short)(B & 0xffffu);
+  return max(a, bneg) - 1;
+}
+#define FG_THREADS 512
+__global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
+                                                            const FastGroup* __restrict__ groups, int n_groups,
+                                                            int total_cells, int tile_rows, int clist_cap,
+                                                            int32_t* __restrict__ cell_cnt, uint32_t* __restrict__ slots,
+                                                            unsigned long long slots_per_image, int ini_th, int min_th,
+                                                            int xcd_run_shift) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fg_smem[];
+  __shared__ int nlist;
+  uint8_t* tile = fg_smem;
+  uint8_t* sc = tile + tile_rows * ORBFE_FG_PITCH;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(sc + tile_rows * ORBFE_FG_PITCH);  // [cell][all 128 | hi 128]
+  uint16_t* clist = reinterpret_cast<uint16_t*>(bits + ORBFE_FG_MAX * 256);
+
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid >> 6;
+  const int img = blockIdx.y;
+  const int q = blockIdx.x >> 3;
+  const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
+  const int gid = (xcd_run_shift < 0 || (int)blockIdx.x >= (n_groups / unit) * unit)
+                      ? (int)blockIdx.x
+                      : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
+                            (q & ((1 << xcd_run_shift) - 1));
+  const FastGroup g = groups[gid];
+  const int pitch = pyr.pitch[g.level];
+  const uint8_t* plane = pyr.base[g.level] + (size_t)img * pyr.img_stride[g.level];
+  const int width = g.width, rows = g.rows, wcell = g.wcell, ncell = g.n_cells;
+  const int ax = g.x0 & ~15, xo = g.x0 & 15;
+  const int ndq = (xo + width + 15) >> 4;  // 16-byte columns, <= 12 (plane base, pitch and ax are 16-byte aligned)
+
+  if (tid == 0) nlist = 0;
+  for (int i = tid; i < ORBFE_FG_MAX * 256; i += FG_THREADS) bits[i] = 0;
+  {
+    // clear the score plane, then stage the ROI with 16-byte loads: thread -> (row r0 + k*rpp, column c), one division
+    uint4* s128 = reinterpret_cast<uint4*>(sc);
+    for (int i = tid; i < rows * (ORBFE_FG_PITCH / 16); i += FG_THREADS) s128[i] = make_uint4(0, 0, 0, 0);
+    const int rpp = FG_THREADS / ndq;  // rows per pass (>= 42)
+    const int r0 = (int)((tid + 0.5f) * (1.0f / (float)ndq));
+    const int c = tid - r0 * ndq;
+    if (r0 < rpp) {
+      const uint8_t* src = plane + (size_t)g.y0 * pitch + ax + 16 * c;
+      uint4* dst = reinterpret_cast<uint4*>(tile) + c;
+      uint4 v[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {   // rows <= 66 < 2 * rpp
+        const int rr = r0 + k * rpp;
+        v[k] = rr < rows ? *reinterpret_cast<const uint4*>(src + (size_t)rr * pitch) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int rr = r0 + k * rpp;
+        if (rr < rows) dst[rr * (ORBFE_FG_PITCH / 16)] = v[k];
+      }
+    }
+  }
+  __syncthreads();
+
+  const int tw = width - 6, th = rows - 6;  // tested region of the group: [3, width-3) x [3, rows-3)
+  const int npix = (tw > 0 && th > 0) ? tw * th : 0;
+  const uint8_t* T = tile + xo;
+
+  // ---- A1 (flattened over the tested region; the index advances without divisions).  Scalar bytes on purpose: on
+  // gfx950 v_pk_*16 / v_perm_b32 / min / max all issue at 16 lanes per clock, the same as their scalar forms, so a packed
+  // two-pixels-per-lane variant (tried: 78 VALU per 4 pixels) was slower than this one (tools/valu_bench.hip).
+  {
+    int ty = (int)((tid + 0.5f) * (1.0f / (float)(tw > 0 ? tw : 1)));
+    int tx = tid - ty * tw;
+    const int sa = FG_THREADS / (tw > 0 ? tw : 1), sb = FG_THREADS - sa * tw;
+    typedef unsigned u16;  // 32-bit container, value in the low half
+    // (processing two pixels per iteration with all 18 LDS reads up front was measured slower: the phase is bound by
+    // VALU / SALU issue, not by LDS latency)
+    for (int p = tid; p < npix; p += FG_THREADS) {
+      const int x = tx + 3, y = ty + 3;
+      const uint8_t* c = T + y * ORBFE_FG_PITCH + x;
+      const int v = c[0];
+      const u16 q0 = c[3 * ORBFE_FG_PITCH], q8 = c[-3 * ORBFE_FG_PITCH];
+      const u16 q2 = c[2 * ORBFE_FG_PITCH + 2], q10 = c[-2 * ORBFE_FG_PITCH - 2];
+      const u16 q4 = c[3], q12 = c[-3];
+      const u16 q6 = c[-2 * ORBFE_FG_PITCH + 2], q14 = c[2 * ORBFE_FG_PITCH - 2];
+      const u16 d01 = max16(min16(q0, q8), min16(q2, q10)), d23 = max16(min16(q4, q12), min16(q6, q14));
+      const u16 b01 = min16(max16(q0, q8), max16(q2, q10)), b23 = min16(max16(q4, q12), max16(q6, q14));
+      const int dm = (int)max16(d01, d23), bm = (int)min16(b01, b23);
+      if (dm < v - min_th || bm > v + min_th) {
+        const int idx = atomicAdd(&nlist, 1);
+        if (idx < clist_cap) clist[idx] = (uint16_t)((y << 8) | x);
+      }
+      tx += sb; ty += sa;
+      while (tx >= tw) { tx -= tw; ty++; }
+    }
+  }
+  __syncthreads();
+
+  // ---- A2: exact score of the survivors
+  const int nl = min(nlist, clist_cap);
+  for (int i = tid; i < nl; i += FG_THREADS) {
+    const int e = clist[i];
+    const int x = e & 0xff, y = e >> 8;
+    const uint8_t* c = T + y * ORBFE_FG_PITCH + x;
+    const int v = c[0];
+    unsigned d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = (unsigned)(v - (int)c[RDY[k] * ORBFE_FG_PITCH + RDX[k]]);
+    const int sc16 = corner_score16_h(d);
+    if (sc16 >= min_th) sc[y * ORBFE_FG_PITCH + x] = (uint8_t)sc16;
+  }
+  __syncthreads();
+
+  // ---- B: strict 3x3 NMS inside the survivor's own cell
+  for (int i = tid; i < nl; i += FG_THREADS) {
+    const int e = clist[i];
+    const int x = e & 0xff, y = e >> 8;
+    const uint8_t* s = sc + y * ORBFE_FG_PITCH + x;
+    const int v = s[0];
+    if (v > 0) {
+      const int xr = x - 3;
+      const int c = (xr >= wcell) + (xr >= 2 * wcell) + (xr >= 3 * wcell);
+      const int lo = c * wcell + 3, hi = (c == ncell - 1) ? width - 3 : lo + wcell;
+      const bool hasl = x > lo, hasr = x + 1 < hi;
+      const int l0 = hasl ? s[-ORBFE_FG_PITCH - 1] : 0, l1 = hasl ? s[-1] : 0, l2 = hasl ? s[ORBFE_FG_PITCH - 1] : 0;
+      const int r0 = hasr ? s[-ORBFE_FG_PITCH + 1] : 0, r1 = hasr ? s[1] : 0, r2 = hasr ? s[ORBFE_FG_PITCH + 1] : 0;
+      const bool keep = v > l0 && v > l1 && v > l2 && v > r0 && v > r1 && v > r2 && v > s[-ORBFE_FG_PITCH] && v > s[ORBFE_FG_PITCH];
+      if (keep) {
+        const int p = (y - 3) * (hi - lo) + (x - lo);
+        atomicOr(&bits[c * 256 + (p >> 5)], 1u << (p & 31));
+        if (v >= ini_th) atomicOr(&bits[c * 256 + 128 + (p >> 5)], 1u << (p & 31));
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- C: wave w emits cell w: two consecutive 32-pixel words per lane, one wave scan
+  if (wid < ncell) {
+    const int c = wid;
+    const CellDesc cd = cells[g.first_cell + c];
+    const int lo = c * wcell + 3, hi = (c == ncell - 1) ? width - 3 : lo + wcell;
+    const int twc = hi - lo;
+    const float inv_twc = 1.0f / (float)twc;
+    const uint32_t* ba = bits + c * 256;
+    const uint32_t a0 = ba[2 * lane], a1 = ba[2 * lane + 1], h0 = ba[128 + 2 * lane], h1 = ba[128 + 2 * lane + 1];
+    const int packed = ((__popc(h0) + __popc(h1)) << 16) | (__popc(a0) + __popc(a1));
+    const int incl = wave_incl_scan(packed);
+    const int total = __shfl(incl, WAVE - 1, WAVE);
+    const int excl = incl - packed;
+    const bool use_hi = (total >> 16) != 0;
+    int off = use_hi ? (excl >> 16) : (excl & 0xffff);
+    const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
+    uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      uint32_t mask = use_hi ? (w ? h1 : h0) : (w ? a1 : a0);
+      while (mask) {
+        const int b = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        const int p = (2 * lane + w) * 32 + b;
+        const int ty = (int)((p + 0.5f) * inv_twc);
+        const int x = p - ty * twc + lo, y = ty + 3;
+        const uint32_t sv = sc[y * ORBFE_FG_PITCH + x];
+        const uint32_t rx = (uint32_t)(x + g.x0 - ORBFE_EDGE), ry = (uint32_t)(y + g.y0 - ORBFE_EDGE);
+        if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
+        off++;
+      }
+    }
+    if (lane == 0) cell_cnt[(size_t)img * total_cells + g.first_cell + c] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ octree
 // DistributeOctTree as an array algorithm.  The leaves of the quadtree are kept in an array in std::list
 // order (index 0 = list head); because every insertion in the reference is a push_front and the initial
@@ -1032,6 +1251,27 @@ void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cell
   dim3 block(256), grid(total_cells, n_images);
   hipLaunchKernelGGL(fast_cells_kernel, grid, block, 0, s, pyr, cells, total_cells, cell_cnt, slots, slots_per_image,
                      ini_th, min_th, run_shift);
+}
+
+void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
+                              int total_cells, int tile_rows, int clist_cap, int32_t* cell_cnt, uint32_t* slots,
+                              unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s) {
+  if (n_groups == 0) return;
+  static int run_shift = -2;
+  if (run_shift == -2) {
+    const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order
+    run_shift = ev ? atoi(ev) : 2;                   // runs of 4 groups (~16 cells) per XCD
+  }
+  const size_t lds = (size_t)2 * tile_rows * ORBFE_FG_PITCH + (size_t)ORBFE_FG_MAX * 256 * 4 + (size_t)clist_cap * 2;
+  static size_t lds_allowed = 48 * 1024;
+  if (lds > lds_allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    lds_allowed = lds;
+  }
+  dim3 block(FG_THREADS), grid(n_groups, n_images);
+  hipLaunchKernelGGL(fast_groups_kernel, grid, block, lds, s, pyr, cells, groups, n_groups, total_cells, tile_rows,
+                     clist_cap, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift);
 }
 
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s) {

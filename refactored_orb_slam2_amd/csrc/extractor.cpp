@@ -82,6 +82,9 @@ struct orbfe_extractor {
   int plan_w = 0, plan_h = 0;
   LevelGeom lg[ORBFE_MAX_LEVELS]{};
   std::vector<CellDesc> cells;
+  std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
+  int fg_tile_rows = 0, fg_clist_cap = 0;
+  bool use_groups = true;
   std::vector<BlurTile> tiles;
   OctLevel oct[ORBFE_MAX_LEVELS]{};
   int total_cells = 0;
@@ -90,7 +93,7 @@ struct orbfe_extractor {
   int max_nodes = 0, lds_keys = 0;
   size_t oct_lds = 0;
   // device tables
-  DevBuf d_cells, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];
+  DevBuf d_cells, d_groups, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];
   bool resize_lds_ok[ORBFE_MAX_LEVELS]{};  // every 256x4 destination tile's source window fits the LDS stage
   // work space for `cap_images`
   int cap_images = 0;
@@ -199,7 +202,15 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   }
   // FAST cells and octree levels
   e->cells.clear();
+  e->groups.clear();
+  e->fg_tile_rows = 0;
+  e->fg_clist_cap = 0;
   e->tiles.clear();
+  static int fg_max = -1;
+  if (fg_max < 0) {
+    const char* ev = getenv("ORBFE_FAST_GROUP");  // experiment knob: cells per workgroup (1..4), 0 = per-cell kernel
+    fg_max = ev ? std::min(std::max(atoi(ev), 0), ORBFE_FG_MAX) : ORBFE_FG_MAX;
+  }
   size_t slot_off = 0, key_off = 0;
   int kp_off = 0, maxM = 0;
   for (int l = 0; l < nl; l++) {
@@ -224,6 +235,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
         float maxY = iniY + hCell + 6;
         if (iniY >= maxBY - 3) continue;
         if (maxY > maxBY) maxY = (float)maxBY;
+        const size_t row_first = e->cells.size();
         for (int j = 0; j < nCols; j++) {
           const float iniX = (float)(minB + j * wCell);
           float maxX = iniX + wCell + 6;
@@ -248,6 +260,26 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
           slot_off += cap;
           level_slots += cap;
           e->cells.push_back(c);
+        }
+        // split this cell row into runs of <= G cells of near-equal length (cells of a row are contiguous: only
+        // trailing ones are ever skipped)
+        const int n_row = (int)(e->cells.size() - row_first);
+        const int G = std::max(1, std::min(fg_max > 0 ? fg_max : 1, (ORBFE_FG_MAX_WIDTH - 6) / wCell));
+        const int n_grp = (n_row + G - 1) / G;
+        int done = 0;
+        for (int k = 0; k < n_grp; k++) {
+          const int cnt = (n_row - done + (n_grp - k) - 1) / (n_grp - k);
+          const CellDesc& a = e->cells[row_first + done];
+          const CellDesc& b = e->cells[row_first + done + cnt - 1];
+          FastGroup fg;
+          fg.first_cell = (int32_t)(row_first + done);
+          fg.n_cells = (int16_t)cnt; fg.level = (int16_t)l;
+          fg.x0 = a.x0; fg.y0 = a.y0; fg.width = (int16_t)(b.x0 + b.cols - a.x0); fg.rows = a.rows;
+          fg.wcell = (int16_t)wCell; fg.pad = 0;
+          e->groups.push_back(fg);
+          e->fg_tile_rows = std::max(e->fg_tile_rows, (int)fg.rows);
+          e->fg_clist_cap = std::max(e->fg_clist_cap, std::max(fg.width - 6, 0) * std::max(fg.rows - 6, 0));
+          done += cnt;
         }
       }
       const int nIni = (int)roundf(width / height);  // :535
@@ -301,6 +333,8 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   // device tables
   int rc;
   if ((rc = upload(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), e->stream))) return rc;
+  if ((rc = upload(e->d_groups, e->groups.data(), e->groups.size() * sizeof(FastGroup), e->stream))) return rc;
+  e->use_groups = fg_max > 0;
   if ((rc = upload(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(BlurTile), e->stream))) return rc;
   for (int l = 1; l < nl; l++) {
     std::vector<ResizeTap> xt, yt;
@@ -440,7 +474,13 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   if (fork) (void)hipEventRecord(e->ev_blur, sb);
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
-    orbfe_launch_fast(pv, (const CellDesc*)e->d_cells.p, e->total_cells, (int32_t*)e->d_cell_cnt.p,
+    if (e->use_groups)
+      orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)e->d_groups.p, (int)e->groups.size(),
+                               e->total_cells, e->fg_tile_rows, e->fg_clist_cap, (int32_t*)e->d_cell_cnt.p,
+                               (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast,
+                               n_images, s);
+    else
+      orbfe_launch_fast(pv, (const CellDesc*)e->d_cells.p, e->total_cells, (int32_t*)e->d_cell_cnt.p,
                       (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast, n_images, s);
   }
   {
@@ -571,7 +611,7 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   drain_events(e);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-  DevBuf* bufs[] = {&e->d_cells, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
+  DevBuf* bufs[] = {&e->d_cells, &e->d_groups, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
                     &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
   for (auto b : bufs) dev_free(*b);
   dev_free(e->d_in_stage);

@@ -36,6 +36,18 @@ struct CellDesc {
   uint32_t slot_off;   // offset (entries) of this cell's slot inside one image's slot block
 };
 
+// A run of horizontally adjacent FAST cells of one cell row, processed by one workgroup (shared ROI staging, one pass of
+// the per-pixel work; NMS, the two-threshold rule and the emission stay per cell)
+#define ORBFE_FG_MAX 4           // cells per group
+#define ORBFE_FG_PITCH 192       // LDS row pitch of a group's ROI (12 x 16 B): (x0 & 15) + width <= 192
+#define ORBFE_FG_MAX_WIDTH 176   // 192 - 15 - 1
+struct FastGroup {
+  int32_t first_cell;            // index into the cell table; the group's cells are consecutive there
+  int16_t n_cells, level;
+  int16_t x0, y0, width, rows;   // group ROI = union of the cells' ROIs
+  int16_t wcell, pad;            // x step between the cells' ROIs
+};
+
 // Per-level parameters of DistributeOctTree
 struct OctLevel {
   int cell_begin, n_cells;  // range in the cell table
@@ -90,6 +102,9 @@ struct BlurTile {
 // launchers (extract_kernels.hip)
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s);
+void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
+                              int total_cells, int tile_rows, int clist_cap, int32_t* cell_cnt, uint32_t* slots,
+                              unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
                        unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
