@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=128, help="stereo frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=256, help="stereo frames per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=160, help="stereo frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
                     help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")

@@ -55,20 +55,43 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // ------------------------------------------------------------------------------------------------ level 0
 // Copies the caller's images (arbitrary stride/alignment) into the pitched, 256-byte aligned level-0 planes.
+// 16 destination bytes per thread: five aligned source dwords + v_alignbyte instead of 16 byte loads (the source rows
+// start at arbitrary alignment); the last chunk of a row takes the byte path and replicates the last pixel into the
+// pitch padding.
 __global__ __launch_bounds__(256) void copy_level0_kernel(const uint8_t* __restrict__ src, int sstride,
                                                            unsigned long long simg, uint8_t* __restrict__ dst,
                                                            int dpitch, unsigned long long dimg, int w, int h) {
-  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  if (x4 >= w || y >= h) return;
+  const int nchunk = (w + 15) >> 4;  // 16-byte chunks per row; (row, chunk) pairs are dealt to threads in raster order
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  const int y = (int)((item + 0.5f) * (1.0f / (float)nchunk));  // exact for item < 2^22
+  const int x16 = (item - y * nchunk) * 16;
+  if (y >= h) return;
   const uint8_t* S = src + (size_t)blockIdx.z * simg + (size_t)y * sstride;
-  uint32_t out = 0;
+  uint32_t out[4];
+  if (x16 + 20 <= w) {
+    const uintptr_t A = reinterpret_cast<uintptr_t>(S + x16);
+    const uint32_t sh = (uint32_t)(A & 3);
+    const uint32_t* B = reinterpret_cast<const uint32_t*>(A - sh);
+    uint32_t d[5];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int x = x4 + i < w ? x4 + i : w - 1;
-    out |= (uint32_t)S[x] << (8 * i);
+    for (int i = 0; i < 5; i++) d[i] = B[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      out[i] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int x = x16 + 4 * i + j < w ? x16 + 4 * i + j : w - 1;
+        out[i] |= (uint32_t)S[x] << (8 * j);
+      }
+    }
   }
-  *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
+  uint8_t* D = dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x16;
+  if (x16 + 16 <= dpitch) *reinterpret_cast<uint4*>(D) = make_uint4(out[0], out[1], out[2], out[3]);
+  else
+    for (int i = 0; i < 4 && x16 + 4 * i < dpitch; i++) reinterpret_cast<uint32_t*>(D)[i] = out[i];
 }
 
 // ------------------------------------------------------------------------------------------------ resize
@@ -154,6 +177,70 @@ __global__ __launch_bounds__(256) void pyr_resize_lds_kernel(const uint8_t* __re
     out |= (uint32_t)(v & 0xff) << (8 * i);
   }
   *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
+}
+
+// 256 x 16 destination tile per workgroup, 4 x 4 destination pixels per thread: the horizontal taps (and all address
+// arithmetic) are loaded once per thread and reused for four rows; the staging divides once per thread and has all its
+// 16-byte loads in flight before the first LDS store.  Same arithmetic and tables as pyr_resize_kernel.
+#define RS2_ROWS 34
+__global__ __launch_bounds__(256) void pyr_resize_lds16_kernel(const uint8_t* __restrict__ src, int spitch,
+                                                                unsigned long long simg, uint8_t* __restrict__ dst,
+                                                                int dpitch, unsigned long long dimg, int dw, int dh,
+                                                                const ResizeTap* __restrict__ xt,
+                                                                const ResizeTap* __restrict__ yt) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[RS2_ROWS * RS_COLS];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * 16;
+  const int xl = min(x0 + 255, dw - 1), yl = min(y0 + 15, dh - 1);
+  const int sxa = xt[x0].s0 & ~15;
+  const int ncols16 = ((xt[xl].s1 - sxa) >> 4) + 1;  // <= 35
+  const int sy_first = yt[y0].s0;
+  const int nrows = yt[yl].s1 - sy_first + 1;        // <= 34
+  const uint8_t* S = src + (size_t)blockIdx.z * simg;
+  {
+    const int rpp = 256 / ncols16;  // rows per pass, >= 7
+    const int r0 = (int)((tid + 0.5f) * (1.0f / (float)ncols16));
+    const int c = tid - r0 * ncols16;
+    if (r0 < rpp) {
+      const uint8_t* g = S + (size_t)sy_first * spitch + sxa + 16 * c;
+      uint4 v[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int r = r0 + k * rpp;
+        v[k] = r < nrows ? *reinterpret_cast<const uint4*>(g + (size_t)r * spitch) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int r = r0 + k * rpp;
+        if (r < nrows) *reinterpret_cast<uint4*>(tile + r * RS_COLS + 16 * c) = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int x4 = x0 + threadIdx.x * 4;
+  if (x4 >= dw) return;
+  ResizeTap tx[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) tx[i] = xt[min(x4 + i, dw - 1)];
+  uint8_t* D = dst + (size_t)blockIdx.z * dimg + x4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int y = y0 + threadIdx.y * 4 + k;
+    if (y >= dh) break;
+    const ResizeTap ty = yt[y];
+    const uint8_t* S0 = tile + (ty.s0 - sy_first) * RS_COLS - sxa;
+    const uint8_t* S1 = tile + (ty.s1 - sy_first) * RS_COLS - sxa;
+    const int b0 = ty.c0, b1 = ty.c1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int t0 = S0[tx[i].s0] * tx[i].c0 + S0[tx[i].s1] * tx[i].c1;
+      const int t1 = S1[tx[i].s0] * tx[i].c0 + S1[tx[i].s1] * tx[i].c1;
+      const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xff) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(D + (size_t)y * dpitch) = out;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ FAST
@@ -1224,7 +1311,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
 // ------------------------------------------------------------------------------------------------ launchers
 void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
                         int h, int n_images, hipStream_t s) {
-  dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4, n_images);
+  dim3 block(256), grid((((w + 15) / 16) * h + 255) / 256, 1, n_images);
   hipLaunchKernelGGL(copy_level0_kernel, grid, block, 0, s, src, sstride, (unsigned long long)simg, dst, dpitch,
                      (unsigned long long)dimg, w, h);
 }
@@ -1232,7 +1319,12 @@ void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* d
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s) {
   dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
-  if (lds_ok)
+  static int legacy = -1;
+  if (legacy < 0) { const char* ev = getenv("ORBFE_RESIZE_LEGACY"); legacy = ev ? atoi(ev) : 0; }  // A/B knob
+  if (lds_ok && !legacy)
+    hipLaunchKernelGGL(pyr_resize_lds16_kernel, dim3((dw + 255) / 256, (dh + 15) / 16, n_images), block, 0, s, src, spitch,
+                       (unsigned long long)simg, dst, dpitch, (unsigned long long)dimg, dw, dh, xt, yt);
+  else if (lds_ok)
     hipLaunchKernelGGL(pyr_resize_lds_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
                        (unsigned long long)dimg, dw, dh, xt, yt);
   else  // source window of a tile exceeds the staged size (scale factor > 2): direct byte gathers

@@ -351,6 +351,10 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
       const int yl = std::min<int>(y0 + 3, (int)yt.size() - 1);
       if (yt[yl].s1 - yt[y0].s0 + 1 > 10) ok = false;
     }
+    for (int y0 = 0; y0 < (int)yt.size() && ok; y0 += 16) {  // 256 x 16 tiles of the 4-rows-per-thread kernel: 34 rows
+      const int yl = std::min<int>(y0 + 15, (int)yt.size() - 1);
+      if (yt[yl].s1 - yt[y0].s0 + 1 > 34) ok = false;
+    }
     e->resize_lds_ok[l] = ok;
     if ((rc = upload(e->d_xt[l], xt.data(), xt.size() * sizeof(ResizeTap), e->stream))) return rc;
     if ((rc = upload(e->d_yt[l], yt.data(), yt.size() * sizeof(ResizeTap), e->stream))) return rc;
