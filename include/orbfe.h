@@ -137,7 +137,7 @@ enum {
   ORBFE_STAGE_DESCRIBE = 4,
   ORBFE_STAGE_COUNT = 5
 };
-int orbfe_profile_enable(orbfe_extractor* e, int enable);
+int orbfe_profile_enable(orbfe_extractor* e, int enable);  /* 0 = off, 1 = every stage, otherwise a bit mask: bit (1 + stage) */
 int orbfe_stage_times(orbfe_extractor* e, float* ms /*[ORBFE_STAGE_COUNT]*/, int32_t* launches, int reset);
 
 /* --------------------------------------------------------------------------------------- ORBmatcher */

@@ -991,36 +991,33 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
-  const bool interior = ox >= 4 && ox + BT_W + 3 < w && oy >= 3 && oy + BT_H + 3 <= h;
-  if (interior) {
+  {
+    // (32+6) rows x 18 dwords (x = ox-4 .. ox+67): three per thread, all issued before the first LDS store.  A dword that
+    // lies inside the row is one aligned load; the few that straddle the image border (left edge, the partial dword at
+    // the right edge, columns beyond it) are assembled from bytes with REFLECT_101 indexing.  Rows reflect as a whole.
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
-    uint32_t v[3];  // (32+6)*18 = 684 dwords: three per thread, all issued before the first LDS store
+    uint32_t v[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int i = tid + 256 * k;
       const int r = i / 18, c = i - r * 18;
-      v[k] = i < (BT_H + 6) * 18 ? *reinterpret_cast<const uint32_t*>(S + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c) : 0u;
+      v[k] = 0u;
+      if (i < (BT_H + 6) * 18) {
+        const int gy = reflect101(oy + r - 3, h), x = ox - 4 + 4 * c;
+        const uint8_t* row = S + (size_t)gy * pitch;
+        if (x >= 0 && x + 3 < w) {
+          v[k] = *reinterpret_cast<const uint32_t*>(row + x);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[k] |= (uint32_t)row[reflect101(x + j, w)] << (8 * j);
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int i = tid + 256 * k;
       const int r = i / 18, c = i - r * 18;
       if (i < (BT_H + 6) * 18) in32[r * (BT_INP / 4) + c] = v[k];
-    }
-  } else {
-    uint8_t v[11];  // (32+6)*70 = 2660 bytes with REFLECT_101 indexing: eleven per thread, loads first
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const int i = tid + 256 * k;
-      const int r = i / 70, c = i - r * 70;  // c <-> x = ox - 3 + c  <-> column j = c + 1
-      const int gy = reflect101(oy + r - 3, h), gx = reflect101(ox + c - 3, w);
-      v[k] = i < (BT_H + 6) * 70 ? S[(size_t)gy * pitch + gx] : (uint8_t)0;
-    }
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const int i = tid + 256 * k;
-      const int r = i / 70, c = i - r * 70;
-      if (i < (BT_H + 6) * 70) in[r * BT_INP + c + 1] = v[k];
     }
   }
   __syncthreads();
@@ -1167,39 +1164,29 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // everything that identifies the wave's keypoint is wave-uniform: readfirstlane keeps it (and all the address
+  // arithmetic that follows) in SGPRs / on the scalar unit instead of 64 redundant VALU lanes
+  const int wv_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int slot = blockIdx.x * 4 + wv_id;
   const int img = blockIdx.y;
-  // per-level keypoint counts of this image: 16 ints, four independent 16-byte loads
-  int cnt[ORBFE_MAX_LEVELS];
-  {
-    const int4* ln4 = reinterpret_cast<const int4*>(P.lvl_n + (size_t)img * ORBFE_MAX_LEVELS);
-#pragma unroll
-    for (int k = 0; k < ORBFE_MAX_LEVELS / 4; k++) {
-      const int4 t = ln4[k];
-      cnt[4 * k] = t.x; cnt[4 * k + 1] = t.y; cnt[4 * k + 2] = t.z; cnt[4 * k + 3] = t.w;
-    }
-  }
   // the four pattern entries of this lane (rounds 0..3): issued early, consumed after the orientation
   float4 pk[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
+  // per-level keypoint counts of this image (scalar loads)
+  const int32_t* ln = P.lvl_n + (size_t)img * ORBFE_MAX_LEVELS;
   if (slot == 0 && lane == 0) {
     int tot = 0;
-#pragma unroll
-    for (int l = 0; l < ORBFE_MAX_LEVELS; l++) tot += l < P.n_levels ? cnt[l] : 0;
+    for (int l = 0; l < P.n_levels; l++) tot += ln[l];
     P.out_n[img] = tot;
   }
   if (slot >= P.kp_per_image) return;
   int level = 0;
   while (level + 1 < P.n_levels && slot >= P.kp_off[level + 1]) level++;
   const int idx = slot - P.kp_off[level];
-  int out = idx, nlev = 0;
-#pragma unroll
-  for (int l = 0; l < ORBFE_MAX_LEVELS; l++) {
-    out += l < level ? cnt[l] : 0;
-    nlev = l == level ? cnt[l] : nlev;
-  }
-  if (idx >= nlev) return;
+  if (idx >= ln[level]) return;
+  int out = idx;
+  for (int l = 0; l < level; l++) out += ln[l];
   if (out >= P.cap) return;
 
   const uint32_t e = P.lvl_kp[(size_t)img * P.kp_per_image + slot];
@@ -1209,7 +1196,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   // --- stage both patches of this keypoint in the wave's LDS slice with aligned dword loads:
   //     un-blurred 31x31 (orientation) and blurred 37x37 (rotated pattern offsets reach +-18).
   //     All 11 loads of a lane are issued before the first LDS store (one memory round trip, not eleven).
-  uint8_t* ori = &patch[threadIdx.x >> 6][0];
+  uint8_t* ori = &patch[wv_id][0];
   uint8_t* dsc = ori + ORI_BYTES;
   const int pitch = P.pyr.pitch[level];
   const int bpitch = P.blur.pitch[level];

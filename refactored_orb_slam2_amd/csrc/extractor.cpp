@@ -107,6 +107,7 @@ struct orbfe_extractor {
   // profiling
   bool overlap_blur = false;  // measured: FAST and the blur are both issue-bound, running them concurrently is 2 % slower
   bool profile = false;
+  unsigned profile_mask = ~0u;  // bit s: stage s is timed
   float stage_ms[ORBFE_STAGE_COUNT]{};
   int stage_launches[ORBFE_STAGE_COUNT]{};
   std::vector<hipEvent_t> ev_pool;
@@ -417,8 +418,9 @@ struct StageTimer {
   hipStream_t s;
   int stage;
   hipEvent_t a = nullptr, b = nullptr;
+  bool on = true;
   StageTimer(orbfe_extractor* e_, hipStream_t s_, int st) : e(e_), s(s_), stage(st) {
-    if (!e->profile) return;
+    if (!e->profile || !(e->profile_mask & (1u << st))) { on = false; return; }
     auto get = [&]() {
       hipEvent_t ev = nullptr;
       if (!e->ev_pool.empty()) { ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
@@ -430,7 +432,7 @@ struct StageTimer {
     (void)hipEventRecord(a, s);
   }
   ~StageTimer() {
-    if (!e->profile) return;
+    if (!on) return;
     (void)hipEventRecord(b, s);
     e->ev_pending.push_back({stage, a, b});
   }
@@ -943,6 +945,7 @@ extern "C" int orbfe_profile_enable(orbfe_extractor* e, int enable) {
   if (!e) return ORBFE_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   e->profile = enable != 0;
+  e->profile_mask = enable == 1 ? ~0u : ((unsigned)enable >> 1);
   return ORBFE_OK;
 }
 

@@ -174,8 +174,12 @@ class ORBextractor:
         return self._xys(self._L.orbfe_debug_level_keypoints, image, level, cap)
 
     # ---- HIP-event stage timing
-    def profile(self, enable: bool = True):
-        _lib.check(self._L.orbfe_profile_enable(self._h, int(enable)), "orbfe_profile_enable")
+    def profile(self, enable=True, stages=None):
+        """Per-stage HIP-event timing on the launch stream.  stages: optional list of stage names to time (default all)."""
+        code = int(bool(enable))
+        if enable and stages is not None:
+            code = sum(2 << STAGES.index(s) for s in stages)
+        _lib.check(self._L.orbfe_profile_enable(self._h, code), "orbfe_profile_enable")
 
     def stage_times(self, reset: bool = True):
         ms = np.zeros(len(STAGES), np.float32)
