@@ -821,11 +821,19 @@ __global__ __launch_bounds__(256) void stereo_bucket_kernel(StereoParams P) {
   }
 }
 
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) {  // |a - b| + c
+  unsigned r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+#define SAD_LP 20   // LDS pitch of the staged left window (5 dwords)
+#define SAD_RP 24   // LDS pitch of the staged right window (6 dwords)
 __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const int pair = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1);
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
   __shared__ float s_r[ORBFE_MAX_LEVELS];  // r = 2 * scale[octave] of a right keypoint (L/src/Frame.cc:496)
+  __shared__ __attribute__((aligned(16))) uint8_t sad_win[4][11 * SAD_LP + 11 * SAD_RP + 16];
   if (threadIdx.x < ORBFE_MAX_LEVELS) s_r[threadIdx.x] = 2.0f * P.scale[threadIdx.x];
   __syncthreads();
   if (iL >= P.cap) return;
@@ -919,24 +927,56 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const uint8_t* imL = P.pyrL.base[levelL] + (size_t)pair * P.pyrL.img_stride[levelL];
   const uint8_t* imR = P.pyrR.base[levelL] + (size_t)pair * P.pyrR.img_stride[levelL];
   const int sL = P.pyrL.pitch[levelL], sR = P.pyrR.pitch[levelL];
-  const int cL = imL[(size_t)(yL0 + w) * sL + xL0 + w];
-  int acc[11];
+  // stage the 11 x 11 left window and the 11 x 21 right window (all 11 shifts) in the wave's LDS slice with aligned
+  // dword loads: 55 + 66 dwords per wave instead of 24 byte loads per lane; the windows' positions are wave-uniform
+  uint8_t* winL = &sad_win[threadIdx.x >> 6][0];
+  uint8_t* winR = winL + 11 * SAD_LP;
+  const int xR0 = __builtin_amdgcn_readfirstlane(xRc - L - w);
+  const int yW = __builtin_amdgcn_readfirstlane(yL0), xW = __builtin_amdgcn_readfirstlane(xL0);
+  const int axL = xW & ~3, axR = xR0 & ~3;
+  {
+    uint32_t vl = 0, vr0 = 0, vr1 = 0;
+    const int rl = lane / 5, cl = lane - rl * 5;      // 11 rows x 5 dwords
+    const int rr = lane / 6, cr = lane - rr * 6;      // 11 rows x 6 dwords: lanes 0..63 + two more
+    if (lane < 55) vl = *reinterpret_cast<const uint32_t*>(imL + (size_t)(yW + rl) * sL + axL + 4 * cl);
+    vr0 = *reinterpret_cast<const uint32_t*>(imR + (size_t)(yW + rr) * sR + axR + 4 * cr);
+    if (lane < 2) vr1 = *reinterpret_cast<const uint32_t*>(imR + (size_t)(yW + 10) * sR + axR + 4 * (4 + lane));
+    if (lane < 55) reinterpret_cast<uint32_t*>(winL)[rl * (SAD_LP / 4) + cl] = vl;
+    reinterpret_cast<uint32_t*>(winR)[rr * (SAD_RP / 4) + cr] = vr0;
+    if (lane < 2) reinterpret_cast<uint32_t*>(winR)[10 * (SAD_RP / 4) + 4 + lane] = vr1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint8_t* WL = winL + (xW - axL);
+  const uint8_t* WR = winR + (xR0 - axR);
+  // |a - b| with a = IL - cL, b = IR - cR[k]: both biased by +255 so that v_sad_u32 (|x - y| + acc) applies
+  const int cLm = (int)WL[w * SAD_LP + w] - 255;
+  int cRm[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) cRm[k] = (int)WR[w * SAD_RP + w + k] - 255;
+  unsigned acc[11];
 #pragma unroll
   for (int k = 0; k < 11; k++) acc[k] = 0;
   for (int p = lane; p < 121; p += WAVE) {
     const int yy = p / 11, xx = p - yy * 11;
-    const int a = (int)imL[(size_t)(yL0 + yy) * sL + xL0 + xx] - cL;
-    const uint8_t* rrow = imR + (size_t)(yL0 + yy) * sR + (xRc - L - w) + xx;
+    const unsigned a = (unsigned)((int)WL[yy * SAD_LP + xx] - cLm);
+    const uint8_t* rrow = WR + yy * SAD_RP + xx;
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const int cR = imR[(size_t)(yL0 + w) * sR + (xRc - L + k)];
-      const int b = (int)rrow[k] - cR;
-      const int d = a - b;
-      acc[k] += d < 0 ? -d : d;
-    }
+    for (int k = 0; k < 11; k++) acc[k] = sad_u32(a, (unsigned)((int)rrow[k] - cRm[k]), acc[k]);
   }
+  // every sum is <= 121 * 510 < 65536: reduce two per register
+  {
+    unsigned pk[6];
 #pragma unroll
-  for (int k = 0; k < 11; k++) acc[k] = wave_sum_i32(acc[k]);
+    for (int j = 0; j < 5; j++) pk[j] = acc[2 * j] | (acc[2 * j + 1] << 16);
+    pk[5] = acc[10];
+#pragma unroll
+    for (int j = 0; j < 6; j++) pk[j] = (unsigned)wave_sum_i32((int)pk[j]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) { acc[2 * j] = pk[j] & 0xffffu; acc[2 * j + 1] = pk[j] >> 16; }
+    acc[10] = pk[5];
+  }
   if (lane != 0) return;
   int sadBest = 2147483647, bestincR = 0;
   float vDists[11];
