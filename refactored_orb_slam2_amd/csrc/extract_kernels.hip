@@ -19,12 +19,13 @@
 
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ int wave_incl_scan(int v) {
-  const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    int t = __shfl_up(v, d, WAVE);
-    if (lane >= d) v += t;
-  }
+  // DPP row shifts + row broadcasts (gfx9): six VALU adds, no LDS crossbar round trips (ds_bpermute) as with __shfl_up
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
   uint32_t* bits = reinterpret_cast<uint32_t*>(sc + tile_rows * ORBFE_FG_PITCH);  // [cell][all 128 | hi 128]
   uint16_t* clist = reinterpret_cast<uint16_t*>(bits + ORBFE_FG_MAX * 256);
 
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img = blockIdx.y;
   const int q = blockIdx.x >> 3;
   const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
@@ -1249,11 +1250,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
     m10 += u * val;
     m01 += v * val;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    m10 += __shfl_xor(m10, d, WAVE);
-    m01 += __shfl_xor(m01, d, WAVE);
-  }
+  m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);  // DPP reduction, total in lane 63
+  m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
   // --- computeOrbDescriptor (L/src/ORBextractor.cc:103-146)

@@ -31,24 +31,24 @@ __device__ __forceinline__ void load_desc4(const uint8_t* p, uint4& d0, uint4& d
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, d, WAVE));
-  return v;
+  // DPP reduction (row shifts, then row broadcasts): lane 63 ends up with the minimum of all 64 lanes
+#define ORBFE_MIN_STEP(ctrl, rmask) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, ctrl, rmask, 0xf, false))
+  ORBFE_MIN_STEP(0x111, 0xf); ORBFE_MIN_STEP(0x112, 0xf); ORBFE_MIN_STEP(0x114, 0xf); ORBFE_MIN_STEP(0x118, 0xf);
+  ORBFE_MIN_STEP(0x142, 0xa); ORBFE_MIN_STEP(0x143, 0xc);
+#undef ORBFE_MIN_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ int wave_incl_scan_i(int v) {
-  const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    int t = __shfl_up(v, d, WAVE);
-    if (lane >= d) v += t;
-  }
+  // DPP row shifts + row broadcasts (gfx9): six VALU adds, no LDS crossbar round trips (ds_bpermute) as with __shfl_up
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
-  return v;
-}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i(v), 63); }
 
 // ------------------------------------------------------------------------------------------------ all pairs
 // Thread = one B column (descriptor in registers); a block stages 64 A rows in LDS; stores are coalesced
