@@ -630,7 +630,7 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
     const uint32_t a0 = ba[2 * lane], a1 = ba[2 * lane + 1], h0 = ba[128 + 2 * lane], h1 = ba[128 + 2 * lane + 1];
     const int packed = ((__popc(h0) + __popc(h1)) << 16) | (__popc(a0) + __popc(a1));
     const int incl = wave_incl_scan(packed);
-    const int total = __shfl(incl, WAVE - 1, WAVE);
+    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
     const int excl = incl - packed;
     const bool use_hi = (total >> 16) != 0;
     int off = use_hi ? (excl >> 16) : (excl & 0xffff);

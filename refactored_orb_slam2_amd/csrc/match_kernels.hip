@@ -233,7 +233,7 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
   // The window's cells of one grid column (ix, nMinCellY..nMaxCellY) are adjacent in CSR order.  Lane c fetches
   // column c's range; the ranges are concatenated (prefix sum) into one flat candidate sequence -- column-major, then
   // cell row, then ascending index: the reference's enumeration order -- that the wave consumes 64 entries at a time.
-  const int ncol = nMaxCellX - nMinCellX + 1;  // <= 64
+  const int ncol = __builtin_amdgcn_readfirstlane(nMaxCellX - nMinCellX + 1);  // <= 64; the query is wave-uniform
   int e0c = 0, cntc = 0;
   if (lane < ncol) {
     const int ix = nMinCellX + lane;
@@ -242,13 +242,13 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
   }
   const int inclc = wave_incl_scan_i(cntc);
   const int exclc = inclc - cntc;
-  const int n_entries = __shfl(inclc, WAVE - 1, WAVE);
+  const int n_entries = __builtin_amdgcn_readlane(inclc, WAVE - 1);
   int rank0 = 0;
   for (int base = 0; base < n_entries; base += WAVE) {
     const int t = base + lane;
     int ent = -1;
     for (int c = 0; c < ncol; c++) {
-      const int oc = __shfl(exclc, c, WAVE), nc = __shfl(cntc, c, WAVE), ec = __shfl(e0c, c, WAVE);
+      const int oc = __builtin_amdgcn_readlane(exclc, c), nc = __builtin_amdgcn_readlane(cntc, c), ec = __builtin_amdgcn_readlane(e0c, c);
       if (t >= oc && t < oc + nc) ent = ec + (t - oc);
     }
     bool ok = false;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
         if (b != 0xFFFFFFFFu) {
           const unsigned long long wm = __ballot(k1 == b);
           const int wl = __ffsll((long long)wm) - 1;
-          const int bestIdx = __shfl(i1, wl, WAVE);
+          const int bestIdx = __builtin_amdgcn_readlane(i1, wl);
           const int bestDist = (int)(b >> 16);
           bool accept = false;
           if (mode == 0) {
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameBatch F, QueryBat
     if (b != 0xFFFFFFFFu) {
       const unsigned long long wm = __ballot(k1 == b);
       const int wl = __ffsll((long long)wm) - 1;
-      const int bestIdx2 = __shfl(i1b, wl, WAVE);
+      const int bestIdx2 = __builtin_amdgcn_readlane(i1b, wl);
       const int bestDist = (int)(b >> 16);
       const unsigned mine = (lane == wl) ? k2 : k1;
       const unsigned s2 = wave_min_u32(mine);
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
     best = wave_min_u32(k);
     if (best == 0xFFFFFFFFu) return;
     const unsigned long long wm = __ballot(k == best);
-    uR0 = __shfl(best_x, __ffsll((long long)wm) - 1, WAVE);
+    uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_x), __ffsll((long long)wm) - 1));
   }
   const int bestDist = (int)(best >> 16);
   const int thOrbDist = (ORBFE_TH_HIGH + ORBFE_TH_LOW) / 2;
