@@ -34,33 +34,23 @@ def level_pixels(ex):
     return [ex.level_size(l, W, H) for l in range(NLEVELS)]
 
 
-def build_queries(torch, kps, desc, n, ur, sf_t, shift_x):
-    """Project frame f-1 ("last") into frame f with the known image motion: the caller-side part of
-    SearchByProjection(cur, last) (Source/Libraries/ORB_SLAM2/src/ORBmatcher.cc:1270-1308), as tensor ops."""
-    F, cap = desc.shape[0], desc.shape[1]
-    k32 = kps.view(torch.int32).view(F, cap, 7)
-    last = torch.roll(k32, 1, 0)
-    dlast = torch.roll(desc.view(torch.int32).view(F, cap, 8), 1, 0)
-    nlast = torch.roll(n, 1, 0)
-    urlast = torch.roll(ur, 1, 0)
-    x = last[..., 0].view(torch.float32)
-    y = last[..., 1].view(torch.float32)
-    ang = last[..., 3].view(torch.float32)
-    octv = last[..., 5].clamp(0, NLEVELS - 1)
-    q = torch.empty((F, cap, 17), dtype=torch.int32, device=desc.device)
-    u = x + shift_x
-    q[..., 0] = u.view(torch.int32)
-    q[..., 1] = y.view(torch.int32)
-    q[..., 2] = (u - (x - urlast)).view(torch.int32)
-    q[..., 3] = (TH_STEREO * sf_t[octv.long()]).view(torch.int32)
-    q[..., 4] = octv - 1
-    q[..., 5] = octv + 1
-    idx = torch.arange(cap, device=desc.device, dtype=torch.int32)[None, :]
-    q[..., 6] = ((idx < nlast[:, None]) & (urlast >= 0)).to(torch.int32)
-    q[..., 7] = 1
-    q[..., 8] = ang.view(torch.int32)
-    q[..., 9:17] = dlast
-    return q.view(torch.uint8).view(F, cap, 68), nlast.contiguous()
+FY, CX, CY = 718.856, 607.1928, 185.2157   # KITTI00-02.yaml
+SHIFT_X = -2.0                             # synth.sequence: the image content moves 2 px per frame
+
+
+def camera_records(n, sf):
+    """Synthetic camera for the motion-model search: identity pose, and a principal point that moves with the image
+    content (SHIFT_X px per frame), so that re-projecting the last frame's stereo points into the current frame
+    (UnprojectStereo -> Rcw*x3Dw+tcw -> pinhole) lands on the known image motion for every depth."""
+    from refactored_orb_slam2_amd._lib import TRACK_POSE_DTYPE, UNPROJECT_CAM_DTYPE
+    cams = np.zeros(n, UNPROJECT_CAM_DTYPE); poses = np.zeros(n, TRACK_POSE_DTYPE)
+    eye = np.eye(3, dtype=np.float32).reshape(9)
+    cams["Rwc"] = eye; cams["cx"] = CX; cams["cy"] = CY
+    cams["invfx"] = np.float32(1) / np.float32(FX); cams["invfy"] = np.float32(1) / np.float32(FY)
+    poses["Rcw"] = eye; poses["fx"] = FX; poses["fy"] = FY; poses["cx"] = np.float32(CX) + np.float32(SHIFT_X); poses["cy"] = CY
+    poses["mbf"] = MBF; poses["max_x"] = W; poses["max_y"] = H; poses["th"] = TH_STEREO
+    poses["scale_factors"] = np.asarray(sf, np.float32)[:8]
+    return cams, poses
 
 
 def cpu_baseline(sample_frames: int):
@@ -71,6 +61,7 @@ def cpu_baseline(sample_frames: int):
     oL, oR = ol.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7), ol.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7)
     sf, isf = oL.scale_factors, oL.inv_scale_factors
     mb = MBF / FX
+    cams, poses = camera_records(1, sf)
     prev = None
     t0 = time.perf_counter()
     for (L, R) in pairs:
@@ -78,18 +69,11 @@ def cpu_baseline(sample_frames: int):
         kR, dR = oR(R)
         planesL = [oL.level_pixels(l) for l in range(NLEVELS)]
         planesR = [oR.level_pixels(l) for l in range(NLEVELS)]
-        _, ur, _ = ol.compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, MBF, mb)
+        _, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, MBF, mb)
         if prev is not None:
-            pk, pd, pur = prev
-            q = np.zeros(len(pk), ol.QUERY_DTYPE)
-            q["u"] = pk["x"] - np.float32(2.0); q["v"] = pk["y"]
-            q["u_r"] = q["u"] - (pk["x"] - pur)
-            q["radius"] = np.float32(TH_STEREO) * sf[pk["octave"]]
-            q["min_level"] = pk["octave"] - 1; q["max_level"] = pk["octave"] + 1
-            q["valid"] = (pur >= 0).astype(np.int32); q["blocks"] = 1
-            q["angle"] = pk["angle"]; q["desc"] = pd
+            q = ol.track_queries(poses[:1], prev)     # projection of the last frame's map points (ORBmatcher.cc:1270-1308)
             ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(q, True)
-        prev = (kL, dL, ur)
+        prev = ol.unproject_stereo(cams[:1], kL, dL, depth)   # Frame::UnprojectStereo for every stereo point
     dt = time.perf_counter() - t0
     return {"value": round(sample_frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{sample_frames} synthetic KITTI-geometry stereo frames (2x extract + stereo match + "
@@ -113,7 +97,7 @@ def main():
     import torch
     import torch.distributed as dist
     from refactored_orb_slam2_amd import ORBextractor, synth
-    from refactored_orb_slam2_amd.matcher import Matcher
+    from refactored_orb_slam2_amd.matcher import Matcher, track_queries_batch, unproject_stereo_batch
     from refactored_orb_slam2_amd.sharding import AsyncGather
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,7 +152,12 @@ def main():
     blocked = torch.zeros((F, cap), dtype=torch.uint8, device=dev)
     assigned = torch.zeros((F, cap), dtype=torch.int32, device=dev)
     n_track = torch.zeros(F, dtype=torch.int32, device=dev)
-    sf_t = torch.from_numpy(exL.GetScaleFactors()).to(dev)
+    cams_np, poses_np = camera_records(F, exL.GetScaleFactors())
+    t_cams = torch.from_numpy(cams_np.view(np.uint8).reshape(F, -1)).to(dev)
+    t_poses = torch.from_numpy(poses_np.view(np.uint8).reshape(F, -1)).to(dev)
+    pts = torch.zeros((F, cap, 60), dtype=torch.uint8, device=dev)      # orbfe_last_point records
+    q = torch.zeros((F, cap, 68), dtype=torch.uint8, device=dev)        # orbfe_query records
+    nq = torch.zeros(F, dtype=torch.int32, device=dev)
     mb = MBF / FX
     # three explicit HIP streams: torch's default stream is the NULL stream, which the C ABI reads as "use the
     # handle's own stream"; the whole step therefore runs on named streams ordered by events
@@ -190,7 +179,8 @@ def main():
             exL.extract_batch_device(dL, kl, dl, nl, stream=cur)
             exR.extract_batch_device(dR, kr, dr, nr, stream=cur)
         mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, MBF, mb, ur, depth, n_stereo, stream=cur)  # ComputeStereoMatches
-        q, nq = build_queries(torch, kl, dl, nl, ur, sf_t, -2.0)
+        unproject_stereo_batch(kl, dl, nl, depth, t_cams, 1, pts, cur)   # Frame::UnprojectStereo: the stereo points of every frame
+        track_queries_batch(t_poses, pts, nl, 1, q, nq, cur)             # projected into the next frame (ORBmatcher.cc:1270-1308)
         blocked.zero_(); assigned.fill_(-1)
         mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned,
                             n_track, stream=cur)              # SearchByProjection(cur, last, th=7)

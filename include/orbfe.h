@@ -275,6 +275,45 @@ int orbfe_search_local_points_batch_device(orbfe_matcher* m, int n_frames, const
                                            orbfe_track* d_track, uint8_t* d_blocked, int32_t* d_assigned,
                                            int32_t* d_n_to_match, int32_t* d_n_matches, void* stream);
 
+/* ---- motion-model tracking on the device: Frame::UnprojectStereo (L/src/Frame.cc:668-679) and the projection part of
+ * SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (L/src/ORBmatcher.cc:1257-1308) ------------- */
+typedef struct orbfe_unproject_cam {   /* the Frame members UnprojectStereo reads */
+  float Rwc[9], Ow[3];                 /* mRwc (row-major), mOw */
+  float cx, cy, invfx, invfy;
+} orbfe_unproject_cam;                 /* 64 bytes */
+
+typedef struct orbfe_last_point {      /* LastFrame keypoint i with its map point; 60 bytes */
+  float pos[3];                        /* pMP->GetWorldPos() */
+  int32_t valid;                       /* LastFrame.mvpMapPoints[i] != NULL && !LastFrame.mvbOutlier[i] */
+  int32_t observed;                    /* pMP->Observations() > 0 */
+  int32_t octave;                      /* LastFrame.mvKeys[i].octave */
+  float angle;                         /* LastFrame.mvKeysUn[i].angle */
+  uint8_t desc[32];                    /* pMP->GetDescriptor() */
+} orbfe_last_point;
+
+typedef struct orbfe_track_pose {      /* CurrentFrame members read by :1257-1308; 128 bytes */
+  float Rcw[9], tcw[3];                /* CurrentFrame.mTcw */
+  float fx, fy, cx, cy, mbf;
+  float min_x, max_x, min_y, max_y;
+  int32_t forward, backward;           /* bForward, bBackward (:1267-1268; tlc = Rlw*twc + tlw stays with the caller) */
+  float th;
+  float scale_factors[8];              /* CurrentFrame.mvScaleFactors */
+} orbfe_track_pose;
+
+/* One record per keypoint of every frame: map point = UnprojectStereo(i) when d_depth > 0 (valid = 0 otherwise), descriptor /
+ * octave / angle of the keypoint itself (a map point created from this frame, L/src/MapPoint.cc:57-86).  DEVICE pointers,
+ * asynchronous on `stream`.  d_points [n_frames][cap]. */
+int orbfe_unproject_stereo_device(int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                  const float* d_depth, int cap, const orbfe_unproject_cam* d_cam, int observed,
+                                  orbfe_last_point* d_points, void* stream);
+/* Queries of frame f from the points of frame (f - frame_shift) mod n_frames (frame_shift = 1: the previous frame of a
+ * sequence batch; 0: the caller arranged the points per frame): projection, invzc / bounds rejects, radius =
+ * th * mvScaleFactors[octave], level range by bForward / bBackward, u_r = u - mbf * invzc.  d_nq[f] receives the point
+ * count of the source frame.  Feed the result to orbfe_proj_match_batch_device(mode 1). */
+int orbfe_track_queries_device(int n_frames, const orbfe_track_pose* d_pose, const orbfe_last_point* d_points,
+                               const int32_t* d_n_points, int p_cap, int frame_shift, orbfe_query* d_queries,
+                               int32_t* d_nq, void* stream);
+
 /* SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), entirely on the device.
  * A DBoW2::FeatureVector is passed as its nodes sorted by id, each {node_id, start, count} into an index array
  * (nodesA/idxA = pKF->mFeatVec, nodesB/idxB = F.mFeatVec).  validA[i] != 0 <=> keyframe feature i has a map point

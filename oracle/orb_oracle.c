@@ -986,6 +986,66 @@ int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq
   return nmatches;
 }
 
+/* Frame::UnprojectStereo: L/src/Frame.cc:668-679 (mRwc * x3Dc + mOw through the cv::gemm small-matrix path, see
+ * oo_is_in_frustum); the map point created from the keypoint carries its descriptor (L/src/MapPoint.cc:57-86). */
+void oo_unproject_stereo(const oo_unproject_cam* cam, const oo_keypoint* kp, float z, const uint8_t* desc, int observed,
+                         oo_last_point* out) {
+  memset(out, 0, sizeof(*out));
+  if (z > 0) {
+    const float u = kp->x, v = kp->y;
+    const float x = (u - cam->cx) * z * cam->invfx;
+    const float y = (v - cam->cy) * z * cam->invfy;
+    for (int r = 0; r < 3; r++) {
+      const float* a = cam->Rwc + 3 * r;
+      const float t = a[0] * x + a[1] * y + a[2] * z;
+      out->pos[r] = (float)((double)t * 1.0 + (double)cam->Ow[r] * 1.0);
+    }
+    out->valid = 1;
+  }
+  out->observed = observed != 0;
+  out->octave = kp->octave;
+  out->angle = kp->angle;
+  memcpy(out->desc, desc, 32);
+}
+
+/* L/src/ORBmatcher.cc:1270-1308, 1326-1327 */
+void oo_track_query(const oo_track_pose* P, const oo_last_point* lp, oo_query* q) {
+  memset(q, 0, sizeof(*q));
+  if (!lp->valid) return;                                     /* pMP == NULL || mvbOutlier[i] */
+  float x3Dc[3];
+  for (int r = 0; r < 3; r++) {
+    const float* a = P->Rcw + 3 * r;
+    const float t = a[0] * lp->pos[0] + a[1] * lp->pos[1] + a[2] * lp->pos[2];
+    x3Dc[r] = (float)((double)t * 1.0 + (double)P->tcw[r] * 1.0);
+  }
+  const float xc = x3Dc[0], yc = x3Dc[1];
+  const float invzc = 1.0 / x3Dc[2];
+  if (invzc < 0) return;
+  float u = P->fx * xc * invzc + P->cx;
+  float v = P->fy * yc * invzc + P->cy;
+  if (u < P->min_x || u > P->max_x) return;
+  if (v < P->min_y || v > P->max_y) return;
+  const int nLastOctave = lp->octave;
+  const float radius = P->th * P->scale_factors[nLastOctave & 7];
+  q->u = u; q->v = v; q->radius = radius;
+  q->u_r = u - P->mbf * invzc;
+  if (P->forward) { q->min_level = nLastOctave; q->max_level = -1; }
+  else if (P->backward) { q->min_level = 0; q->max_level = nLastOctave; }
+  else { q->min_level = nLastOctave - 1; q->max_level = nLastOctave + 1; }
+  q->valid = 1;
+  q->blocks = lp->observed != 0;
+  q->angle = lp->angle;
+  memcpy(q->desc, lp->desc, 32);
+}
+
+void oo_unproject_stereo_n(const oo_unproject_cam* cam, const oo_keypoint* kps, const float* depth, const uint8_t* desc, int n,
+                           int observed, oo_last_point* out) {
+  for (int i = 0; i < n; i++) oo_unproject_stereo(cam, &kps[i], depth[i], desc + (size_t)i * 32, observed, &out[i]);
+}
+void oo_track_queries_n(const oo_track_pose* pose, const oo_last_point* lp, int n, oo_query* q) {
+  for (int i = 0; i < n; i++) oo_track_query(pose, &lp[i], &q[i]);
+}
+
 /* MapPoint::PredictScale(const float&, Frame*): L/src/MapPoint.cc:409-423.  `using namespace ::std` (:25) makes
  * log(float) -> logf and ceil(float) -> ceilf. */
 int oo_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels) {

@@ -173,6 +173,25 @@ void oo_local_point_query(const oo_frustum* fr, const oo_map_point* mp, const oo
 int oo_search_local_points(const oo_frame* f, const oo_frustum* fr, const oo_map_point* mp, int n, float th, float nnratio,
                            oo_track* track, uint8_t* blocked, int32_t* assigned, int* n_to_match);
 
+/* ---- motion-model tracking: Frame::UnprojectStereo (Frame.cc:668-679) and the projection part of
+ * SearchByProjection(cur, last) (ORBmatcher.cc:1257-1308) */
+typedef struct oo_unproject_cam { float Rwc[9], Ow[3], cx, cy, invfx, invfy; } oo_unproject_cam;
+typedef struct oo_last_point { float pos[3]; int32_t valid, observed, octave; float angle; uint8_t desc[32]; } oo_last_point;
+typedef struct oo_track_pose {
+  float Rcw[9], tcw[3], fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y;
+  int32_t forward, backward;
+  float th, scale_factors[8];
+} oo_track_pose;
+/* record of keypoint kp with depth z: map point = UnprojectStereo when z > 0 */
+void oo_unproject_stereo(const oo_unproject_cam* cam, const oo_keypoint* kp, float z, const uint8_t* desc, int observed,
+                         oo_last_point* out);
+/* query the reference forms from one last-frame point (valid = 0 where it `continue`s) */
+void oo_track_query(const oo_track_pose* pose, const oo_last_point* lp, oo_query* q);
+/* the same over arrays (n keypoints of one frame) */
+void oo_unproject_stereo_n(const oo_unproject_cam* cam, const oo_keypoint* kps, const float* depth, const uint8_t* desc, int n,
+                           int observed, oo_last_point* out);
+void oo_track_queries_n(const oo_track_pose* pose, const oo_last_point* lp, int n, oo_query* q);
+
 /* SearchByProjection(Frame& cur, const Frame& last, th, bMono): ORBmatcher.cc:1247-1383 (window,
  * argmin, TH_HIGH, rotation histogram).  Queries carry the projection.  Returns nmatches. */
 int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq, int check_orientation,

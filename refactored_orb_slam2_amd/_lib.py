@@ -37,6 +37,14 @@ MAP_POINT_DTYPE = np.dtype(
 TRACK_DTYPE = np.dtype(
     [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
 )
+UNPROJECT_CAM_DTYPE = np.dtype([("Rwc", "<f4", (9,)), ("Ow", "<f4", (3,)), ("cx", "<f4"), ("cy", "<f4"), ("invfx", "<f4"), ("invfy", "<f4")])
+LAST_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("valid", "<i4"), ("observed", "<i4"), ("octave", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
+TRACK_POSE_DTYPE = np.dtype(
+    [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("mbf", "<f4"),
+     ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"), ("forward", "<i4"), ("backward", "<i4"),
+     ("th", "<f4"), ("scale_factors", "<f4", (8,))]
+)
+assert UNPROJECT_CAM_DTYPE.itemsize == 64 and LAST_POINT_DTYPE.itemsize == 60 and TRACK_POSE_DTYPE.itemsize == 128
 assert FRUSTUM_DTYPE.itemsize == 136 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
 BF_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_dist", "<i4")])
 
@@ -74,7 +82,7 @@ EXPORTS = [
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
     "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
-    "orbfe_search_local_points_batch_device",
+    "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow",
 ]
@@ -146,6 +154,8 @@ def lib():
     L.orbfe_proj_candidates.argtypes = [C.POINTER(FrameView), vp, ci, vp, vp, ci]
     L.orbfe_search_by_projection_points.argtypes = [C.POINTER(FrameView), vp, ci, cf, vp, vp, pi]
     L.orbfe_search_by_projection_frame.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, pi]
+    L.orbfe_unproject_stereo_device.argtypes = [ci, vp, vp, vp, vp, ci, vp, ci, vp, vp]
+    L.orbfe_track_queries_device.argtypes = [ci, vp, vp, vp, ci, ci, vp, vp, vp]
     L.orbfe_search_local_points.argtypes = [C.POINTER(FrameView), vp, vp, ci, cf, cf, vp, vp, vp, pi, pi]
     L.orbfe_search_local_points_batch_device.argtypes = [vp, ci, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, ci, cf, cf,
                                                          vp, vp, vp, vp, vp, vp]

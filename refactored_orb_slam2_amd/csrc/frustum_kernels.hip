@@ -11,6 +11,7 @@
 #define MP_DW (int)(sizeof(orbfe_map_point) / 4)   // 18
 #define Q_DW (int)(sizeof(orbfe_query) / 4)        // 17
 #define TR_DW (int)(sizeof(orbfe_track) / 4)       // 6
+static_assert(sizeof(orbfe_last_point) == 60 && sizeof(orbfe_track_pose) == 128 && sizeof(orbfe_unproject_cam) == 64, "record layout");
 static_assert(sizeof(orbfe_map_point) == 72 && sizeof(orbfe_query) == 68 && sizeof(orbfe_track) == 24, "record layout");
 
 // glibc 2.35 logf (__logf_data, LOGF_TABLE_BITS = 4): {invc, logc} pairs.  Same constants as the oracle's oo_logf; the
@@ -156,6 +157,115 @@ __global__ __launch_bounds__(FQ_THREADS) void frustum_queries_kernel(const orbfe
   for (int o = tid; o < cnt * Q_DW; o += FQ_THREADS) qdst[o] = rec[(o / Q_DW) * MP_DW + (o % Q_DW)];
   uint32_t* tdst = reinterpret_cast<uint32_t*>(track + (size_t)f * p_cap + p0);
   for (int o = tid; o < cnt * TR_DW; o += FQ_THREADS) tdst[o] = trk[o];
+}
+
+// ---- Frame::UnprojectStereo (L/src/Frame.cc:668-679) for every keypoint: thread per keypoint
+__global__ __launch_bounds__(256) void unproject_stereo_kernel(const orbfe_keypoint* __restrict__ kps,
+                                                               const uint8_t* __restrict__ desc,
+                                                               const int32_t* __restrict__ n,
+                                                               const float* __restrict__ depth, int cap,
+                                                               const orbfe_unproject_cam* __restrict__ cams, int observed,
+                                                               orbfe_last_point* __restrict__ points) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t g = (size_t)f * cap + i;
+  orbfe_last_point p;
+  uint32_t* pw = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(p) / 4); j++) pw[j] = 0u;
+  if (i < n[f]) {
+    const orbfe_unproject_cam c = cams[f];
+    const orbfe_keypoint kp = kps[g];
+    const float z = depth[g];
+    if (z > 0) {
+      const float x = (kp.x - c.cx) * z * c.invfx;
+      const float y = (kp.y - c.cy) * z * c.invfy;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {   // mRwc * x3Dc + mOw: cv::gemm small-matrix path (float dot, double epilogue)
+        const float t = c.Rwc[3 * r] * x + c.Rwc[3 * r + 1] * y + c.Rwc[3 * r + 2] * z;
+        p.pos[r] = (float)((double)t * 1.0 + (double)c.Ow[r] * 1.0);
+      }
+      p.valid = 1;
+    }
+    p.observed = observed != 0;
+    p.octave = kp.octave;
+    p.angle = kp.angle;
+    const uint4* d = reinterpret_cast<const uint4*>(desc + g * 32);
+    const uint4 d0 = d[0], d1 = d[1];
+    uint32_t* dw = reinterpret_cast<uint32_t*>(p.desc);
+    dw[0] = d0.x; dw[1] = d0.y; dw[2] = d0.z; dw[3] = d0.w; dw[4] = d1.x; dw[5] = d1.y; dw[6] = d1.z; dw[7] = d1.w;
+  }
+  uint32_t* out = reinterpret_cast<uint32_t*>(points + g);
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(p) / 4); j++) out[j] = pw[j];
+}
+
+// ---- the projection part of SearchByProjection(cur, last) (L/src/ORBmatcher.cc:1270-1308): thread per last-frame point
+__global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_pose* __restrict__ poses,
+                                                            const orbfe_last_point* __restrict__ points,
+                                                            const int32_t* __restrict__ n_points, int p_cap, int n_frames,
+                                                            int frame_shift, orbfe_query* __restrict__ queries,
+                                                            int32_t* __restrict__ nq) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  int fs = (f - frame_shift) % n_frames;
+  if (fs < 0) fs += n_frames;
+  const int np = n_points[fs];
+  if (i == 0) nq[f] = np;
+  if (i >= p_cap) return;
+  orbfe_query q;
+  uint32_t* qw = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(q) / 4); j++) qw[j] = 0u;
+  if (i < np) {
+    const orbfe_track_pose P = poses[f];
+    orbfe_last_point lp;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(points + (size_t)fs * p_cap + i);
+    uint32_t* lw = reinterpret_cast<uint32_t*>(&lp);
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(lp) / 4); j++) lw[j] = src[j];
+    if (lp.valid) {
+      float xc3[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {   // Rcw * x3Dw + tcw
+        const float t = P.Rcw[3 * r] * lp.pos[0] + P.Rcw[3 * r + 1] * lp.pos[1] + P.Rcw[3 * r + 2] * lp.pos[2];
+        xc3[r] = (float)((double)t * 1.0 + (double)P.tcw[r] * 1.0);
+      }
+      const float invzc = (float)(1.0 / (double)xc3[2]);   // `1.0 / x3Dc.at<float>(2)`: double division (:1283)
+      if (!(invzc < 0)) {
+        const float u = P.fx * xc3[0] * invzc + P.cx;
+        const float v = P.fy * xc3[1] * invzc + P.cy;
+        if (!(u < P.min_x || u > P.max_x) && !(v < P.min_y || v > P.max_y)) {
+          const int oct = lp.octave;
+          q.u = u; q.v = v;
+          q.u_r = u - P.mbf * invzc;                                   // :1327
+          q.radius = P.th * P.scale_factors[oct & 7];                  // :1297
+          if (P.forward) { q.min_level = oct; q.max_level = -1; }      // GetFeaturesInArea(u, v, radius, nLastOctave)
+          else if (P.backward) { q.min_level = 0; q.max_level = oct; }
+          else { q.min_level = oct - 1; q.max_level = oct + 1; }
+          q.valid = 1;
+          q.blocks = lp.observed != 0;
+          q.angle = lp.angle;
+#pragma unroll
+          for (int j = 0; j < 8; j++) reinterpret_cast<uint32_t*>(q.desc)[j] = reinterpret_cast<const uint32_t*>(lp.desc)[j];
+        }
+      }
+    }
+  }
+  uint32_t* out = reinterpret_cast<uint32_t*>(queries + (size_t)f * p_cap + i);
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(q) / 4); j++) out[j] = qw[j];
+}
+
+void orbfe_launch_unproject_stereo(const orbfe_keypoint* kps, const uint8_t* desc, const int32_t* n, const float* depth, int cap,
+                                   const orbfe_unproject_cam* cams, int observed, orbfe_last_point* points, int n_frames,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(unproject_stereo_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, s, kps, desc, n, depth, cap, cams,
+                     observed, points);
+}
+void orbfe_launch_track_queries(const orbfe_track_pose* poses, const orbfe_last_point* points, const int32_t* n_points, int p_cap,
+                                int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames, hipStream_t s) {
+  hipLaunchKernelGGL(track_queries_kernel, dim3((p_cap + 255) / 256, n_frames), dim3(256), 0, s, poses, points, n_points, p_cap,
+                     n_frames, frame_shift, queries, nq);
 }
 
 void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,

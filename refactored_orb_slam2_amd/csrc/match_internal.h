@@ -72,6 +72,11 @@ struct BowParams {
   int32_t* counters;    // [0] pushes, [1] nmatches, [2..31] rotation histogram
   int32_t* push_idx; uint8_t* push_bin;
 };
+void orbfe_launch_unproject_stereo(const orbfe_keypoint* kps, const uint8_t* desc, const int32_t* n, const float* depth, int cap,
+                                   const orbfe_unproject_cam* cams, int observed, orbfe_last_point* points, int n_frames,
+                                   hipStream_t s);
+void orbfe_launch_track_queries(const orbfe_track_pose* poses, const orbfe_last_point* points, const int32_t* n_points, int p_cap,
+                                int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames, hipStream_t s);
 void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,
                                   int p_cap, float th, float viewing_cos_limit, orbfe_track* track, orbfe_query* queries,
                                   int32_t* n_to_match, int n_frames, hipStream_t s);

@@ -329,6 +329,29 @@ extern "C" int orbfe_search_by_projection_frame(const orbfe_frame_view* f, const
   return search_host(f, q, nq, 1, 0.f, check_orientation, blocked, assigned, n_matches);
 }
 
+// ---- motion-model tracking: UnprojectStereo + the projection part of SearchByProjection(cur, last)
+extern "C" int orbfe_unproject_stereo_device(int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                                             const int32_t* d_n, const float* d_depth, int cap,
+                                             const orbfe_unproject_cam* d_cam, int observed, orbfe_last_point* d_points,
+                                             void* stream) {
+  if (!d_kps || !d_desc || !d_n || !d_depth || !d_cam || !d_points || n_frames < 1 || cap < 1) return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_desc & 15) || ((uintptr_t)d_kps & 3) || ((uintptr_t)d_points & 3) || ((uintptr_t)d_cam & 3)) {
+    orbfe_set_error("descriptors must be 16-byte aligned, records 4-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  orbfe_launch_unproject_stereo(d_kps, d_desc, d_n, d_depth, cap, d_cam, observed, d_points, n_frames, (hipStream_t)stream);
+  return launch_ok();
+}
+
+extern "C" int orbfe_track_queries_device(int n_frames, const orbfe_track_pose* d_pose, const orbfe_last_point* d_points,
+                                          const int32_t* d_n_points, int p_cap, int frame_shift, orbfe_query* d_queries,
+                                          int32_t* d_nq, void* stream) {
+  if (!d_pose || !d_points || !d_n_points || !d_queries || !d_nq || n_frames < 1 || p_cap < 1) return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_pose & 3) || ((uintptr_t)d_points & 3) || ((uintptr_t)d_queries & 3)) return ORBFE_ERR_INVALID;
+  orbfe_launch_track_queries(d_pose, d_points, d_n_points, p_cap, frame_shift, d_queries, d_nq, n_frames, (hipStream_t)stream);
+  return launch_ok();
+}
+
 // ---- Tracking::SearchLocalPoints (L/src/Tracking.cc:1050-1078): isInFrustum -> queries (in HBM) -> SearchByProjection
 static int local_points_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
                                 const int32_t* d_n, const float* d_ur, int cap, float min_x, float max_x, float min_y,

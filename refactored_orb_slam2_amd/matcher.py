@@ -220,6 +220,24 @@ def search_by_bow_kf(descA, angleA, validA, groupsA, descB, angleB, validB, grou
     return nm.value, matchA
 
 
+def unproject_stereo_batch(kps, desc, n, depth, cams, observed, points, stream):
+    """Frame::UnprojectStereo for every keypoint of a batch (torch CUDA tensors): kps (F,cap,28) u8, desc (F,cap,32) u8,
+    n (F) i32, depth (F,cap) f32, cams (F,64) u8 [UNPROJECT_CAM_DTYPE], points (F,cap,60) u8 out [LAST_POINT_DTYPE]."""
+    F, cap = desc.shape[0], desc.shape[1]
+    _lib.check(_lib.lib().orbfe_unproject_stereo_device(F, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n), _lib.ptr(depth), cap,
+                                                        _lib.ptr(cams), int(observed), _lib.ptr(points), _lib.stream_handle(stream)),
+               "orbfe_unproject_stereo_device")
+
+
+def track_queries_batch(poses, points, n_points, frame_shift, queries, nq, stream):
+    """Projection part of SearchByProjection(cur, last) (ORBmatcher.cc:1257-1308): poses (F,128) u8 [TRACK_POSE_DTYPE],
+    points (F,pcap,60) u8, n_points (F) i32 -> queries (F,pcap,68) u8, nq (F) i32."""
+    F, pcap = points.shape[0], points.shape[1]
+    _lib.check(_lib.lib().orbfe_track_queries_device(F, _lib.ptr(poses), _lib.ptr(points), _lib.ptr(n_points), pcap, int(frame_shift),
+                                                     _lib.ptr(queries), _lib.ptr(nq), _lib.stream_handle(stream)),
+               "orbfe_track_queries_device")
+
+
 def featvec_arrays(groups: dict):
     """{node_id: [indices]} -> (ctypes array of orbfe_featvec_node sorted by id, count, flat int32 index array)."""
     ids = sorted(groups)

@@ -38,6 +38,13 @@ MAP_POINT_DTYPE = np.dtype(
 TRACK_DTYPE = np.dtype(
     [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
 )
+UNPROJECT_CAM_DTYPE = np.dtype([("Rwc", "<f4", (9,)), ("Ow", "<f4", (3,)), ("cx", "<f4"), ("cy", "<f4"), ("invfx", "<f4"), ("invfy", "<f4")])
+LAST_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("valid", "<i4"), ("observed", "<i4"), ("octave", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
+TRACK_POSE_DTYPE = np.dtype(
+    [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("mbf", "<f4"),
+     ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"), ("forward", "<i4"), ("backward", "<i4"),
+     ("th", "<f4"), ("scale_factors", "<f4", (8,))]
+)
 assert FRUSTUM_DTYPE.itemsize == 136 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
 
 GRID_COLS, GRID_ROWS = 64, 48
@@ -119,6 +126,14 @@ def lib():
     L.oo_features_in_area.argtypes = [C.POINTER(OOFrame), cf, cf, cf, ci, ci, vp]
     L.oo_search_by_projection_points.restype = ci
     L.oo_search_by_projection_points.argtypes = [C.POINTER(OOFrame), vp, ci, cf, vp, vp]
+    L.oo_unproject_stereo.restype = None
+    L.oo_unproject_stereo.argtypes = [vp, vp, cf, vp, ci, vp]
+    L.oo_track_query.restype = None
+    L.oo_track_query.argtypes = [vp, vp, vp]
+    L.oo_unproject_stereo_n.restype = None
+    L.oo_unproject_stereo_n.argtypes = [vp, vp, vp, vp, ci, ci, vp]
+    L.oo_track_queries_n.restype = None
+    L.oo_track_queries_n.argtypes = [vp, vp, ci, vp]
     L.oo_logf.restype = cf
     L.oo_logf.argtypes = [cf]
     L.oo_predict_scale.restype = ci
@@ -342,6 +357,23 @@ def _kf(self, queries, check_orientation=True, orb_dist=100, blocked=None):
 
 
 OracleFrame.search_by_projection_keyframe = _kf
+
+
+def unproject_stereo(cam, keys, desc, depth, observed=1):
+    cam = np.ascontiguousarray(cam, UNPROJECT_CAM_DTYPE).reshape(1)
+    keys = np.ascontiguousarray(keys, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    out = np.zeros(len(keys), LAST_POINT_DTYPE)
+    depth = np.ascontiguousarray(depth[: len(keys)], np.float32)
+    lib().oo_unproject_stereo_n(_p(cam), _p(keys), _p(depth), _p(desc), len(keys), observed, _p(out))
+    return out
+
+
+def track_queries(pose, points):
+    pose = np.ascontiguousarray(pose, TRACK_POSE_DTYPE).reshape(1)
+    pts = np.ascontiguousarray(points, LAST_POINT_DTYPE)
+    q = np.zeros(len(pts), QUERY_DTYPE)
+    lib().oo_track_queries_n(_p(pose), _p(pts), len(pts), _p(q))
+    return q
 
 
 def is_in_frustum(frustum, points, viewing_cos_limit=0.5):

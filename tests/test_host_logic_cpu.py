@@ -53,32 +53,34 @@ def test_shard_range_partitions_frames():
         sharding.shard_range(4, 4, 4)
 
 
-def test_bench_query_builder_matches_record_layout():
+def test_bench_camera_reprojects_the_known_image_motion():
+    """bench.camera_records: stereo points of frame f-1 (oracle UnprojectStereo), projected with frame f's camera (oracle
+    track query), land SHIFT_X px from where they were seen, with the reference's radius / level range / right coordinate"""
     sys.path.insert(0, ROOT)
     import bench
     rng = np.random.default_rng(1)
-    F, cap = 3, 50
-    kp = np.zeros((F, cap), KP_DTYPE)
-    kp["x"] = rng.uniform(20, 1200, (F, cap)).astype(np.float32); kp["y"] = rng.uniform(20, 350, (F, cap)).astype(np.float32)
-    kp["angle"] = rng.uniform(0, 360, (F, cap)).astype(np.float32); kp["octave"] = rng.integers(0, 8, (F, cap))
-    desc = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
-    n = np.array([50, 31, 44], np.int32)
-    ur = np.where(rng.random((F, cap)) < 0.7, kp["x"] - 20, -1).astype(np.float32)
+    n = 400
+    kp = np.zeros(n, KP_DTYPE)
+    kp["x"] = rng.uniform(20, 1200, n).astype(np.float32); kp["y"] = rng.uniform(20, 350, n).astype(np.float32)
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32); kp["octave"] = rng.integers(0, 8, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    disparity = rng.uniform(3, 80, n).astype(np.float32)
+    depth = np.where(rng.random(n) < 0.7, np.float32(bench.MBF) / disparity, -1).astype(np.float32)
     sf = ol.OracleExtractor(100).scale_factors
-    q, nq = bench.build_queries(torch, torch.from_numpy(kp.view(np.uint8).reshape(F, cap, 28)), torch.from_numpy(desc),
-                                torch.from_numpy(n), torch.from_numpy(ur), torch.from_numpy(sf), -2.0)
-    rec = q.numpy().reshape(F, cap * 68).view(QUERY_DTYPE).reshape(F, cap)
-    for f in range(F):
-        last = (f - 1) % F
-        assert int(nq[f]) == n[last]
-        np.testing.assert_array_equal(rec[f]["u"], kp[last]["x"] + np.float32(-2.0))
-        np.testing.assert_array_equal(rec[f]["v"], kp[last]["y"])
-        np.testing.assert_array_equal(rec[f]["radius"], np.float32(7.0) * sf[kp[last]["octave"]])
-        np.testing.assert_array_equal(rec[f]["min_level"], kp[last]["octave"] - 1)
-        np.testing.assert_array_equal(rec[f]["max_level"], kp[last]["octave"] + 1)
-        np.testing.assert_array_equal(rec[f]["desc"], desc[last])
-        np.testing.assert_array_equal(rec[f]["angle"], kp[last]["angle"])
-        np.testing.assert_array_equal(rec[f]["valid"], ((np.arange(cap) < n[last]) & (ur[last] >= 0)).astype(np.int32))
+    cams, poses = bench.camera_records(2, sf)
+    assert cams.dtype.itemsize == 64 and poses.dtype.itemsize == 128
+    pts = ol.unproject_stereo(cams[:1], kp, desc, depth)
+    q = ol.track_queries(poses[1:2], pts)
+    ok = depth > 0
+    np.testing.assert_array_equal(q["valid"] == 1, ok & (kp["x"] + bench.SHIFT_X >= 0))
+    v = q["valid"] == 1
+    assert np.abs(q["u"][v] - (kp["x"][v] + np.float32(bench.SHIFT_X))).max() < 2e-3 and np.abs(q["v"][v] - kp["y"][v]).max() < 2e-3
+    assert np.abs((q["u"][v] - q["u_r"][v]) - disparity[v]).max() < 2e-3        # u_r = u - mbf / z
+    np.testing.assert_array_equal(q["radius"][v], np.float32(bench.TH_STEREO) * sf[kp["octave"][v]])
+    np.testing.assert_array_equal(q["min_level"][v], kp["octave"][v] - 1)
+    np.testing.assert_array_equal(q["max_level"][v], kp["octave"][v] + 1)
+    np.testing.assert_array_equal(q["desc"][v], desc[v]); np.testing.assert_array_equal(q["angle"][v], kp["angle"][v])
+    assert (q["blocks"][v] == 1).all()
 
 
 def _free_port():

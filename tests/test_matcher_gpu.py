@@ -247,6 +247,76 @@ def test_search_local_points_batch_device():
     m.close()
 
 
+@pytest.mark.parametrize("mode", ["window", "forward", "backward"])
+def test_unproject_and_track_queries_device(mode):
+    """Frame::UnprojectStereo + the projection part of SearchByProjection(cur, last) on the device, then the search itself:
+    records, queries and matches equal the oracle's"""
+    import torch
+    from refactored_orb_slam2_amd import synth
+    from refactored_orb_slam2_amd.matcher import Matcher, unproject_stereo_batch, track_queries_batch
+    from refactored_orb_slam2_amd._lib import LAST_POINT_DTYPE, QUERY_DTYPE
+    w, h, F = 752, 480, 3
+    frames = [_two_frames(w, h, 1200, seed=s)[2:] for s in range(F)]
+    cap = max(len(f[0]) for f in frames) + 7
+    rng = np.random.default_rng(4)
+    kps = np.zeros((F, cap), ol.KP_DTYPE); desc = np.zeros((F, cap, 32), np.uint8); n = np.zeros(F, np.int32)
+    depth = np.full((F, cap), -1, np.float32)
+    cams = np.zeros(F, ol.UNPROJECT_CAM_DTYPE); poses = np.zeros(F, ol.TRACK_POSE_DTYPE)
+    sf = frames[0][2]
+    for i, (k1, d1, _) in enumerate(frames):
+        kps[i, :len(k1)] = k1; desc[i, :len(k1)] = d1; n[i] = len(k1)
+        z = rng.uniform(2, 60, len(k1)).astype(np.float32); z[rng.random(len(k1)) < 0.25] = -1   # no stereo match
+        z[:3] = [0.0, 1e-30, 1e30]
+        depth[i, :len(k1)] = z
+        R, t = synth.camera_pose(200 + i)
+        cams["Rwc"][i] = R.T.reshape(9); cams["Ow"][i] = -(R.T @ t)
+        cams["cx"][i] = 370.0; cams["cy"][i] = 236.5; cams["invfx"][i] = np.float32(1) / np.float32(458.654); cams["invfy"][i] = np.float32(1) / np.float32(457.296)
+        # the current frame of frame i's points is frame i+1: nearly the same pose (small motion), so most points project inside
+        R2, t2 = synth.camera_pose(200 + i)
+        t2 = t2 + np.array([0.05, -0.02, 0.3 if mode == "forward" else (-0.3 if mode == "backward" else 0.0)], np.float32)
+        j = (i + 1) % F
+        poses["Rcw"][j] = R2.reshape(9); poses["tcw"][j] = t2
+        poses["fx"][j] = 458.654; poses["fy"][j] = 457.296; poses["cx"][j] = 367.215; poses["cy"][j] = 248.375; poses["mbf"][j] = 47.9
+        poses["min_x"][j] = 0; poses["max_x"][j] = w; poses["min_y"][j] = 0; poses["max_y"][j] = h
+        poses["forward"][j] = mode == "forward"; poses["backward"][j] = mode == "backward"
+        poses["th"][j] = 15.0; poses["scale_factors"][j] = sf
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape + (-1,)) if a.dtype.names else a).cuda()
+    t_kps, t_desc, t_n, t_depth, t_cams, t_poses = dev(kps), dev(desc), dev(n), dev(depth), dev(cams), dev(poses)
+    t_pts = torch.zeros((F, cap, 60), dtype=torch.uint8, device="cuda")
+    t_q = torch.zeros((F, cap, 68), dtype=torch.uint8, device="cuda")
+    t_nq = torch.zeros(F, dtype=torch.int32, device="cuda")
+    t_blocked = torch.zeros((F, cap), dtype=torch.uint8, device="cuda")
+    t_assigned = torch.full((F, cap), -1, dtype=torch.int32, device="cuda")
+    t_nm = torch.zeros(F, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    m = Matcher()
+    with torch.cuda.stream(s):
+        unproject_stereo_batch(t_kps, t_desc, t_n, t_depth, t_cams, 1, t_pts, s)
+        track_queries_batch(t_poses, t_pts, t_n, 1, t_q, t_nq, s)
+        m.proj_match_batch(t_kps, t_desc, t_n, None, (0.0, float(w), 0.0, float(h)), t_q, t_nq, 1, 0.9, True, t_blocked, t_assigned,
+                           t_nm, stream=s)
+    s.synchronize()
+    g_pts = t_pts.cpu().numpy().reshape(F, cap * 60).view(LAST_POINT_DTYPE).reshape(F, cap)
+    g_q = t_q.cpu().numpy().reshape(F, cap * 68).view(QUERY_DTYPE).reshape(F, cap)
+    tot_valid = 0
+    for i, (k1, d1, _) in enumerate(frames):
+        opts = ol.unproject_stereo(cams[i:i + 1], k1, d1, depth[i])
+        assert g_pts[i, :len(k1)].tobytes() == opts.tobytes()
+        j = (i + 1) % F
+        oq = ol.track_queries(poses[j:j + 1], opts)
+        assert int(t_nq[j]) == len(k1)
+        assert g_q[j, :len(k1)].tobytes() == oq.tobytes()
+        tot_valid += int(oq["valid"].sum())
+        kj, dj, _ = frames[j]
+        of = ol.OracleFrame(kj, dj, sf, 0, w, 0, h, None)
+        onm, oassigned, oblocked = of.search_by_projection_frame(oq, True)
+        assert int(t_nm[j]) == onm
+        np.testing.assert_array_equal(t_assigned[j].cpu().numpy()[: len(kj)], oassigned)
+    assert tot_valid > 0.4 * int(n.sum())
+    m.close()
+
+
 @pytest.mark.parametrize("th,orb_dist", [(10.0, 100), (3.0, 64), (10.0, 30)])
 def test_search_by_projection_keyframe(th, orb_dist):
     """Relocalization's SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist): no stereo gate (u_right present in the
@@ -464,13 +534,21 @@ def test_bench_pipeline_matches_oracle():
     n_tr = torch.zeros(F, dtype=torch.int32, device=dev)
     sf = exL.GetScaleFactors(); isf = exL.GetInverseScaleFactors()
     mb = bench.MBF / bench.FX
+    from refactored_orb_slam2_amd.matcher import track_queries_batch, unproject_stereo_batch
+    cams_np, poses_np = bench.camera_records(F, sf)
+    t_cams = torch.from_numpy(cams_np.view(np.uint8).reshape(F, -1)).to(dev)
+    t_poses = torch.from_numpy(poses_np.view(np.uint8).reshape(F, -1)).to(dev)
+    pts = torch.zeros((F, cap, 60), dtype=torch.uint8, device=dev)
+    q = torch.zeros((F, cap, 68), dtype=torch.uint8, device=dev)
+    nq = torch.zeros(F, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     exL.extract_batch_device(dL, kl, dl, nl); exR.extract_batch_device(dR, kr, dr, nr)
     exL.sync(); exR.sync()
     cur = torch.cuda.Stream()
     with torch.cuda.stream(cur):
         mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, bench.MBF, mb, ur, depth, n_st, stream=cur)
-        q, nq = bench.build_queries(torch, kl, dl, nl, ur, torch.from_numpy(sf).to(dev), -2.0)
+        unproject_stereo_batch(kl, dl, nl, depth, t_cams, 1, pts, cur)
+        track_queries_batch(t_poses, pts, nl, 1, q, nq, cur)
         mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned, n_tr, stream=cur)
     torch.cuda.synchronize()
     qh = q.cpu().numpy().reshape(F, cap * 68).view(QUERY_DTYPE).reshape(F, cap)
@@ -480,7 +558,17 @@ def test_bench_pipeline_matches_oracle():
         d = dl[f].cpu().numpy()[:n]
         u = ur[f].cpu().numpy()[:n]
         of = ol.OracleFrame(k, d, sf, 0, W, 0, H, u)
-        onm, oa, ob = of.search_by_projection_frame(qh[f, : int(nq[f])], True)
+        # the queries of frame f: the stereo points of frame f-1 (oracle UnprojectStereo) projected with frame f's camera
+        fp = (f - 1) % F
+        npv = int(nl[fp])
+        kp = kl[fp].cpu().numpy().view(KP_DTYPE).reshape(-1)[:npv]
+        opts = ol.unproject_stereo(cams_np[fp:fp + 1], kp, dl[fp].cpu().numpy()[:npv], depth[fp].cpu().numpy()[:npv])
+        oq = ol.track_queries(poses_np[f:f + 1], opts)
+        assert int(nq[f]) == npv and qh[f, :npv].tobytes() == oq.tobytes()
+        # the projection reproduces the known image motion of the synthetic sequence
+        ok = oq["valid"] == 1
+        assert np.abs(oq["u"][ok] - (kp["x"][ok] + np.float32(bench.SHIFT_X))).max() < 2e-3 and np.array_equal(oq["v"][ok] > 0, ok[ok])
+        onm, oa, ob = of.search_by_projection_frame(oq, True)
         assert int(n_tr[f]) == onm, f
         np.testing.assert_array_equal(assigned[f].cpu().numpy()[:n], oa)
         np.testing.assert_array_equal(blocked[f].cpu().numpy()[:n], ob)

@@ -118,6 +118,40 @@ def test_is_in_frustum_known_answers():
         assert lvl == min(max(exp, 0), 7) and abs(lvl - k) <= 1
 
 
+def test_unproject_and_track_query_known_answers():
+    """Frame::UnprojectStereo (Frame.cc:668-679) and the projection of SearchByProjection(cur, last) (ORBmatcher.cc:1270-1308)"""
+    cam = np.zeros(1, ol.UNPROJECT_CAM_DTYPE)
+    cam["Rwc"][0] = np.eye(3, dtype=np.float32).reshape(9); cam["Ow"][0] = [1, 2, 3]
+    cam["cx"] = 320; cam["cy"] = 240; cam["invfx"] = np.float32(1) / np.float32(500); cam["invfy"] = np.float32(1) / np.float32(500)
+    keys = np.zeros(3, ol.KP_DTYPE); keys["x"] = [320, 820, 100]; keys["y"] = [240, 240, 40]; keys["octave"] = [0, 3, 7]; keys["angle"] = [10, 20, 30]
+    desc = np.arange(96, dtype=np.uint8).reshape(3, 32)
+    pts = ol.unproject_stereo(cam, keys, desc, np.array([10, 5, -1], np.float32))
+    assert pts["valid"].tolist() == [1, 1, 0] and pts["octave"].tolist() == [0, 3, 7] and pts["observed"].tolist() == [1, 1, 1]
+    assert pts["pos"][0].tolist() == [1.0, 2.0, 13.0]              # on the axis, depth 10, camera centre (1,2,3)
+    x1 = np.float32(np.float32(np.float32(500) * np.float32(5)) * cam["invfx"][0])
+    assert pts["pos"][1].tolist() == [float(x1 + np.float32(1)), 2.0, 8.0]
+    assert pts["pos"][2].tolist() == [0, 0, 0] and (pts["desc"] == desc).all()
+    pose = np.zeros(1, ol.TRACK_POSE_DTYPE)
+    pose["Rcw"][0] = np.eye(3, dtype=np.float32).reshape(9); pose["tcw"][0] = [-1, -2, -3]      # same camera
+    pose["fx"] = 500; pose["fy"] = 500; pose["cx"] = 318; pose["cy"] = 240; pose["mbf"] = 40    # principal point moved by -2
+    pose["max_x"] = 640; pose["max_y"] = 480; pose["th"] = 7
+    pose["scale_factors"][0] = np.cumprod(np.r_[1, [np.float32(1.2)] * 7]).astype(np.float32)
+    q = ol.track_queries(pose, pts)
+    assert q["valid"].tolist() == [1, 0, 0]                        # point 1 projects to u = 818 > 640, point 2 has no map point
+    assert (q["u"][0], q["v"][0], q["u_r"][0], q["radius"][0]) == (318.0, 240.0, 314.0, 7.0)
+    assert (q["min_level"][0], q["max_level"][0], q["blocks"][0], q["angle"][0]) == (-1, 1, 1, 10.0)
+    pose["max_x"] = 1000
+    q = ol.track_queries(pose, pts)
+    assert q["valid"].tolist() == [1, 1, 0] and (q["min_level"][1], q["max_level"][1]) == (2, 4)
+    assert q["radius"][1] == np.float32(7) * pose["scale_factors"][0][3]
+    pose["forward"] = 1
+    assert tuple(ol.track_queries(pose, pts)[["min_level", "max_level"]][1]) == (3, -1)
+    pose["forward"] = 0; pose["backward"] = 1
+    assert tuple(ol.track_queries(pose, pts)[["min_level", "max_level"]][1]) == (0, 3)
+    pose["tcw"][0] = [-1, -2, -20]                                 # behind the camera: invzc < 0
+    assert ol.track_queries(pose, pts)["valid"].tolist() == [0, 0, 0]
+
+
 def test_is_in_frustum_vs_numpy_restatement():
     """independent numpy restatement of the cv::Mat arithmetic (float gemm, double norm / dot)"""
     rng = np.random.default_rng(12)
