@@ -976,7 +976,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 // (64+8)x(32+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
 // REFLECT_101 indexing.  Both passes produce 4 adjacent pixels per work item (dword LDS/global accesses).
 #define BT_W 64
-#define BT_H 32
+#define BT_H ORBFE_BLUR_TILE_H   // 58: (58 + 6) / 2 = 32 row pairs x 16 groups = exactly two full 256-thread passes
 #define BT_INP 80   // LDS pitch (bytes) of the input window: column j <-> level x = ox - 4 + j
 #define BT_HP 68    // LDS pitch (dwords) of one row PAIR of the horizontal-pass result (two u16 rows interleaved)
 __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles) {
@@ -993,13 +993,14 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
   {
-    // (32+6) rows x 18 dwords (x = ox-4 .. ox+67): three per thread, all issued before the first LDS store.  A dword that
+    // (BT_H+6) rows x 18 dwords (x = ox-4 .. ox+67): five per thread, all issued before the first LDS store.  A dword that
     // lies inside the row is one aligned load; the few that straddle the image border (left edge, the partial dword at
     // the right edge, columns beyond it) are assembled from bytes with REFLECT_101 indexing.  Rows reflect as a whole.
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
-    uint32_t v[3];
+    constexpr int NLD = ((BT_H + 6) * 18 + 255) / 256;
+    uint32_t v[NLD];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < NLD; k++) {
       const int i = tid + 256 * k;
       const int r = i / 18, c = i - r * 18;
       v[k] = 0u;
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
       }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < NLD; k++) {
       const int i = tid + 256 * k;
       const int r = i / 18, c = i - r * 18;
       if (i < (BT_H + 6) * 18) in32[r * (BT_INP / 4) + c] = v[k];
@@ -1052,7 +1053,8 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   // vertical pass: thread = (4-pixel group g, row pair rp): output rows 2rp, 2rp+1 from the row pairs rp .. rp+3
   {
     typedef __attribute__((ext_vector_type(2))) unsigned short us2;
-    const int g = tid & 15, rp = tid >> 4;
+    for (int it = tid; it < (BT_H / 2) * 16; it += 256) {
+    const int g = it & 15, rp = it >> 4;
     uint4 P[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4*>(hbp + (rp + k) * BT_HP + 4 * g);
@@ -1076,6 +1078,7 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     if (gx < w) {
       if (gy < h) *reinterpret_cast<uint32_t*>(D + (size_t)gy * dst.pitch[lvl] + gx) = outE;
       if (gy + 1 < h) *reinterpret_cast<uint32_t*>(D + (size_t)(gy + 1) * dst.pitch[lvl] + gx) = outO;
+    }
     }
   }
 }

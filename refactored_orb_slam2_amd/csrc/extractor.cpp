@@ -300,7 +300,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     o.key_cap = (int)std::min<size_t>(level_slots, 0xFFFFFF);
     key_off += level_slots;
     // blur tiles
-    for (int ty = 0; ty < (g.h + 31) / 32; ty++)
+    for (int ty = 0; ty < (g.h + ORBFE_BLUR_TILE_H - 1) / ORBFE_BLUR_TILE_H; ty++)
       for (int tx = 0; tx < (g.w + 63) / 64; tx++) e->tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
   }
   e->total_cells = (int)e->cells.size();

@@ -8,6 +8,7 @@
 #define ORBFE_EDGE 16            // minBorder = EDGE_THRESHOLD - 3 (L/src/ORBextractor.cc:740)
 #define ORBFE_CELL_MAX 66        // largest FAST cell ROI side the cell kernel stages in LDS
 #define ORBFE_TILE_PITCH 72      // LDS row pitch of the staged ROI (ROI side + 3 bytes alignment slack)
+#define ORBFE_BLUR_TILE_H 58      // rows of a blur tile (64 wide); must be even
 #define ORBFE_MAX_INI 256        // largest nIni (root nodes of DistributeOctTree) supported
 #define ORBFE_OCT_THREADS 256
 
