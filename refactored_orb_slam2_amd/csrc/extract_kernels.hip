@@ -1161,8 +1161,8 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 
 // One wave per keypoint slot.  IC_Angle on the un-blurred level, steered BRIEF on the blurred level,
 // 4 x __ballot -> 256 bits; writes the cv::KeyPoint record (pt scaled to level-0 pixels) and 32 bytes.
-#define ORI_PITCH 36
-#define DSC_PITCH 40
+#define ORI_PITCH 48   // 3 x 16 B: (cx - 15) & 15 <= 15, 15 + 31 <= 48
+#define DSC_PITCH 64   // 4 x 16 B: 15 + 37 <= 64
 #define ORI_BYTES (31 * ORI_PITCH)                        // 1116
 #define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 2608
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) {
@@ -1171,8 +1171,22 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   // everything that identifies the wave's keypoint is wave-uniform: readfirstlane keeps it (and all the address
   // arithmetic that follows) in SGPRs / on the scalar unit instead of 64 redundant VALU lanes
   const int wv_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int slot = blockIdx.x * 4 + wv_id;
-  const int img = blockIdx.y;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest).  The patch gather
+  // is bound by L2 misses (every patch byte used to come over the fabric: the planes of the ~4 images in flight do not
+  // fit one XCD's 4 MB L2 when each XCD sees all of them), so XCD k takes whole images k, k+8, ...: the planes of the one
+  // image an XCD is working on (2.9 MB) stay in its L2 and neighbouring patches share their lines.
+  int bx = blockIdx.x, img = blockIdx.y;
+  if (P.xcd_images) {
+    const unsigned gx = gridDim.x;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned grp = lin / (8u * gx);
+    if (8u * grp + 8u <= gridDim.y) {
+      const unsigned within = lin - grp * 8u * gx;
+      img = (int)(8u * grp + (within & 7u));
+      bx = (int)(within >> 3);
+    }
+  }
+  const int slot = bx * 4 + wv_id;
   // the four pattern entries of this lane (rounds 0..3): issued early, consumed after the orientation
   float4 pk[4];
 #pragma unroll
@@ -1206,32 +1220,33 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   const int bpitch = P.blur.pitch[level];
   const uint8_t* plane = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level];
   const uint8_t* bplane = P.blur.base[level] + (size_t)img * P.blur.img_stride[level];
-  const int ax_o = (cx - 15) & ~3, ax_d = (cx - 18) & ~3;
-  constexpr int ndw_o = 9, ndw_d = 10;  // enough for any alignment; the extra dword stays inside the row pitch + slack
-  uint32_t vo[5], vd[6];
+  // 16-byte loads: 31 x 3 + 37 x 4 = 241 per keypoint, four per lane (the gather is bound by address processing / L2
+  // requests, not bytes: 4-byte loads needed eleven per lane).  A row's last 16 bytes may lie beyond the image width
+  // (inside the pitch, or the plane buffers' slack for the last row); those bytes are never used.
+  const int ax_o = (cx - 15) & ~15, ax_d = (cx - 18) & ~15;
+  uint4 vo[2], vd[3];
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 2; k++) {
     const int i = lane + WAVE * k;
-    const int r = i / ndw_o, c = i - r * ndw_o;
-    vo[k] = i < 31 * ndw_o ? *reinterpret_cast<const uint32_t*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 4 * c) : 0u;
+    const int r = i / 3, c = i - r * 3;
+    vo[k] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 16 * c) : make_uint4(0, 0, 0, 0);
   }
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 3; k++) {
     const int i = lane + WAVE * k;
-    const int r = i / ndw_d, c = i - r * ndw_d;
-    vd[k] = i < 37 * ndw_d ? *reinterpret_cast<const uint32_t*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 4 * c) : 0u;
+    const int r = i >> 2, c = i & 3;
+    vd[k] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 16 * c) : make_uint4(0, 0, 0, 0);
   }
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 2; k++) {
     const int i = lane + WAVE * k;
-    const int r = i / ndw_o, c = i - r * ndw_o;
-    if (i < 31 * ndw_o) reinterpret_cast<uint32_t*>(ori)[r * (ORI_PITCH / 4) + c] = vo[k];
+    const int r = i / 3, c = i - r * 3;
+    if (i < 31 * 3) reinterpret_cast<uint4*>(ori)[r * (ORI_PITCH / 16) + c] = vo[k];
   }
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 3; k++) {
     const int i = lane + WAVE * k;
-    const int r = i / ndw_d, c = i - r * ndw_d;
-    if (i < 37 * ndw_d) reinterpret_cast<uint32_t*>(dsc)[r * (DSC_PITCH / 4) + c] = vd[k];
+    if (i < 37 * 4) reinterpret_cast<uint4*>(dsc)[i] = vd[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1367,7 +1382,11 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
   dim3 block(256), grid((p.kp_per_image + 3) / 4 > 0 ? (p.kp_per_image + 3) / 4 : 1, n_images);
-  hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, p);
+  static int xcd = -1;
+  if (xcd < 0) { const char* ev = getenv("ORBFE_DESC_XCD"); xcd = ev ? atoi(ev) : 1; }  // A/B knob
+  DescribeParams pp = p;
+  pp.xcd_images = xcd;
+  hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, pp);
 }
 
 int orbfe_upload_pattern_floats() {

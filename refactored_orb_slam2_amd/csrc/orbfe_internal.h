@@ -93,6 +93,7 @@ struct DescribeParams {
   uint8_t* out_desc;
   int32_t* out_n;
   int cap;
+  int xcd_images;   // 1: XCD k works on images k, k+8, ... (see orient_describe_kernel)
 };
 
 struct BlurTile {
