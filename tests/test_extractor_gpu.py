@@ -171,6 +171,21 @@ def test_other_extractor_parameters(params):
     ex.close()
 
 
+@pytest.mark.parametrize("w,h,nf", [(91, 91, 300), (123, 95, 300), (1920, 1080, 4000), (2047, 211, 1500), (64, 64, 100)])
+def test_unusual_geometries(w, h, nf):
+    """cell sizes at the extremes (one 59 x 59 cell per level; 64 x 34 cell rows of a full-HD frame; a strip), odd widths,
+    an image too small for any upper level: whole-pipeline equality with the oracle"""
+    img = synth.frame(w, h, seq=7, f=1) if w <= 1600 else np.tile(synth.frame(960, 540, seq=7, f=1), (2, 2))[:h, :w].copy()
+    ex = ORBextractor(nf)
+    r = ex(img)
+    ok, od = ol.OracleExtractor(nf)(img)
+    assert r is not None
+    np.testing.assert_array_equal(r[0], ok); np.testing.assert_array_equal(r[1], od)
+    if w >= 91:
+        assert len(ok) > 20
+    ex.close()
+
+
 def test_dense_texture_spills_keys_to_hbm():
     """white noise: tens of thousands of FAST candidates per level (> the LDS key budget) -> global-key path"""
     rng = np.random.default_rng(0)
