@@ -206,23 +206,31 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
                                                             const int32_t* __restrict__ n_points, int p_cap, int n_frames,
                                                             int frame_shift, orbfe_query* __restrict__ queries,
                                                             int32_t* __restrict__ nq) {
-  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  constexpr int LP_DW = (int)(sizeof(orbfe_last_point) / 4);  // 15
+  __shared__ uint32_t rec[256 * Q_DW];  // the block's 256 point records in (15 dwords each), its queries out (17 each):
+                                        // both move as coalesced dwords instead of 60- / 68-byte strided accesses
+  const int f = blockIdx.y, tid = threadIdx.x, p0 = blockIdx.x * 256;
   int fs = (f - frame_shift) % n_frames;
   if (fs < 0) fs += n_frames;
   const int np = n_points[fs];
-  if (i == 0) nq[f] = np;
-  if (i >= p_cap) return;
+  if (p0 == 0 && tid == 0) nq[f] = np;
+  const int cnt = min(256, p_cap - p0);        // query slots this block owns
+  const int have = max(0, min(cnt, np - p0));  // of which backed by a point
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(points + (size_t)fs * p_cap + p0);
+    for (int i = tid; i < have * LP_DW; i += 256) rec[i] = src[i];
+  }
+  __syncthreads();
   orbfe_query q;
   uint32_t* qw = reinterpret_cast<uint32_t*>(&q);
 #pragma unroll
-  for (int j = 0; j < (int)(sizeof(q) / 4); j++) qw[j] = 0u;
-  if (i < np) {
+  for (int j = 0; j < Q_DW; j++) qw[j] = 0u;
+  if (tid < have) {
     const orbfe_track_pose P = poses[f];
     orbfe_last_point lp;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(points + (size_t)fs * p_cap + i);
     uint32_t* lw = reinterpret_cast<uint32_t*>(&lp);
 #pragma unroll
-    for (int j = 0; j < (int)(sizeof(lp) / 4); j++) lw[j] = src[j];
+    for (int j = 0; j < LP_DW; j++) lw[j] = rec[tid * LP_DW + j];
     if (lp.valid) {
       float xc3[3];
 #pragma unroll
@@ -251,9 +259,12 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
       }
     }
   }
-  uint32_t* out = reinterpret_cast<uint32_t*>(queries + (size_t)f * p_cap + i);
+  __syncthreads();   // every thread has read its point record
 #pragma unroll
-  for (int j = 0; j < (int)(sizeof(q) / 4); j++) out[j] = qw[j];
+  for (int j = 0; j < Q_DW; j++) rec[tid * Q_DW + j] = qw[j];
+  __syncthreads();
+  uint32_t* out = reinterpret_cast<uint32_t*>(queries + (size_t)f * p_cap + p0);
+  for (int i = tid; i < cnt * Q_DW; i += 256) out[i] = rec[i];
 }
 
 void orbfe_launch_unproject_stereo(const orbfe_keypoint* kps, const uint8_t* desc, const int32_t* n, const float* depth, int cap,
