@@ -257,7 +257,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fast.json")))
             if pmc["kernel"].startswith(dom):
-                traffic = int((pmc["fetch_kb"] + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
+                traffic = int((pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
         except Exception:
             traffic = None
         value = world * F * args.steps / dt
