@@ -3,7 +3,7 @@
 // Kernel            replaces (reference file:line, L/ = Source/Libraries/ORB_SLAM2/)
 // copy_level0       copyMakeBorder of the input into mvImagePyramid[0]  L/src/ORBextractor.cc:1061
 // pyr_resize        cv::resize(INTER_LINEAR) chained level to level      L/src/ORBextractor.cc:1054
-// fast_cells        per-cell cv::FAST(th=ini, else th=min) + NMS         L/src/ORBextractor.cc:756-791
+// fast_groups       per-cell cv::FAST(th=ini, else th=min) + NMS         L/src/ORBextractor.cc:756-791
 // octree_select     DistributeOctTree + DivideNode                       L/src/ORBextractor.cc:475-731
 // gauss_blur7       GaussianBlur(7x7, sigma 2, REFLECT_101)              L/src/ORBextractor.cc:1017-1019
 // orient_describe   IC_Angle + computeOrbDescriptor + pt*=scale          L/src/ORBextractor.cc:76-146,1028-1035
@@ -124,65 +124,12 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
   *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
 }
 
-// LDS-staged variant: a workgroup produces a 256 x 4 destination tile; the source window it needs (at most
-// RS_ROWS rows x RS_COLS bytes for scale factors up to 2) is fetched with aligned 16-byte loads, the per-pixel taps
-// then gather single bytes from LDS instead of issuing byte loads to HBM/L2.  Same arithmetic, same tables.
-#define RS_ROWS 10
-#define RS_COLS 560
-__global__ __launch_bounds__(256) void pyr_resize_lds_kernel(const uint8_t* __restrict__ src, int spitch,
-                                                              unsigned long long simg, uint8_t* __restrict__ dst,
-                                                              int dpitch, unsigned long long dimg, int dw, int dh,
-                                                              const ResizeTap* __restrict__ xt,
-                                                              const ResizeTap* __restrict__ yt) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[RS_ROWS * RS_COLS];
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * 4;
-  const int xl = min(x0 + 255, dw - 1), yl = min(y0 + 3, dh - 1);
-  const int sxa = xt[x0].s0 & ~15;
-  const int ncols16 = ((xt[xl].s1 - sxa) >> 4) + 1;
-  const int sy_first = yt[y0].s0;
-  const int nrows = yt[yl].s1 - sy_first + 1;
-  const uint8_t* S = src + (size_t)blockIdx.z * simg;
-  {
-    const int total = nrows * ncols16;  // <= 10 * 35
-    uint4 v[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int i = tid + 256 * k;
-      const int r = i / ncols16, c = i - r * ncols16;
-      v[k] = i < total ? *reinterpret_cast<const uint4*>(S + (size_t)(sy_first + r) * spitch + sxa + 16 * c) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int i = tid + 256 * k;
-      const int r = i / ncols16, c = i - r * ncols16;
-      if (i < total) *reinterpret_cast<uint4*>(tile + r * RS_COLS + 16 * c) = v[k];
-    }
-  }
-  __syncthreads();
-  const int x4 = x0 + threadIdx.x * 4;
-  const int y = y0 + threadIdx.y;
-  if (x4 >= dw || y >= dh) return;
-  const ResizeTap ty = yt[y];
-  const uint8_t* S0 = tile + (ty.s0 - sy_first) * RS_COLS - sxa;
-  const uint8_t* S1 = tile + (ty.s1 - sy_first) * RS_COLS - sxa;
-  const int b0 = ty.c0, b1 = ty.c1;
-  uint32_t out = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int dx = x4 + i < dw ? x4 + i : dw - 1;
-    const ResizeTap tx = xt[dx];
-    const int t0 = S0[tx.s0] * tx.c0 + S0[tx.s1] * tx.c1;
-    const int t1 = S1[tx.s0] * tx.c0 + S1[tx.s1] * tx.c1;
-    const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-    out |= (uint32_t)(v & 0xff) << (8 * i);
-  }
-  *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x4) = out;
-}
-
-// 256 x 16 destination tile per workgroup, 4 x 4 destination pixels per thread: the horizontal taps (and all address
-// arithmetic) are loaded once per thread and reused for four rows; the staging divides once per thread and has all its
-// 16-byte loads in flight before the first LDS store.  Same arithmetic and tables as pyr_resize_kernel.
+#define RS_COLS 560   // bytes of a staged source row: 256 destination pixels x scale <= 2, plus alignment slack
+// LDS-staged resize: a workgroup produces a 256 x 16 destination tile; the source window it needs (at most RS2_ROWS rows x
+// RS_COLS bytes for scale factors up to 2) is fetched with aligned 16-byte loads (one division per thread, all loads in
+// flight before the first LDS store), the per-pixel taps then gather single bytes from LDS.  4 x 4 destination pixels per
+// thread: the horizontal taps and all address arithmetic are loaded once and reused for four rows.  Same arithmetic and
+// tables as pyr_resize_kernel (the direct-gather fallback for larger scale factors).
 #define RS2_ROWS 34
 __global__ __launch_bounds__(256) void pyr_resize_lds16_kernel(const uint8_t* __restrict__ src, int spitch,
                                                                 unsigned long long simg, uint8_t* __restrict__ dst,
@@ -284,166 +231,6 @@ __device__ __forceinline__ int corner_score16(const int d[16]) {
   return max(A, -B) - 1;
 }
 
-// One workgroup per (cell, image).  Stages the cell ROI in LDS, finds FAST corners at min_th, scores them,
-// applies 3x3 strict NMS inside the cell's tested region, then emits the th=ini survivors if there are any,
-// else all survivors, in row-major order (== cv::FAST(ini) else cv::FAST(min) of the reference).
-__global__ __launch_bounds__(256) void fast_cells_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
-                                                          int total_cells, int32_t* __restrict__ cell_cnt,
-                                                          uint32_t* __restrict__ slots,
-                                                          unsigned long long slots_per_image, int ini_th,
-                                                          int min_th, int xcd_run_shift) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[ORBFE_CELL_MAX * ORBFE_TILE_PITCH];
-  __shared__ __attribute__((aligned(16))) uint8_t sc[ORBFE_CELL_MAX * ORBFE_TILE_PITCH];
-  __shared__ uint16_t clist[(ORBFE_CELL_MAX - 6) * (ORBFE_CELL_MAX - 6)];
-  __shared__ int nlist;
-  __shared__ int scan_tmp[8];
-  __shared__ uint32_t bits_all[128], bits_hi[128];
-
-  const int tid = threadIdx.x;
-  const int img = blockIdx.y;
-  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own
-  // L2), so consecutive cells -- which share 6-pixel halos -- would be fetched by different L2s.  Hand every XCD
-  // runs of 16 consecutive cells instead (runs interleave over the XCDs, so all levels stay balanced).
-  // (the last partial group of 8 runs keeps the identity order, so the grid needs no padding blocks)
-  const int q = blockIdx.x >> 3;
-  const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
-  const int cell_id = (xcd_run_shift < 0 || (int)blockIdx.x >= (total_cells / unit) * unit)
-                          ? (int)blockIdx.x
-                          : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
-                                (q & ((1 << xcd_run_shift) - 1));
-  const CellDesc cd = cells[cell_id];
-  const int lvl = cd.level;
-  const int pitch = pyr.pitch[lvl];
-  const uint8_t* plane = pyr.base[lvl] + (size_t)img * pyr.img_stride[lvl];
-  const int cols = cd.cols, rows = cd.rows;
-  const int ax = cd.x0 & ~3, xo = cd.x0 & 3;
-  const int ndw = (xo + cols + 3) >> 2;
-
-  if (tid == 0) nlist = 0;
-  if (tid < 128) { bits_all[tid] = 0; bits_hi[tid] = 0; }
-  // stage ROI (aligned dwords) and clear the score plane
-  {
-    uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
-    uint32_t* s32 = reinterpret_cast<uint32_t*>(sc);
-    const int total = rows * ndw;
-    const float inv_ndw = 1.0f / (float)ndw;
-    for (int i = tid; i < total; i += 256) {
-      int r = (int)((i + 0.5f) * inv_ndw);
-      int c = i - r * ndw;
-      t32[r * (ORBFE_TILE_PITCH / 4) + c] =
-          *reinterpret_cast<const uint32_t*>(plane + (size_t)(cd.y0 + r) * pitch + ax + 4 * c);
-    }
-    for (int i = tid; i < rows * (ORBFE_TILE_PITCH / 4); i += 256) s32[i] = 0;
-  }
-  __syncthreads();
-
-  const int tw = cols - 6, th = rows - 6;  // tested region [3, cols-3) x [3, rows-3)
-  const float inv_tw = 1.0f / (float)(tw > 0 ? tw : 1);  // (p + 0.5) * inv_tw floors exactly for p < 4096, tw < 64
-  const int npix = (tw > 0 && th > 0) ? tw * th : 0;
-  const uint8_t* T = tile + xo;
-
-  // pass A1: quick reject.  A 9-arc of the 16-ring contains at least one pixel of every antipodal pair, so a
-  // corner needs, in each of the pairs (0,8) (2,10) (4,12) (6,14), a pixel darker than v-t (dark arc) -- or, in
-  // each of them, one brighter than v+t (bright arc).  Sign bits do the comparisons; survivors are compacted.
-  // Threads form a 32 x 8 patch that sweeps the tested region (no index division).
-  {
-    const int lx = tid & 31, ly = tid >> 5;
-    for (int by = 0; by < th; by += 8) {
-      const int ty = by + ly;
-      for (int bx = 0; bx < tw; bx += 32) {
-        const int tx = bx + lx;
-        if (ty < th && tx < tw) {
-          const int x = tx + 3, y = ty + 3;
-          const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
-          const int v = c[0];
-          const int lo = v - min_th, hi = v + min_th;
-          int dark = -1, bright = -1;  // sign bit = "every pair so far has a darker / brighter member"
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) {
-            const int qa = c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
-            const int qb = c[RDY[k + 8] * ORBFE_TILE_PITCH + RDX[k + 8]];
-            dark &= (qa - lo) | (qb - lo);
-            bright &= (hi - qa) | (hi - qb);
-          }
-          if ((dark | bright) < 0) {
-            int idx = atomicAdd(&nlist, 1);
-            clist[idx] = (uint16_t)((y << 8) | x);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // pass A2: exact score of the survivors (dense over the compacted list).  score >= t  <=>  corner at t.
-  const int nl = nlist;
-  for (int i = tid; i < nl; i += 256) {
-    const int e = clist[i];
-    const int x = e & 0xff, y = e >> 8;
-    const uint8_t* c = T + y * ORBFE_TILE_PITCH + x;
-    const int v = c[0];
-    int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)c[RDY[k] * ORBFE_TILE_PITCH + RDX[k]];
-    const int sc16 = corner_score16(d);
-    if (sc16 >= min_th) sc[y * ORBFE_TILE_PITCH + x] = (uint8_t)sc16;
-  }
-  __syncthreads();
-
-  // pass B: strict 3x3 NMS of the scored pixels only (out-of-region neighbours are 0); survivors set one bit per
-  // tested pixel (row-major index p = ty*tw + tx), th=ini survivors a second bit.
-  for (int i = tid; i < nl; i += 256) {
-    const int e = clist[i];
-    const int x = e & 0xff, y = e >> 8;
-    const uint8_t* s = sc + y * ORBFE_TILE_PITCH + x;
-    const int v = s[0];
-    if (v > 0) {
-      const bool keep = v > s[-1] && v > s[1] && v > s[-ORBFE_TILE_PITCH - 1] && v > s[-ORBFE_TILE_PITCH] &&
-                        v > s[-ORBFE_TILE_PITCH + 1] && v > s[ORBFE_TILE_PITCH - 1] && v > s[ORBFE_TILE_PITCH] &&
-                        v > s[ORBFE_TILE_PITCH + 1];
-      if (keep) {
-        const int p = (y - 3) * tw + (x - 3);
-        atomicOr(&bits_all[p >> 5], 1u << (p & 31));
-        if (v >= ini_th) atomicOr(&bits_hi[p >> 5], 1u << (p & 31));
-      }
-    }
-  }
-  __syncthreads();
-
-  // ordered emission: one 32-pixel word per thread, one block scan, cv::FAST(ini) result if non-empty else cv::FAST(min)
-  const int nwords = (npix + 31) >> 5;  // <= 113 (60 x 60 tested pixels)
-  const uint32_t wall = tid < nwords ? bits_all[tid] : 0u, whi = tid < nwords ? bits_hi[tid] : 0u;
-  int total;
-  const int packed = (__popc(whi) << 16) | __popc(wall);
-  const int incl = block_incl_scan256(packed, scan_tmp, &total);
-  const int excl = incl - packed;
-  const bool use_hi = (total >> 16) != 0;
-  uint32_t mask = use_hi ? whi : wall;
-  int off = use_hi ? (excl >> 16) : (excl & 0xffff);
-  const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
-  uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
-  while (mask) {
-    const int b = __ffs((int)mask) - 1;
-    mask &= mask - 1;
-    const int p = tid * 32 + b;
-    const int ty = (int)((p + 0.5f) * inv_tw);
-    const int x = p - ty * tw + 3, y = ty + 3;
-    const uint32_t sv = sc[y * ORBFE_TILE_PITCH + x];
-    const uint32_t rx = (uint32_t)(x + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(y + cd.y0 - ORBFE_EDGE);
-    if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
-    off++;
-  }
-  if (tid == 0) cell_cnt[(size_t)img * total_cells + cell_id] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
-}
-
-// Grouped form of fast_cells_kernel: one workgroup per (run of <= 4 horizontally adjacent cells, image).  The per-pixel
-// work (quick reject, exact score) does not depend on the cell, so it runs once over the union ROI; the cell only
-// matters for the NMS neighbourhood (cv::FAST sees one cell's ROI: neighbours in another cell's tested region count as
-// 0), the two-threshold rule and the output slots.  Versus one cell per workgroup this amortises the prologue, the
-// staging and the emission scan (which was a 4-wave block scan per cell; here one wave per cell, no barrier).
-//   A1  quick reject, min/max form: a 9-arc contains a pixel of every antipodal pair, so a dark corner needs
-//       max_k min(q_k, q_k+8) < v - t over the 4 even pairs, a bright one min_k max(q_k, q_k+8) > v + t
-//   A2  exact cornerScore for the survivors;  B  per-cell strict 3x3 NMS -> bitmasks;  C  ordered emission per cell
 // 16-bit VOP2 min / max issue at twice the rate of their 32-bit forms on gfx950 (tools/valu_bench.hip).  Operands are
 // 32-bit containers whose low halves hold the value (gfx9 16-bit ops zero the high half of the destination).
 __device__ __forceinline__ unsigned min16(unsigned a, unsigned b) {
@@ -506,6 +293,10 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img = blockIdx.y;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so consecutive groups --
+  // which share 6-pixel halo lines -- would be fetched by different L2s.  Hand every XCD runs of 2^shift consecutive
+  // groups instead (runs interleave over the XCDs, so all levels stay balanced); the last partial set of 8 runs keeps the
+  // identity order, so the grid needs no padding blocks.
   const int q = blockIdx.x >> 3;
   const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
   const int gid = (xcd_run_shift < 0 || (int)blockIdx.x >= (n_groups / unit) * unit)
@@ -983,7 +774,7 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
   __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
   const int tid = threadIdx.x;
-  // XCD-aware mapping (see fast_cells): runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
+  // XCD-aware mapping (see fast_groups): runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
   const int q = blockIdx.x >> 3;
   const int tile_id = (int)blockIdx.x >= (n_tiles / 64) * 64 ? (int)blockIdx.x : (q >> 3) * 64 + (blockIdx.x & 7) * 8 + (q & 7);
   const BlurTile t = tiles[tile_id];
@@ -1322,30 +1113,12 @@ void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* d
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s) {
   dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
-  static int legacy = -1;
-  if (legacy < 0) { const char* ev = getenv("ORBFE_RESIZE_LEGACY"); legacy = ev ? atoi(ev) : 0; }  // A/B knob
-  if (lds_ok && !legacy)
+  if (lds_ok)
     hipLaunchKernelGGL(pyr_resize_lds16_kernel, dim3((dw + 255) / 256, (dh + 15) / 16, n_images), block, 0, s, src, spitch,
                        (unsigned long long)simg, dst, dpitch, (unsigned long long)dimg, dw, dh, xt, yt);
-  else if (lds_ok)
-    hipLaunchKernelGGL(pyr_resize_lds_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
-                       (unsigned long long)dimg, dw, dh, xt, yt);
   else  // source window of a tile exceeds the staged size (scale factor > 2): direct byte gathers
     hipLaunchKernelGGL(pyr_resize_kernel, grid, block, 0, s, src, spitch, (unsigned long long)simg, dst, dpitch,
                        (unsigned long long)dimg, dw, dh, xt, yt);
-}
-
-void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
-                       unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s) {
-  if (total_cells == 0) return;
-  static int run_shift = -2;
-  if (run_shift == -2) {
-    const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order
-    run_shift = ev ? atoi(ev) : 4;
-  }
-  dim3 block(256), grid(total_cells, n_images);
-  hipLaunchKernelGGL(fast_cells_kernel, grid, block, 0, s, pyr, cells, total_cells, cell_cnt, slots, slots_per_image,
-                     ini_th, min_th, run_shift);
 }
 
 void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,

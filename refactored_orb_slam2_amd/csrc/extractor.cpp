@@ -84,7 +84,6 @@ struct orbfe_extractor {
   std::vector<CellDesc> cells;
   std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
   int fg_tile_rows = 0, fg_clist_cap = 0;
-  bool use_groups = true;
   std::vector<BlurTile> tiles;
   OctLevel oct[ORBFE_MAX_LEVELS]{};
   int total_cells = 0;
@@ -209,8 +208,8 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   e->tiles.clear();
   static int fg_max = -1;
   if (fg_max < 0) {
-    const char* ev = getenv("ORBFE_FAST_GROUP");  // experiment knob: cells per workgroup (1..4), 0 = per-cell kernel
-    fg_max = ev ? std::min(std::max(atoi(ev), 0), ORBFE_FG_MAX) : ORBFE_FG_MAX;
+    const char* ev = getenv("ORBFE_FAST_GROUP");  // experiment knob: cells per workgroup (1..4)
+    fg_max = ev ? std::min(std::max(atoi(ev), 1), ORBFE_FG_MAX) : ORBFE_FG_MAX;
   }
   size_t slot_off = 0, key_off = 0;
   int kp_off = 0, maxM = 0;
@@ -265,7 +264,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
         // split this cell row into runs of <= G cells of near-equal length (cells of a row are contiguous: only
         // trailing ones are ever skipped)
         const int n_row = (int)(e->cells.size() - row_first);
-        const int G = std::max(1, std::min(fg_max > 0 ? fg_max : 1, (ORBFE_FG_MAX_WIDTH - 6) / wCell));
+        const int G = std::max(1, std::min(fg_max, (ORBFE_FG_MAX_WIDTH - 6) / wCell));
         const int n_grp = (n_row + G - 1) / G;
         int done = 0;
         for (int k = 0; k < n_grp; k++) {
@@ -335,22 +334,17 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   int rc;
   if ((rc = upload(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), e->stream))) return rc;
   if ((rc = upload(e->d_groups, e->groups.data(), e->groups.size() * sizeof(FastGroup), e->stream))) return rc;
-  e->use_groups = fg_max > 0;
   if ((rc = upload(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(BlurTile), e->stream))) return rc;
   for (int l = 1; l < nl; l++) {
     std::vector<ResizeTap> xt, yt;
     build_taps(e->lg[l - 1].w, e->lg[l].w, true, xt);
     build_taps(e->lg[l - 1].h, e->lg[l].h, false, yt);
-    // does the source window of every 256 x 4 destination tile fit the staged 10 rows x 560 bytes?
+    // does the source window of every 256 x 16 destination tile fit the staged 34 rows x 560 bytes?
     bool ok = true;
     for (int x0 = 0; x0 < (int)xt.size() && ok; x0 += 256) {
       const int xl = std::min<int>(x0 + 255, (int)xt.size() - 1);
       const int sxa = xt[x0].s0 & ~15;
       if ((((xt[xl].s1 - sxa) >> 4) + 1) * 16 > 560) ok = false;
-    }
-    for (int y0 = 0; y0 < (int)yt.size() && ok; y0 += 4) {
-      const int yl = std::min<int>(y0 + 3, (int)yt.size() - 1);
-      if (yt[yl].s1 - yt[y0].s0 + 1 > 10) ok = false;
     }
     for (int y0 = 0; y0 < (int)yt.size() && ok; y0 += 16) {  // 256 x 16 tiles of the 4-rows-per-thread kernel: 34 rows
       const int yl = std::min<int>(y0 + 15, (int)yt.size() - 1);
@@ -480,14 +474,10 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   if (fork) (void)hipEventRecord(e->ev_blur, sb);
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
-    if (e->use_groups)
-      orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)e->d_groups.p, (int)e->groups.size(),
-                               e->total_cells, e->fg_tile_rows, e->fg_clist_cap, (int32_t*)e->d_cell_cnt.p,
-                               (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast,
-                               n_images, s);
-    else
-      orbfe_launch_fast(pv, (const CellDesc*)e->d_cells.p, e->total_cells, (int32_t*)e->d_cell_cnt.p,
-                      (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast, n_images, s);
+    orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)e->d_groups.p, (int)e->groups.size(),
+                             e->total_cells, e->fg_tile_rows, e->fg_clist_cap, (int32_t*)e->d_cell_cnt.p,
+                             (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast,
+                             n_images, s);
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_OCTREE);

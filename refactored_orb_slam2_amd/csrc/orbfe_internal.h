@@ -7,7 +7,6 @@
 
 #define ORBFE_EDGE 16            // minBorder = EDGE_THRESHOLD - 3 (L/src/ORBextractor.cc:740)
 #define ORBFE_CELL_MAX 66        // largest FAST cell ROI side the cell kernel stages in LDS
-#define ORBFE_TILE_PITCH 72      // LDS row pitch of the staged ROI (ROI side + 3 bytes alignment slack)
 #define ORBFE_BLUR_TILE_H 58      // rows of a blur tile (64 wide); must be even
 #define ORBFE_MAX_INI 256        // largest nIni (root nodes of DistributeOctTree) supported
 #define ORBFE_OCT_THREADS 256
@@ -107,8 +106,6 @@ void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* d
 void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
                               int total_cells, int tile_rows, int clist_cap, int32_t* cell_cnt, uint32_t* slots,
                               unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
-void orbfe_launch_fast(const PyrView& pyr, const CellDesc* cells, int total_cells, int32_t* cell_cnt, uint32_t* slots,
-                       unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
 void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
                        hipStream_t s);
