@@ -314,6 +314,35 @@ def test_stereo_oracle_sane():
     np.testing.assert_allclose(depth[ok], np.float32(386.1448) / disp.astype(np.float32), rtol=1e-6)
 
 
+def _bow_groups(desc):
+    g = {}
+    for i, d in enumerate(desc):
+        g.setdefault(int(d[0]) % 64, []).append(i)
+    return g
+
+
+def test_oracle_reproduces_golden_tracking():
+    """isInFrustum / SearchLocalPoints, UnprojectStereo + projection, relocalisation search, SearchByBoW(KF,KF)"""
+    g = np.load(os.path.join(GOLD, "tracking_tum.npz"))
+    g0 = np.load(os.path.join(GOLD, "extract_tum_640x480_1000_f0.npz")); g1 = np.load(os.path.join(GOLD, "extract_tum_640x480_1000_f1.npz"))
+    k0, d0, k1, d1 = g0["keypoints"], g0["descriptors"], g1["keypoints"], g1["descriptors"]
+    sf = ol.OracleExtractor(1000).scale_factors
+    of = ol.OracleFrame(k1, d1, sf, 0, 640, 0, 480, g["u_right"])
+    ntm, nm, track, assigned, blocked = of.search_local_points(g["frustum"], g["map_points"], np.float32(3.0), np.float32(0.8), g["blocked0"])
+    assert (ntm, nm) == (int(g["lp_n_to_match"]), int(g["lp_nm"])) and track.tobytes() == g["lp_track"].tobytes()
+    np.testing.assert_array_equal(assigned, g["lp_assigned"]); np.testing.assert_array_equal(blocked, g["lp_blocked"])
+    pts = ol.unproject_stereo(g["cam"], k0, d0, g["depth"])
+    assert pts.tobytes() == g["last_points"].tobytes()
+    tq = ol.track_queries(g["pose"], pts)
+    assert tq.tobytes() == g["track_queries"].tobytes()
+    t_nm, t_assigned, _ = ol.OracleFrame(k1, d1, sf, 0, 640, 0, 480, None).search_by_projection_frame(tq, True)
+    assert t_nm == int(g["track_nm"]); np.testing.assert_array_equal(t_assigned, g["track_assigned"])
+    k_nm, k_assigned, k_blocked = of.search_by_projection_keyframe(tq, True, 64, g["blocked0"])
+    assert k_nm == int(g["kf_nm"]); np.testing.assert_array_equal(k_assigned, g["kf_assigned"]); np.testing.assert_array_equal(k_blocked, g["kf_blocked"])
+    b_nm, b_matchA = ol.search_by_bow_kf(d0, k0["angle"], g["validA"], _bow_groups(d0), d1, k1["angle"], g["validB"], _bow_groups(d1), np.float32(0.9), True)
+    assert b_nm == int(g["bow_nm"]); np.testing.assert_array_equal(b_matchA, g["bow_matchA"])
+
+
 def test_vocabulary_transform_hand_example(tmp_path):
     """k=2, L=2 tree with hand-checked descent, word ids in file order, TF-IDF sums, L1 norm, FeatureVector order."""
     z = np.zeros(32, np.uint8)
