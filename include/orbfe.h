@@ -335,6 +335,25 @@ int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint
                            int n_nodesB, const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA,
                            int* n_matches);
 
+/* SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo) (L/src/ORBmatcher.cc:614-764)
+ * with CheckDistEpipolarLine (:137-159).  The epipole (:622-630) is computed by the caller. */
+typedef struct orbfe_epipolar {
+  float F12[9];               /* row-major */
+  float ex, ey;               /* epipole of pKF1's camera centre in pKF2's image */
+  float scale_factors[8];     /* pKF2->mvScaleFactors */
+  float level_sigma2[8];      /* pKF2->mvLevelSigma2 */
+} orbfe_epipolar;             /* 108 bytes */
+/* keys = mvKeysUn, u_right = mvuRight (NULL = monocular: all -1), has_mp[i] = (GetMapPoint(i) != NULL); FeatureVectors as in
+ * orbfe_search_by_bow.  matchA[i] = index in pKF2 matched to feature i of pKF1, or -1 (vMatchedPairs = the pairs
+ * (i, matchA[i]) in ascending i).  No match blocks another (vbMatched2 is never set in the reference); among the
+ * candidates that pass the gates the smallest distance wins, the LAST one on ties (`dist > bestDist` rejects, :691). */
+int orbfe_search_for_triangulation(const orbfe_keypoint* keysA, const uint8_t* descA, const float* u_rightA,
+                                   const uint8_t* has_mpA, int nA, const orbfe_featvec_node* nodesA, int n_nodesA,
+                                   const int32_t* idxA, const orbfe_keypoint* keysB, const uint8_t* descB,
+                                   const float* u_rightB, const uint8_t* has_mpB, int nB, const orbfe_featvec_node* nodesB,
+                                   int n_nodesB, const int32_t* idxB, const orbfe_epipolar* ep, int only_stereo,
+                                   int check_orientation, int32_t* matchA, int* n_matches);
+
 /* SearchForInitialization (L/src/ORBmatcher.cc:388-492), the monocular map-initialisation matcher: level-0
  * keypoints of F1 are searched in a window of `window_size` pixels around prev_matched_xy[2*i..2*i+1] in F2; a
  * closer later keypoint steals an earlier match (vMatchedDistance / vnMatches21).  matches12[i] = F2 index or -1;

@@ -1279,6 +1279,79 @@ int oo_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t
   return nmatches;
 }
 
+/* ORBmatcher::CheckDistEpipolarLine: L/src/ORBmatcher.cc:137-159 */
+static int check_dist_epipolar_line(const oo_keypoint* kp1, const oo_keypoint* kp2, const float* F12, const float* level_sigma2) {
+  const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+  const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+  const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+  const float num = a * kp2->x + b * kp2->y + c;
+  const float den = a * a + b * b;
+  if (den == 0) return 0;
+  const float dsqr = num * num / den;
+  return dsqr < 3.84 * level_sigma2[kp2->octave];
+}
+
+/* SearchForTriangulation: L/src/ORBmatcher.cc:614-764 (the epipole :622-630 arrives in ep) */
+int oo_search_for_triangulation(const oo_keypoint* keysA, const uint8_t* descA, const float* u_rightA, const uint8_t* has_mpA, int nA,
+                                const oo_featvec_node* nodesA, int nA_nodes, const int32_t* idxA, const oo_keypoint* keysB,
+                                const uint8_t* descB, const float* u_rightB, const uint8_t* has_mpB, int nB,
+                                const oo_featvec_node* nodesB, int nB_nodes, const int32_t* idxB, const oo_epipolar* ep,
+                                int bOnlyStereo, int check_orientation, int32_t* vMatches12) {
+  int nmatches = 0;
+  rot_hist rh; memset(&rh, 0, sizeof(rh));
+  uint8_t* vbMatched2 = (uint8_t*)calloc(nB ? nB : 1, 1);   /* declared and tested by the reference, never set (:635,679) */
+  for (int i = 0; i < nA; i++) vMatches12[i] = -1;
+  int ia = 0, ib = 0;
+  while (ia < nA_nodes && ib < nB_nodes) {
+    if (nodesA[ia].node_id == nodesB[ib].node_id) {
+      for (int i1 = 0; i1 < nodesA[ia].count; i1++) {
+        const int idx1 = idxA[nodesA[ia].start + i1];
+        if (has_mpA[idx1]) continue;
+        const int bStereo1 = u_rightA && u_rightA[idx1] >= 0;
+        if (bOnlyStereo && !bStereo1) continue;
+        const oo_keypoint* kp1 = &keysA[idx1];
+        const uint8_t* d1 = descA + (size_t)idx1 * 32;
+        int bestDist = OO_TH_LOW, bestIdx2 = -1;
+        for (int i2 = 0; i2 < nodesB[ib].count; i2++) {
+          const int idx2 = idxB[nodesB[ib].start + i2];
+          if (vbMatched2[idx2] || has_mpB[idx2]) continue;
+          const int bStereo2 = u_rightB && u_rightB[idx2] >= 0;
+          if (bOnlyStereo && !bStereo2) continue;
+          const int dist = oo_descriptor_distance(d1, descB + (size_t)idx2 * 32);
+          if (dist > OO_TH_LOW || dist > bestDist) continue;
+          const oo_keypoint* kp2 = &keysB[idx2];
+          if (!bStereo1 && !bStereo2) {
+            const float distex = ep->ex - kp2->x, distey = ep->ey - kp2->y;
+            if (distex * distex + distey * distey < 100 * ep->scale_factors[kp2->octave]) continue;
+          }
+          if (check_dist_epipolar_line(kp1, kp2, ep->F12, ep->level_sigma2)) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (check_orientation) rh_push(&rh, rot_bin(kp1->angle, keysB[bestIdx2].angle), idx1);
+        }
+      }
+      ia++; ib++;
+    } else if (nodesA[ia].node_id < nodesB[ib].node_id) {
+      ia = featvec_lower_bound(nodesA, nA_nodes, nodesB[ib].node_id);
+    } else {
+      ib = featvec_lower_bound(nodesB, nB_nodes, nodesA[ia].node_id);
+    }
+  }
+  if (check_orientation) {
+    int i1, i2, i3;
+    oo_three_maxima(rh.n, OO_HISTO_LENGTH, &i1, &i2, &i3);
+    for (int i = 0; i < OO_HISTO_LENGTH; i++) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int j = 0; j < rh.n[i]; j++) { vMatches12[rh.v[i][j]] = -1; nmatches--; }
+    }
+  }
+  rh_free(&rh);
+  free(vbMatched2);
+  return nmatches;
+}
+
 /* SearchForInitialization: L/src/ORBmatcher.cc:388-492 */
 int oo_search_for_initialization(const oo_keypoint* keys1, const uint8_t* desc1, int n1, const oo_frame* f2,
                                  float* prev_xy, int window, float nnratio, int check_orientation,

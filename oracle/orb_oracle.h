@@ -215,6 +215,14 @@ int oo_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t
                         const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
                         const float* angleB, const uint8_t* validB, int nB, const oo_featvec_node* nodesB, int n_nodesB,
                         const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA);
+/* SearchForTriangulation: ORBmatcher.cc:614-764 with CheckDistEpipolarLine :137-159.  has_mp: GetMapPoint(i) != NULL; u_right may
+ * be NULL (monocular).  matchA[i] = vMatches12[i].  Returns nmatches. */
+typedef struct oo_epipolar { float F12[9], ex, ey, scale_factors[8], level_sigma2[8]; } oo_epipolar;
+int oo_search_for_triangulation(const oo_keypoint* keysA, const uint8_t* descA, const float* u_rightA, const uint8_t* has_mpA, int nA,
+                                const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const oo_keypoint* keysB,
+                                const uint8_t* descB, const float* u_rightB, const uint8_t* has_mpB, int nB,
+                                const oo_featvec_node* nodesB, int n_nodesB, const int32_t* idxB, const oo_epipolar* ep,
+                                int only_stereo, int check_orientation, int32_t* matchA);
 /* SearchForInitialization: ORBmatcher.cc:388-492 */
 int oo_search_for_initialization(const oo_keypoint* keys1, const uint8_t* desc1, int n1, const oo_frame* f2,
                                  float* prev_matched_xy, int window, float nnratio, int check_orientation,

@@ -81,6 +81,13 @@ void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map
                                   int p_cap, float th, float viewing_cos_limit, orbfe_track* track, orbfe_query* queries,
                                   int32_t* n_to_match, int n_frames, hipStream_t s);
 void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream_t s);
+struct TriParams {
+  BowParams b;   // pairs, descriptors, idx arrays, matchA, counters, push arrays, check_ori, sequential, n_pairs (validA / validB: candidate masks)
+  const orbfe_keypoint* keysA; const orbfe_keypoint* keysB;
+  const uint8_t* stereoA; const uint8_t* stereoB;   // mvuRight >= 0
+  orbfe_epipolar ep;
+};
+void orbfe_launch_triangulation(const TriParams& p, int n_pairs, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s);
 void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s);
 void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s);

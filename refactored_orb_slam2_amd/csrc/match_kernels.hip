@@ -650,6 +650,69 @@ __global__ __launch_bounds__(64) void bow_match_kernel(BowParams P) {
   }
 }
 
+// SearchForTriangulation (L/src/ORBmatcher.cc:614-764): one wave per common vocabulary node.  Nothing couples two features
+// of pKF1 (vbMatched2 is never set), so each is an independent arg-min over the node's pKF2 features that pass the
+// gates: dist <= TH_LOW, the epipole distance for two monocular keypoints (:697-703), CheckDistEpipolarLine (:137-159);
+// `dist > bestDist` rejects, so of equal distances the LAST one in list order wins.
+__global__ __launch_bounds__(64) void triangulation_match_kernel(TriParams T) {
+  const BowParams& P = T.b;
+  const int lane = threadIdx.x;
+  const int first = P.sequential ? 0 : blockIdx.x, last = P.sequential ? P.n_pairs : blockIdx.x + 1;
+  for (int pi = first; pi < last; pi++) {
+    const BowPair pr = P.pairs[pi];
+    for (int i1 = 0; i1 < pr.countA; i1++) {
+      const int idx1 = P.idxA[pr.startA + i1];
+      if (!P.validA[idx1]) continue;   // has a map point, or monocular under bOnlyStereo (:655-664)
+      const bool bStereo1 = T.stereoA[idx1] != 0;
+      const orbfe_keypoint kp1 = T.keysA[idx1];
+      uint4 a0, a1;
+      load_desc(P.descA + (size_t)idx1 * 32, a0, a1);
+      // epipolar line in the second image l = x1' F12 = [a b c]
+      const float* F = T.ep.F12;
+      const float la = kp1.x * F[0] + kp1.y * F[3] + F[6];
+      const float lb = kp1.x * F[1] + kp1.y * F[4] + F[7];
+      const float lc = kp1.x * F[2] + kp1.y * F[5] + F[8];
+      const float den = la * la + lb * lb;
+      unsigned key = 0xFFFFFFFFu;   // dist << 16 | (0xffff - position): minimum = smallest distance, last position
+      for (int i2 = lane; i2 < pr.countB; i2 += WAVE) {
+        const int idx2 = P.idxB[pr.startB + i2];
+        if (!P.validB[idx2]) continue;   // matched map point, or monocular under bOnlyStereo (:677-686)
+        uint4 b0, b1;
+        load_desc(P.descB + (size_t)idx2 * 32, b0, b1);
+        const int dist = hamming256(a0, a1, b0, b1);
+        if (dist > ORBFE_TH_LOW) continue;
+        const orbfe_keypoint kp2 = T.keysB[idx2];
+        if (!bStereo1 && !T.stereoB[idx2]) {
+          const float distex = T.ep.ex - kp2.x, distey = T.ep.ey - kp2.y;
+          if (distex * distex + distey * distey < 100 * T.ep.scale_factors[kp2.octave & 7]) continue;
+        }
+        const float num = la * kp2.x + lb * kp2.y + lc;
+        if (den == 0) continue;
+        const float dsqr = num * num / den;
+        if (!((double)dsqr < 3.84 * (double)T.ep.level_sigma2[kp2.octave & 7])) continue;
+        const unsigned k = ((unsigned)dist << 16) | (unsigned)(0xffff - i2);
+        key = min(key, k);
+      }
+      const unsigned b = wave_min_u32(key);
+      if (b != 0xFFFFFFFFu && lane == 0) {
+        const int idx2 = P.idxB[pr.startB + (0xffff - (int)(b & 0xffff))];
+        P.matchA[idx1] = idx2;
+        atomicAdd(&P.counters[1], 1);
+        if (P.check_ori) {
+          float rot = kp1.angle - T.keysB[idx2].angle;
+          if (rot < 0.0f) rot += 360.0f;
+          int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
+          if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+          const int pos = atomicAdd(&P.counters[0], 1);
+          P.push_idx[pos] = idx1;
+          P.push_bin[pos] = (uint8_t)bin;
+          atomicAdd(&P.counters[2 + bin], 1);
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bow_finish_kernel(BowParams P) {
   __shared__ int top[3];
   __shared__ int removed;
@@ -1103,6 +1166,10 @@ void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream
   if (n_pairs > 0)
     hipLaunchKernelGGL(bow_match_kernel, dim3(p.sequential ? 1 : n_pairs), dim3(64), (size_t)((max_countB + 15) & ~15), s, p);
   hipLaunchKernelGGL(bow_finish_kernel, dim3(1), dim3(256), 0, s, p);
+}
+void orbfe_launch_triangulation(const TriParams& p, int n_pairs, hipStream_t s) {
+  if (n_pairs > 0) hipLaunchKernelGGL(triangulation_match_kernel, dim3(p.b.sequential ? 1 : n_pairs), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(bow_finish_kernel, dim3(1), dim3(256), 0, s, p.b);
 }
 void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
                                int max_cand, float nnratio, int check_ori, int32_t* matches12, float* prev_xy,

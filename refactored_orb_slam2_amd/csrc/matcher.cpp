@@ -554,6 +554,101 @@ extern "C" int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA,
                   nnratio, check_orientation, 1, matchA, matchB.data(), n_matches);
 }
 
+// SearchForTriangulation (L/src/ORBmatcher.cc:614-764), host pointers, synchronous
+extern "C" int orbfe_search_for_triangulation(const orbfe_keypoint* keysA, const uint8_t* descA, const float* u_rightA,
+                                              const uint8_t* has_mpA, int nA, const orbfe_featvec_node* nodesA, int n_nodesA,
+                                              const int32_t* idxA, const orbfe_keypoint* keysB, const uint8_t* descB,
+                                              const float* u_rightB, const uint8_t* has_mpB, int nB,
+                                              const orbfe_featvec_node* nodesB, int n_nodesB, const int32_t* idxB,
+                                              const orbfe_epipolar* ep, int only_stereo, int check_orientation,
+                                              int32_t* matchA, int* n_matches) {
+  if (nA < 0 || nB < 0 || n_nodesA < 0 || n_nodesB < 0 || !n_matches || (nA > 0 && !matchA) || !ep) return ORBFE_ERR_INVALID;
+  *n_matches = 0;
+  for (int i = 0; i < nA; i++) matchA[i] = -1;
+  if (nA == 0 || nB == 0 || n_nodesA == 0 || n_nodesB == 0) return ORBFE_OK;
+  if (!keysA || !descA || !has_mpA || !nodesA || !idxA || !keysB || !descB || !has_mpB || !nodesB || !idxB) return ORBFE_ERR_INVALID;
+  std::vector<BowPair> pairs;
+  int ia = 0, ib = 0, totA = 0, totB = 0;
+  while (ia < n_nodesA && ib < n_nodesB) {
+    if (nodesA[ia].node_id == nodesB[ib].node_id) {
+      pairs.push_back(BowPair{nodesA[ia].start, nodesA[ia].count, nodesB[ib].start, nodesB[ib].count});
+      if (nodesB[ib].count > 60000) return ORBFE_ERR_INVALID;
+      ia++; ib++;
+    } else if (nodesA[ia].node_id < nodesB[ib].node_id) ia++;
+    else ib++;
+  }
+  for (int i = 0; i < n_nodesA; i++) totA = std::max(totA, nodesA[i].start + nodesA[i].count);
+  for (int i = 0; i < n_nodesB; i++) totB = std::max(totB, nodesB[i].start + nodesB[i].count);
+  if (pairs.empty()) return ORBFE_OK;
+  // a pKF1 feature listed under two nodes (never produced by DBoW2) is visited twice by the reference: replay in order
+  int sequential = 0;
+  {
+    std::vector<uint8_t> seen((size_t)nA, 0);
+    for (const BowPair& pr : pairs) {
+      for (int t = 0; t < pr.countA; t++) {
+        const int j = idxA[pr.startA + t];
+        if (j < 0 || j >= nA) return ORBFE_ERR_INVALID;
+        if (seen[j]) sequential = 1;
+        seen[j] = 1;
+      }
+      for (int t = 0; t < pr.countB; t++)
+        if (idxB[pr.startB + t] < 0 || idxB[pr.startB + t] >= nB) return ORBFE_ERR_INVALID;
+    }
+  }
+  // candidate masks and stereo flags (:655-664, 677-686)
+  std::vector<uint8_t> vA((size_t)nA), vB((size_t)nB), sA((size_t)nA), sB((size_t)nB);
+  for (int i = 0; i < nA; i++) { sA[i] = u_rightA && u_rightA[i] >= 0; vA[i] = !has_mpA[i] && (!only_stereo || sA[i]); }
+  for (int i = 0; i < nB; i++) { sB[i] = u_rightB && u_rightB[i] >= 0; vB[i] = !has_mpB[i] && (!only_stereo || sB[i]); }
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_pairs = 0, o_dA = al(pairs.size() * sizeof(BowPair)), o_dB = o_dA + al((size_t)nA * 32),
+               o_kA = o_dB + al((size_t)nB * 32), o_kB = o_kA + al((size_t)nA * sizeof(orbfe_keypoint)),
+               o_iA = o_kB + al((size_t)nB * sizeof(orbfe_keypoint)), o_iB = o_iA + al((size_t)totA * 4),
+               o_vA = o_iB + al((size_t)totB * 4), o_vB = o_vA + al((size_t)nA), o_sA = o_vB + al((size_t)nB),
+               o_sB = o_sA + al((size_t)nA), o_mA = o_sB + al((size_t)nB), o_cnt = o_mA + al((size_t)nA * 4), o_pi = o_cnt + 256,
+               o_pb = o_pi + al((size_t)std::max(totA, nA) * 4), total = o_pb + al((size_t)std::max(totA, nA));
+  if ((rc = mb_alloc(m->h_q, total))) return rc;
+  uint8_t* d = (uint8_t*)m->h_q.p;
+  HIPCHK(hipMemcpyAsync(d + o_pairs, pairs.data(), pairs.size() * sizeof(BowPair), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_dA, descA, (size_t)nA * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_dB, descB, (size_t)nB * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_kA, keysA, (size_t)nA * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_kB, keysB, (size_t)nB * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_iA, idxA, (size_t)totA * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_iB, idxB, (size_t)totB * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_vA, vA.data(), (size_t)nA, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_vB, vB.data(), (size_t)nB, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_sA, sA.data(), (size_t)nA, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + o_sB, sB.data(), (size_t)nB, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(d + o_mA, 0xff, (size_t)nA * 4, s));
+  HIPCHK(hipMemsetAsync(d + o_cnt, 0, 256, s));
+  TriParams t;
+  memset(&t, 0, sizeof(t));
+  t.b.pairs = (const BowPair*)(d + o_pairs);
+  t.b.descA = d + o_dA; t.b.validA = d + o_vA; t.b.idxA = (const int32_t*)(d + o_iA);
+  t.b.descB = d + o_dB; t.b.validB = d + o_vB; t.b.idxB = (const int32_t*)(d + o_iB);
+  t.b.check_ori = check_orientation; t.b.sequential = sequential; t.b.n_pairs = (int)pairs.size();
+  t.b.kf_mode = 1;   // bow_finish_kernel: rotation rejects clear matchA[push_idx]
+  t.b.matchA = (int32_t*)(d + o_mA); t.b.matchB = nullptr;
+  t.b.counters = (int32_t*)(d + o_cnt); t.b.push_idx = (int32_t*)(d + o_pi); t.b.push_bin = d + o_pb;
+  t.keysA = (const orbfe_keypoint*)(d + o_kA); t.keysB = (const orbfe_keypoint*)(d + o_kB);
+  t.stereoA = d + o_sA; t.stereoB = d + o_sB;
+  t.ep = *ep;
+  orbfe_launch_triangulation(t, (int)pairs.size(), s);
+  if ((rc = launch_ok())) return rc;
+  int32_t cnt[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(matchA, d + o_mA, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(cnt, d + o_cnt, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_matches = cnt[1];
+  return ORBFE_OK;
+}
+
 // SearchForInitialization (L/src/ORBmatcher.cc:388-492), host pointers, synchronous
 extern "C" int orbfe_search_for_initialization(const orbfe_frame_view* f1, const orbfe_frame_view* f2, float* prev_matched_xy,
                                                int window_size, float nnratio, int check_orientation, int32_t* matches12,

@@ -220,6 +220,30 @@ def search_by_bow_kf(descA, angleA, validA, groupsA, descB, angleB, validB, grou
     return nm.value, matchA
 
 
+def search_for_triangulation(keysA, descA, u_rightA, has_mpA, groupsA, keysB, descB, u_rightB, has_mpB, groupsB, epipolar,
+                             only_stereo=False, check_orientation=True):
+    """SearchForTriangulation (ORBmatcher.cc:614-764) on the device.  Returns (nmatches, matchA); vMatchedPairs are the
+    pairs (i, matchA[i]) with matchA[i] >= 0."""
+    from ._lib import EPIPOLAR_DTYPE
+    L = _lib.lib()
+    keysA = np.ascontiguousarray(keysA, KP_DTYPE); keysB = np.ascontiguousarray(keysB, KP_DTYPE)
+    descA = np.ascontiguousarray(descA, np.uint8).reshape(-1, 32); descB = np.ascontiguousarray(descB, np.uint8).reshape(-1, 32)
+    urA = None if u_rightA is None else np.ascontiguousarray(u_rightA, np.float32)
+    urB = None if u_rightB is None else np.ascontiguousarray(u_rightB, np.float32)
+    hA = np.ascontiguousarray(has_mpA, np.uint8); hB = np.ascontiguousarray(has_mpB, np.uint8)
+    ep = np.ascontiguousarray(epipolar, EPIPOLAR_DTYPE).reshape(1)
+    nA, nnA, iA = featvec_arrays(groupsA)
+    nB, nnB, iB = featvec_arrays(groupsB)
+    matchA = np.full(len(descA), -1, np.int32)
+    nm = C.c_int(0)
+    _lib.check(L.orbfe_search_for_triangulation(_lib.ptr(keysA), _lib.ptr(descA), _lib.ptr(urA), _lib.ptr(hA), len(descA),
+                                                C.cast(nA, C.c_void_p), nnA, _lib.ptr(iA), _lib.ptr(keysB), _lib.ptr(descB), _lib.ptr(urB),
+                                                _lib.ptr(hB), len(descB), C.cast(nB, C.c_void_p), nnB, _lib.ptr(iB), _lib.ptr(ep),
+                                                int(only_stereo), int(check_orientation), _lib.ptr(matchA), C.byref(nm)),
+               "orbfe_search_for_triangulation")
+    return nm.value, matchA
+
+
 def unproject_stereo_batch(kps, desc, n, depth, cams, observed, points, stream):
     """Frame::UnprojectStereo for every keypoint of a batch (torch CUDA tensors): kps (F,cap,28) u8, desc (F,cap,32) u8,
     n (F) i32, depth (F,cap) f32, cams (F,64) u8 [UNPROJECT_CAM_DTYPE], points (F,cap,60) u8 out [LAST_POINT_DTYPE]."""

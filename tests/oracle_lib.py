@@ -38,6 +38,7 @@ MAP_POINT_DTYPE = np.dtype(
 TRACK_DTYPE = np.dtype(
     [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
 )
+EPIPOLAR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ex", "<f4"), ("ey", "<f4"), ("scale_factors", "<f4", (8,)), ("level_sigma2", "<f4", (8,))])
 UNPROJECT_CAM_DTYPE = np.dtype([("Rwc", "<f4", (9,)), ("Ow", "<f4", (3,)), ("cx", "<f4"), ("cy", "<f4"), ("invfx", "<f4"), ("invfy", "<f4")])
 LAST_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("valid", "<i4"), ("observed", "<i4"), ("octave", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
 TRACK_POSE_DTYPE = np.dtype(
@@ -148,6 +149,8 @@ def lib():
     L.oo_search_by_projection_frame.argtypes = [C.POINTER(OOFrame), vp, ci, ci, vp, vp]
     L.oo_search_by_bow.restype = ci
     L.oo_search_by_bow.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp]
+    L.oo_search_for_triangulation.restype = ci
+    L.oo_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp]
     L.oo_search_by_bow_kf.restype = ci
     L.oo_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp]
     L.oo_search_for_initialization.restype = ci
@@ -443,6 +446,23 @@ def search_by_bow_kf(descA, angleA, validA, groupsA, descB, angleB, validB, grou
     nm = lib().oo_search_by_bow_kf(_p(descA), _p(angleA), _p(validA), len(descA), C.cast(nA, C.c_void_p), nnA, _p(iA), _p(descB),
                                    _p(angleB), _p(validB), len(descB), C.cast(nB, C.c_void_p), nnB, _p(iB), nnratio,
                                    int(check_orientation), _p(matchA))
+    return nm, matchA
+
+
+def search_for_triangulation(keysA, descA, u_rightA, has_mpA, groupsA, keysB, descB, u_rightB, has_mpB, groupsB, epipolar,
+                             only_stereo=False, check_orientation=True):
+    keysA = np.ascontiguousarray(keysA, KP_DTYPE); keysB = np.ascontiguousarray(keysB, KP_DTYPE)
+    descA = np.ascontiguousarray(descA, np.uint8); descB = np.ascontiguousarray(descB, np.uint8)
+    urA = None if u_rightA is None else np.ascontiguousarray(u_rightA, np.float32)
+    urB = None if u_rightB is None else np.ascontiguousarray(u_rightB, np.float32)
+    hA = np.ascontiguousarray(has_mpA, np.uint8); hB = np.ascontiguousarray(has_mpB, np.uint8)
+    ep = np.ascontiguousarray(epipolar, EPIPOLAR_DTYPE).reshape(1)
+    nA, nnA, iA = featvec_arrays(groupsA)
+    nB, nnB, iB = featvec_arrays(groupsB)
+    matchA = np.full(len(descA), -1, np.int32)
+    nm = lib().oo_search_for_triangulation(_p(keysA), _p(descA), None if urA is None else _p(urA), _p(hA), len(descA), C.cast(nA, C.c_void_p),
+                                           nnA, _p(iA), _p(keysB), _p(descB), None if urB is None else _p(urB), _p(hB), len(descB),
+                                           C.cast(nB, C.c_void_p), nnB, _p(iB), _p(ep), int(only_stereo), int(check_orientation), _p(matchA))
     return nm, matchA
 
 
