@@ -335,6 +335,17 @@ int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint
                            int n_nodesB, const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA,
                            int* n_matches);
 
+/* The candidate loop of the searches in which no query blocks another -- Fuse (L/src/ORBmatcher.cc:818-868), Fuse with Sim3
+ * (:983-1009), SearchBySim3 (both directions, :1118-1147, 1194-1223): for every query the FIRST minimum-distance keypoint
+ * of KeyFrame::GetFeaturesInArea(u, v, radius) (L/src/KeyFrame.cc:526-567) whose octave lies in [min_level, max_level]
+ * (nPredictedLevel-1 .. nPredictedLevel).  gate: ORBFE_GATE_NONE, or ORBFE_GATE_FUSE_CHI2 = Fuse's reprojection test with
+ * u_r = the projected right coordinate and inv_level_sigma2 = mvInvLevelSigma2 (e2 * invSigma2 > 7.8 stereo / 5.99 mono).
+ * best_idx[q] = keypoint index or -1, best_dist[q] = its distance (256 if none): the caller applies TH_LOW / TH_HIGH and
+ * the map bookkeeping (Replace / AddObservation / the mutual check) in query order.  HOST pointers, synchronous. */
+enum { ORBFE_GATE_NONE = 1, ORBFE_GATE_FUSE_CHI2 = 2 };
+int orbfe_proj_best(const orbfe_frame_view* keyframe, const orbfe_query* q, int nq, int gate, const float* inv_level_sigma2,
+                    int32_t* best_idx, int32_t* best_dist);
+
 /* SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo) (L/src/ORBmatcher.cc:614-764)
  * with CheckDistEpipolarLine (:137-159).  The epipole (:622-630) is computed by the caller. */
 typedef struct orbfe_epipolar {

@@ -1279,6 +1279,41 @@ int oo_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t
   return nmatches;
 }
 
+/* Fuse: L/src/ORBmatcher.cc:818-868; Fuse(Sim3): :983-1009; SearchBySim3: :1118-1147, 1194-1223.  KeyFrame::GetFeaturesInArea
+ * (L/src/KeyFrame.cc:526-567) is Frame's grid walk without the level filter; the level test follows inside the loop. */
+void oo_proj_best(const oo_frame* kf, const oo_query* q, int nq, int gate, const float* inv_level_sigma2, int32_t* best_idx,
+                  int32_t* best_dist) {
+  int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (kf->n ? kf->n : 1));
+  for (int i = 0; i < nq; i++) {
+    best_idx[i] = -1; best_dist[i] = 256;
+    if (!q[i].valid) continue;
+    const float u = q[i].u, v = q[i].v, ur = q[i].u_r;
+    const int nI = oo_features_in_area(kf, u, v, q[i].radius, -1, -1, vIndices);
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < nI; k++) {
+      const int idx = vIndices[k];
+      const oo_keypoint* kp = &kf->keys_un[idx];
+      const int kpLevel = kp->octave;
+      if (kpLevel < q[i].min_level || kpLevel > q[i].max_level) continue;
+      if (gate == 2) {
+        if (kf->u_right && kf->u_right[idx] >= 0) {
+          const float ex = u - kp->x, ey = v - kp->y, er = ur - kf->u_right[idx];
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+        } else {
+          const float ex = u - kp->x, ey = v - kp->y;
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+        }
+      }
+      const int dist = oo_descriptor_distance(q[i].desc, kf->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    best_idx[i] = bestIdx; best_dist[i] = bestIdx >= 0 ? bestDist : 256;
+  }
+  free(vIndices);
+}
+
 /* ORBmatcher::CheckDistEpipolarLine: L/src/ORBmatcher.cc:137-159 */
 static int check_dist_epipolar_line(const oo_keypoint* kp1, const oo_keypoint* kp2, const float* F12, const float* level_sigma2) {
   const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];

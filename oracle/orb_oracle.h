@@ -215,6 +215,11 @@ int oo_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint8_t
                         const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const uint8_t* descB,
                         const float* angleB, const uint8_t* validB, int nB, const oo_featvec_node* nodesB, int n_nodesB,
                         const int32_t* idxB, float nnratio, int check_orientation, int32_t* matchA);
+/* Candidate loop of Fuse (ORBmatcher.cc:818-868; gate = 2: chi-square reprojection test) and of Fuse(Sim3) / SearchBySim3
+ * (:983-1009, 1118-1147; gate = 1: none): first minimum over KeyFrame::GetFeaturesInArea(u, v, radius) with the octave in
+ * [min_level, max_level].  best_idx / best_dist per query (-1 / 256 when nothing qualifies). */
+void oo_proj_best(const oo_frame* kf, const oo_query* q, int nq, int gate, const float* inv_level_sigma2, int32_t* best_idx,
+                  int32_t* best_dist);
 /* SearchForTriangulation: ORBmatcher.cc:614-764 with CheckDistEpipolarLine :137-159.  has_mp: GetMapPoint(i) != NULL; u_right may
  * be NULL (monocular).  matchA[i] = vMatches12[i].  Returns nmatches. */
 typedef struct oo_epipolar { float F12[9], ex, ey, scale_factors[8], level_sigma2[8]; } oo_epipolar;

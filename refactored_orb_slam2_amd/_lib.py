@@ -82,7 +82,7 @@ EXPORTS = [
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
-    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
+    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
     "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow",
@@ -168,6 +168,7 @@ def lib():
     L.orbfe_vocabulary_info.argtypes = [vp, pi, pi, pi, pi]
     L.orbfe_bow_transform_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.orbfe_compute_bow.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, pi, vp, vp, pi]
+    L.orbfe_proj_best.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, vp]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp, pi]
     L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]

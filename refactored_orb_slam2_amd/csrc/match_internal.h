@@ -88,6 +88,8 @@ struct TriParams {
   orbfe_epipolar ep;
 };
 void orbfe_launch_triangulation(const TriParams& p, int n_pairs, hipStream_t s);
+void orbfe_launch_proj_best(const FrameBatch& f, const QueryBatch& q, int gate, const float* inv_sigma2, int32_t* best_idx,
+                            int32_t* best_dist, int n_frames, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s);
 void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s);
 void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s);

@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256) void grid_build_kernel(FrameBatch F) {
 // Enumerates, in the reference's order, the keypoints GetFeaturesInArea returns for query q that also pass the
 // matcher's stereo gate, and calls fn(rank, idx, dist) for each, wave-cooperatively: a chunk of up to 64
 // consecutive grid entries is tested per step, survivors get consecutive ranks.  Returns the survivor count.
-template <typename Fn>
+// GATE 0: the matcher's stereo gate |u_r - mvuRight| <= radius (SearchByProjection); 1: none (Fuse(Sim3), SearchBySim3);
+// 2: Fuse's chi-square reprojection gate (L/src/ORBmatcher.cc:833-854) with inv_sigma2 = mvInvLevelSigma2
+template <int GATE = 0, typename Fn>
 __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, const orbfe_query& q, const uint4 q0,
-                                                const uint4 q1, Fn fn) {
+                                                const uint4 q1, Fn fn, const float* inv_sigma2 = nullptr) {
   const int lane = threadIdx.x & (WAVE - 1);
   const float x = q.u, y = q.v, r = q.radius;
   const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.gw_inv));
@@ -264,11 +266,27 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
       }
       const float distx = kp.x - x, disty = kp.y - y;
       if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
-      if (ok && ur) {
-        const float u = ur[idx];
-        if (u > 0) {
-          const float er = fabsf(q.u_r - u);
-          if (er > r) ok = false;
+      if (GATE == 0) {
+        if (ok && ur) {
+          const float u = ur[idx];
+          if (u > 0) {
+            const float er = fabsf(q.u_r - u);
+            if (er > r) ok = false;
+          }
+        }
+      } else if (GATE == 2) {
+        if (ok) {
+          const float kpr = ur ? ur[idx] : -1.0f;
+          const float ex = x - kp.x, ey = y - kp.y;
+          const float invs = inv_sigma2[kp.octave & 7];
+          if (kpr >= 0) {
+            const float er = q.u_r - kpr;
+            const float e2 = ex * ex + ey * ey + er * er;
+            if ((double)(e2 * invs) > 7.8) ok = false;
+          } else {
+            const float e2 = ex * ex + ey * ey;
+            if ((double)(e2 * invs) > 5.99) ok = false;
+          }
         }
       }
     }
@@ -282,6 +300,41 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
     rank0 += __popcll(m);
   }
   return rank0;
+}
+
+// One wave per query, independent arg-min (no query blocks another): Fuse, Fuse(Sim3), SearchBySim3.  best = first
+// minimum in GetFeaturesInArea order (strict `dist < bestDist`).
+template <int GATE>
+__global__ __launch_bounds__(256) void proj_best_kernel(FrameBatch F, QueryBatch Q, const float* __restrict__ inv_sigma2,
+                                                        int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist) {
+  __shared__ float s_inv[ORBFE_MAX_LEVELS];
+  if (threadIdx.x < 8) s_inv[threadIdx.x] = inv_sigma2 ? inv_sigma2[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int f = blockIdx.y;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= Q.n[f]) return;
+  const orbfe_query* qp = Q.q + (size_t)f * Q.cap + qi;
+  const orbfe_query q = *qp;
+  unsigned key = 0xFFFFFFFFu;
+  int mine = -1;
+  if (q.valid) {
+    uint4 q0, q1;
+    load_desc4(qp->desc, q0, q1);
+    enumerate_window<GATE>(F, f, q, q0, q1, [&](int rank, int idx, int dist, int) {
+      const unsigned k = ((unsigned)dist << 16) | (unsigned)min(rank, 0xffff);
+      if (k < key) { key = k; mine = idx; }
+    }, s_inv);
+  }
+  const unsigned b = wave_min_u32(key);
+  int bi = -1;
+  if (b != 0xFFFFFFFFu) {
+    const unsigned long long wm = __ballot(key == b);
+    bi = __builtin_amdgcn_readlane(mine, __ffsll((long long)wm) - 1);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    best_idx[(size_t)f * Q.cap + qi] = bi;
+    best_dist[(size_t)f * Q.cap + qi] = bi >= 0 ? (int)(b >> 16) : 256;
+  }
 }
 
 // One wave per query: candidate lists in enumeration order.
@@ -1166,6 +1219,14 @@ void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream
   if (n_pairs > 0)
     hipLaunchKernelGGL(bow_match_kernel, dim3(p.sequential ? 1 : n_pairs), dim3(64), (size_t)((max_countB + 15) & ~15), s, p);
   hipLaunchKernelGGL(bow_finish_kernel, dim3(1), dim3(256), 0, s, p);
+}
+void orbfe_launch_proj_best(const FrameBatch& f, const QueryBatch& q, int gate, const float* inv_sigma2, int32_t* best_idx,
+                            int32_t* best_dist, int n_frames, hipStream_t s) {
+  if (q.cap < 1) return;
+  dim3 grid((q.cap + 3) / 4, n_frames);
+  if (gate == 2) hipLaunchKernelGGL(proj_best_kernel<2>, grid, dim3(256), 0, s, f, q, inv_sigma2, best_idx, best_dist);
+  else if (gate == 1) hipLaunchKernelGGL(proj_best_kernel<1>, grid, dim3(256), 0, s, f, q, inv_sigma2, best_idx, best_dist);
+  else hipLaunchKernelGGL(proj_best_kernel<0>, grid, dim3(256), 0, s, f, q, inv_sigma2, best_idx, best_dist);
 }
 void orbfe_launch_triangulation(const TriParams& p, int n_pairs, hipStream_t s) {
   if (n_pairs > 0) hipLaunchKernelGGL(triangulation_match_kernel, dim3(p.b.sequential ? 1 : n_pairs), dim3(64), 0, s, p);

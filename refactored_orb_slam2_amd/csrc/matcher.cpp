@@ -554,6 +554,38 @@ extern "C" int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA,
                   nnratio, check_orientation, 1, matchA, matchB.data(), n_matches);
 }
 
+// Independent arg-min searches (Fuse, Fuse(Sim3), SearchBySim3), host pointers, synchronous
+extern "C" int orbfe_proj_best(const orbfe_frame_view* f, const orbfe_query* q, int nq, int gate, const float* inv_level_sigma2,
+                               int32_t* best_idx, int32_t* best_dist) {
+  if (!frame_ok(f) || nq < 0 || (nq > 0 && (!q || !best_idx || !best_dist)) || (gate != ORBFE_GATE_NONE && gate != ORBFE_GATE_FUSE_CHI2) ||
+      (gate == ORBFE_GATE_FUSE_CHI2 && !inv_level_sigma2))
+    return ORBFE_ERR_INVALID;
+  for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+  if (nq == 0 || f->n == 0) return ORBFE_OK;
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  if ((rc = stage_host(m, f, q, nq, s))) return rc;
+  if ((rc = ensure_proj_scratch(m, 1, f->n, nq))) return rc;
+  if ((rc = mb_alloc(m->lp_cnt, 64))) return rc;
+  if (gate == ORBFE_GATE_FUSE_CHI2) HIPCHK(hipMemcpyAsync(m->lp_cnt.p, inv_level_sigma2, 8 * sizeof(float), hipMemcpyHostToDevice, s));
+  FrameBatch fb;
+  fill_frame_batch(m, fb, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
+                   f->u_right ? (const float*)m->h_ur.p : nullptr, f->n, f->min_x, f->max_x, f->min_y, f->max_y);
+  QueryBatch qb{(const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, nq};
+  orbfe_launch_grid_build(fb, 1, s);
+  // results land in the (otherwise unused here) n_cand / push_idx scratch: nq ints each
+  orbfe_launch_proj_best(fb, qb, gate, (const float*)m->lp_cnt.p, (int32_t*)m->n_cand.p, (int32_t*)m->push_idx.p, 1, s);
+  if ((rc = launch_ok())) return rc;
+  HIPCHK(hipMemcpyAsync(best_idx, m->n_cand.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(best_dist, m->push_idx.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ORBFE_OK;
+}
+
 // SearchForTriangulation (L/src/ORBmatcher.cc:614-764), host pointers, synchronous
 extern "C" int orbfe_search_for_triangulation(const orbfe_keypoint* keysA, const uint8_t* descA, const float* u_rightA,
                                               const uint8_t* has_mpA, int nA, const orbfe_featvec_node* nodesA, int n_nodesA,

@@ -173,6 +173,16 @@ class ORBmatcher:
                    "orbfe_search_by_projection_keyframe")
         return nm.value, assigned, blocked
 
+    # ---- candidate loop of Fuse / Fuse(Sim3) / SearchBySim3: independent first-minimum per query
+    def ProjBest(self, keyframe: FrameView, queries: np.ndarray, inv_level_sigma2=None):
+        """inv_level_sigma2 given -> Fuse's chi-square gate (ORBmatcher.cc:833-854), else no gate.  Returns (best_idx, best_dist)."""
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        bi = np.full(len(q), -1, np.int32); bd = np.full(len(q), 256, np.int32)
+        inv = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        _lib.check(self._L.orbfe_proj_best(C.byref(keyframe.c), _lib.ptr(q), len(q), 2 if inv is not None else 1, _lib.ptr(inv),
+                                           _lib.ptr(bi), _lib.ptr(bd)), "orbfe_proj_best")
+        return bi, bd
+
     # ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): ORBmatcher.cc:388-492
     def SearchForInitialization(self, f1: FrameView, f2: FrameView, prev_matched: np.ndarray, windowSize: int = 10):
         """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""

@@ -149,6 +149,8 @@ def lib():
     L.oo_search_by_projection_frame.argtypes = [C.POINTER(OOFrame), vp, ci, ci, vp, vp]
     L.oo_search_by_bow.restype = ci
     L.oo_search_by_bow.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp]
+    L.oo_proj_best.restype = None
+    L.oo_proj_best.argtypes = [C.POINTER(OOFrame), vp, ci, ci, vp, vp, vp]
     L.oo_search_for_triangulation.restype = ci
     L.oo_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp]
     L.oo_search_by_bow_kf.restype = ci
@@ -360,6 +362,17 @@ def _kf(self, queries, check_orientation=True, orb_dist=100, blocked=None):
 
 
 OracleFrame.search_by_projection_keyframe = _kf
+
+
+def _proj_best(self, queries, inv_level_sigma2=None):
+    q = np.ascontiguousarray(queries, QUERY_DTYPE)
+    bi = np.full(len(q), -1, np.int32); bd = np.full(len(q), 256, np.int32)
+    inv = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    lib().oo_proj_best(C.byref(self.f), _p(q), len(q), 2 if inv is not None else 1, None if inv is None else _p(inv), _p(bi), _p(bd))
+    return bi, bd
+
+
+OracleFrame.proj_best = _proj_best
 
 
 def unproject_stereo(cam, keys, desc, depth, observed=1):

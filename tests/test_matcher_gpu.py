@@ -472,6 +472,35 @@ def test_hip_reproduces_golden_matcher():
         np.testing.assert_array_equal(cand[i, : n[i]]["idx"], exp)
 
 
+@pytest.mark.parametrize("th", [3.0, 7.5])
+def test_proj_best_fuse_and_sim3(th):
+    """candidate loop of Fuse (chi-square gate) and of Fuse(Sim3) / SearchBySim3 (no gate): independent first minimum"""
+    w, h = 640, 480
+    k0, d0, k1, d1, sf = _two_frames(w, h, 1000)
+    rng = np.random.default_rng(23)
+    ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - np.float32(20.0) + rng.normal(0, 1, len(k1)).astype(np.float32), np.float32(-1)).astype(np.float32)
+    q = _queries_from_last(k0, d0, sf, th, rng=rng)
+    q["max_level"] = k0["octave"]                 # nPredictedLevel-1 .. nPredictedLevel
+    q["u_r"] = q["u"] - np.float32(20.0)
+    inv_sigma2 = (np.float32(1) / (sf * sf)).astype(np.float32)
+    fv = FrameView(k1, d1, 0, w, 0, h, ur)
+    of = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, ur)
+    m = ORBmatcher()
+    for inv in (inv_sigma2, None):
+        bi, bd = m.ProjBest(fv, q, inv)
+        obi, obd = of.proj_best(q, inv)
+        np.testing.assert_array_equal(bi, obi); np.testing.assert_array_equal(bd, obd)
+        assert (bi >= 0).sum() > 0.4 * len(q)
+    # the gate matters: without it more queries find a keypoint (or a closer one)
+    g_bi, g_bd = m.ProjBest(fv, q, inv_sigma2)
+    n_bi, n_bd = m.ProjBest(fv, q, None)
+    assert ((n_bd < g_bd) | ((g_bi < 0) & (n_bi >= 0))).any()
+    # mono keyframe (no mvuRight): the 5.99 branch everywhere
+    fvm = FrameView(k1, d1, 0, w, 0, h, None); ofm = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, None)
+    bi, bd = m.ProjBest(fvm, q, inv_sigma2); obi, obd = ofm.proj_best(q, inv_sigma2)
+    np.testing.assert_array_equal(bi, obi); np.testing.assert_array_equal(bd, obd)
+
+
 @pytest.mark.parametrize("only_stereo,mono", [(False, False), (True, False), (False, True)])
 def test_search_for_triangulation(only_stereo, mono):
     """SearchForTriangulation: BoW node groups, epipole / epipolar-line gates, last-minimum tie rule, rotation histogram"""
