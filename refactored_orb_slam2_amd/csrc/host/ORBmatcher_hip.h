@@ -170,6 +170,53 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
   return nmatches;
 }
 
+// DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>, ascending node ids) -> the flat form of the C ABI
+template <class FeatVecT>
+inline void FlattenFeatureVector(const FeatVecT& fv, std::vector<orbfe_featvec_node>& nodes, std::vector<int32_t>& idx) {
+  nodes.clear();
+  idx.clear();
+  for (const auto& kv : fv) {
+    orbfe_featvec_node nd;
+    nd.node_id = (int32_t)kv.first;
+    nd.start = (int32_t)idx.size();
+    nd.count = (int32_t)kv.second.size();
+    nodes.push_back(nd);
+    for (const auto i : kv.second) idx.push_back((int32_t)i);
+  }
+}
+
+// SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)   L/src/ORBmatcher.cc:161-273 -- whole body.
+// Members used: pKF->GetMapPointMatches(), mFeatVec, mDescriptors, mvKeysUn; F.N, mFeatVec, mDescriptors, mvKeys.
+template <class KeyFrameT, class FrameT, class MapPointT>
+int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches, float nnratio, bool checkOrientation) {
+  const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+  vpMapPointMatches.assign((size_t)F.N, static_cast<MapPointT*>(nullptr));
+  const int nKF = (int)vpMapPointsKF.size();
+  std::vector<orbfe_featvec_node> nodesKF, nodesF;
+  std::vector<int32_t> idxKF, idxF;
+  FlattenFeatureVector(pKF->mFeatVec, nodesKF, idxKF);
+  FlattenFeatureVector(F.mFeatVec, nodesF, idxF);
+  std::vector<uint8_t> validKF((size_t)nKF, 0);
+  std::vector<float> anglesKF((size_t)nKF), anglesF((size_t)F.N);
+  for (int i = 0; i < nKF; i++) {
+    validKF[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();   // :191-197
+    anglesKF[i] = pKF->mvKeysUn[i].angle;                          // :229
+  }
+  for (int j = 0; j < F.N; j++) anglesF[j] = F.mvKeys[j].angle;   // :229 (mvKeys, not mvKeysUn: the angle is the same)
+  std::vector<int32_t> matchB((size_t)(F.N > 0 ? F.N : 1), -1);
+  int nmatches = 0;
+  const int rc = orbfe_search_by_bow(pKF->mDescriptors.ptr(0), anglesKF.data(), validKF.data(), nKF, nodesKF.data(),
+                                     (int)nodesKF.size(), idxKF.data(), F.mDescriptors.ptr(0), anglesF.data(), F.N, nodesF.data(),
+                                     (int)nodesF.size(), idxF.data(), nnratio, checkOrientation ? 1 : 0, matchB.data(), &nmatches);
+  if (rc != ORBFE_OK) {
+    fprintf(stderr, "ORBmatcher::SearchByBoW: liborbfe error %d: %s\n", rc, orbfe_last_error());
+    return 0;
+  }
+  for (int j = 0; j < F.N; j++)
+    if (matchB[j] >= 0) vpMapPointMatches[(size_t)j] = vpMapPointsKF[(size_t)matchB[j]];   // :226
+  return nmatches;
+}
+
 // SearchByProjection(Frame& cur, const Frame& last, th, bMono)   L/src/ORBmatcher.cc:1247-1383
 // `queries[i]` is filled by the caller from LastFrame point i exactly as the reference projects it
 // (:1276-1308): u, v, u_r = u - mbf*invzc, radius = th*scale[octave], the forward/backward level range,

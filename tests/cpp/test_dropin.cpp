@@ -10,6 +10,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -279,6 +280,50 @@ int main(int argc, char** argv) {
               lps[i].mnTrackScaleLevel == otr[i].level && lps[i].mTrackViewCos == otr[i].view_cos);
     }
     printf("SearchLocalPoints ok: %d to match, %d matches\n", ntm, nml);
+  }
+  {
+    // ---- SearchByBoW(KeyFrame*, Frame&, ...) through the adapter (std::map FeatureVectors) vs. the oracle
+    struct MockKF {
+      std::vector<MockMapPoint*> mps;
+      std::map<unsigned, std::vector<unsigned>> mFeatVec;
+      cv::Mat mDescriptors;
+      std::vector<cv::KeyPoint> mvKeysUn;
+      std::vector<MockMapPoint*> GetMapPointMatches() { return mps; }
+    };
+    struct MockF {
+      int N = 0;
+      std::map<unsigned, std::vector<unsigned>> mFeatVec;
+      cv::Mat mDescriptors;
+      std::vector<cv::KeyPoint> mvKeys;
+    };
+    MockKF kf;
+    MockF fr;
+    kf.mDescriptors = desc; kf.mvKeysUn = keys; kf.mps.assign(on, nullptr);
+    fr.N = on; fr.mvKeys = keys;
+    fr.mDescriptors = cv::Mat(on, 32, cv::CV_8U);
+    for (int i = 0; i < on; i++) {
+      memcpy(fr.mDescriptors.ptr(i), desc.ptr((i * 7 + 3) % on), 32);   // a permutation of the keyframe's descriptors ...
+      if (i % 3 == 0) fr.mDescriptors.ptr(i)[i % 32] ^= 0x11;          // ... with a few flipped bits
+      fr.mvKeys[i] = keys[(i * 7 + 3) % on];
+      if (i % 11) kf.mps[i] = &mps[i];                                  // mps[i].bad for i % 29 == 0 (set above)
+      kf.mFeatVec[desc.ptr(i)[0] % 40].push_back((unsigned)i);
+      fr.mFeatVec[fr.mDescriptors.ptr(i)[0] % 40].push_back((unsigned)i);
+    }
+    std::vector<MockMapPoint*> matches;
+    const int nb = ORB_SLAM2::orbfe_host::SearchByBoW(&kf, fr, matches, 0.7f, true);
+    std::vector<oo_featvec_node> nA, nB;
+    std::vector<int32_t> iA, iB;
+    for (auto& kv : kf.mFeatVec) { nA.push_back({(int32_t)kv.first, (int32_t)iA.size(), (int32_t)kv.second.size()}); for (auto v : kv.second) iA.push_back((int32_t)v); }
+    for (auto& kv : fr.mFeatVec) { nB.push_back({(int32_t)kv.first, (int32_t)iB.size(), (int32_t)kv.second.size()}); for (auto v : kv.second) iB.push_back((int32_t)v); }
+    std::vector<uint8_t> validA(on);
+    std::vector<float> angA(on), angB(on);
+    for (int i = 0; i < on; i++) { validA[i] = kf.mps[i] && !kf.mps[i]->isBad(); angA[i] = keys[i].angle; angB[i] = fr.mvKeys[i].angle; }
+    std::vector<int32_t> omatchB(on, -1);
+    const int onb = oo_search_by_bow(desc.ptr(0), angA.data(), validA.data(), nA.data(), (int)nA.size(), iA.data(), fr.mDescriptors.ptr(0),
+                                     angB.data(), on, nB.data(), (int)nB.size(), iB.data(), 0.7f, 1, omatchB.data());
+    CHECK(nb == onb && nb > on / 8 && (int)matches.size() == on);
+    for (int j = 0; j < on; j++) CHECK(matches[j] == (omatchB[j] >= 0 ? kf.mps[omatchB[j]] : nullptr));
+    printf("SearchByBoW ok: %d matches\n", nb);
   }
   oo_extractor_destroy(orc);
   delete ext;
