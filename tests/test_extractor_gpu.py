@@ -112,6 +112,21 @@ def test_batch_equals_single_and_is_idempotent():
     ex.close()
 
 
+def test_batch_of_19_images_covers_both_workgroup_orders():
+    """orient_describe hands whole images to XCDs in sets of eight and keeps the dispatch order for the remainder: 19 images
+    exercise both in one launch; every image must equal its single-image extraction"""
+    w, h, nf, B = 640, 480, 1000, 19
+    imgs = synth.sequence(w, h, B, seq=9)
+    ex = ORBextractor(nf)
+    batch = ex.extract_batch(imgs)
+    for i in (0, 7, 8, 15, 16, 18):
+        k, d = ex(imgs[i])
+        np.testing.assert_array_equal(batch[i][0], k); np.testing.assert_array_equal(batch[i][1], d)
+    ok, od = ol.OracleExtractor(nf)(imgs[17])
+    np.testing.assert_array_equal(batch[17][0], ok); np.testing.assert_array_equal(batch[17][1], od)
+    ex.close()
+
+
 def test_keypoint_invariants_at_full_size():
     """size-independent properties on the benchmark geometry (no oracle needed)."""
     w, h, nf = 1241, 376, 2000
