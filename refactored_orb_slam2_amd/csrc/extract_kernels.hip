@@ -784,33 +784,43 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
   {
-    // (BT_H+6) rows x 18 dwords (x = ox-4 .. ox+67): five per thread, all issued before the first LDS store.  A dword that
-    // lies inside the row is one aligned load; the few that straddle the image border (left edge, the partial dword at
-    // the right edge, columns beyond it) are assembled from bytes with REFLECT_101 indexing.  Rows reflect as a whole.
+    // (BT_H+6) rows x 18 dwords (x = ox-4 .. ox+67).  Thread -> dword column c = tid % 18 and rows r0 + 14 k (one division;
+    // 252 of 256 threads), all loads issued before the first LDS store.  Interior tiles (the common case, wave-uniform) load
+    // plain aligned dwords; on edge tiles a dword that straddles the image border (left edge, the partial dword at the right
+    // edge, columns beyond it) is assembled from bytes with REFLECT_101 indexing, and rows reflect as a whole.
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
-    constexpr int NLD = ((BT_H + 6) * 18 + 255) / 256;
+    constexpr int RPP = 14, NLD = (BT_H + 6 + RPP - 1) / RPP;
+    const int r0 = tid / 18, c = tid - r0 * 18;
+    const int x = ox - 4 + 4 * c;
     uint32_t v[NLD];
+    const bool interior = oy >= 3 && oy + BT_H + 3 <= h && ox >= 4 && ox + BT_W + 4 <= w;
+    if (r0 < RPP) {
+      if (interior) {
+        const uint8_t* p0 = S + (size_t)(oy - 3 + r0) * pitch + x;
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = tid + 256 * k;
-      const int r = i / 18, c = i - r * 18;
-      v[k] = 0u;
-      if (i < (BT_H + 6) * 18) {
-        const int gy = reflect101(oy + r - 3, h), x = ox - 4 + 4 * c;
-        const uint8_t* row = S + (size_t)gy * pitch;
-        if (x >= 0 && x + 3 < w) {
-          v[k] = *reinterpret_cast<const uint32_t*>(row + x);
-        } else {
+        for (int k = 0; k < NLD; k++)
+          v[k] = r0 + RPP * k < BT_H + 6 ? *reinterpret_cast<const uint32_t*>(p0 + (size_t)(RPP * k) * pitch) : 0u;
+      } else {
+        const bool whole = x >= 0 && x + 3 < w;
+        int gx[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) v[k] |= (uint32_t)row[reflect101(x + j, w)] << (8 * j);
+        for (int j = 0; j < 4; j++) gx[j] = reflect101(x + j, w);
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+          const int r = r0 + RPP * k;
+          v[k] = 0u;
+          if (r < BT_H + 6) {
+            const uint8_t* row = S + (size_t)reflect101(oy + r - 3, h) * pitch;
+            if (whole) v[k] = *reinterpret_cast<const uint32_t*>(row + x);
+            else v[k] = (uint32_t)row[gx[0]] | ((uint32_t)row[gx[1]] << 8) | ((uint32_t)row[gx[2]] << 16) | ((uint32_t)row[gx[3]] << 24);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = tid + 256 * k;
-      const int r = i / 18, c = i - r * 18;
-      if (i < (BT_H + 6) * 18) in32[r * (BT_INP / 4) + c] = v[k];
+      for (int k = 0; k < NLD; k++) {
+        const int r = r0 + RPP * k;
+        if (r < BT_H + 6) in32[r * (BT_INP / 4) + c] = v[k];
+      }
     }
   }
   __syncthreads();
