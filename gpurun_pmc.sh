@@ -1,11 +1,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/pmc6 gpurun_out/prof6 gpurun_out/prof6lp
+mkdir -p gpurun_out/pmc7 gpurun_out/prof7 gpurun_out/prof7lp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   name=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc6 -o $name -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/pmc6/$name.log 2>&1 || echo "failed $name"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc7 -o $name -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/pmc7/$name.log 2>&1 || echo "failed $name"
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof6 -o r6 -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/prof6/bench.log 2>&1
-tail -1 gpurun_out/prof6/bench.log | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof6lp -o lp -- python3 tools/bench_local_points.py > gpurun_out/prof6lp/bench.log 2>&1
-tail -1 gpurun_out/prof6lp/bench.log | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof7 -o r7 -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/prof7/bench.log 2>&1
+tail -1 gpurun_out/prof7/bench.log | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof7lp -o lp -- python3 tools/bench_local_points.py > gpurun_out/prof7lp/bench.log 2>&1
+tail -1 gpurun_out/prof7lp/bench.log | cut -c1-300
 python bench.py | cut -c1-2500
