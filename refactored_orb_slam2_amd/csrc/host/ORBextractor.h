@@ -53,7 +53,7 @@ class ORBextractor {
   // Host copies of the 8-bit pyramid of the last call (read by Frame::ComputeStereoMatches,
   // L/src/Frame.cc:483,567-589).  Each level is a view into a buffer with a 19-pixel REFLECT_101 border,
   // like the reference's.  Disable the per-call download with SetPyramidDownload(false) when the stereo
-  // association runs on the device (orbfe_stereo_match_last).
+  // association runs on the device (orbfe_stereo_match_device).
   std::vector<cv::Mat> mvImagePyramid;
 
   // ---- additions (not in the reference)
