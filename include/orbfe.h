@@ -233,7 +233,7 @@ typedef struct orbfe_frustum {
   float fx, fy, cx, cy, mbf;
   float min_x, max_x, min_y, max_y;   /* mnMinX, mnMaxX, mnMinY, mnMaxY */
   float log_scale_factor;             /* mfLogScaleFactor */
-  int32_t n_levels;                   /* mnScaleLevels (<= 8) */
+  int32_t n_levels;                   /* mnScaleLevels, 1..8 (ORBFE_ERR_INVALID otherwise) */
   float scale_factors[8];             /* mvScaleFactors */
 } orbfe_frustum;                      /* 136 bytes */
 

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(FQ_THREADS) void frustum_queries_kernel(const orbfe
       float r = ((double)tr.view_cos > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos (:130-135)
       if ((double)th != 1.0) r *= th;
       q.u = tr.proj_x; q.v = tr.proj_y; q.u_r = tr.proj_xr;
-      q.radius = r * fr.scale_factors[tr.level];
+      q.radius = r * fr.scale_factors[tr.level & 7];   // n_levels <= 8 (checked on the host entry point)
       q.min_level = tr.level - 1;
       q.max_level = tr.level;
       q.valid = 1;

@@ -389,7 +389,7 @@ extern "C" int orbfe_search_local_points(const orbfe_frame_view* f, const orbfe_
                                          int n_points, float th, float nnratio, orbfe_track* track, uint8_t* blocked,
                                          int32_t* assigned, int* n_to_match, int* n_matches) {
   if (!frame_ok(f) || !fr || n_points < 0 || (n_points > 0 && (!mp || !track)) || !blocked || !assigned || !n_to_match ||
-      !n_matches || fr->n_levels < 1 || fr->n_levels > ORBFE_MAX_LEVELS)
+      !n_matches || fr->n_levels < 1 || fr->n_levels > 8)  // orbfe_frustum::scale_factors holds 8 levels
     return ORBFE_ERR_INVALID;
   *n_to_match = 0;
   *n_matches = 0;
