@@ -211,3 +211,39 @@ def test_dense_texture_spills_keys_to_hbm():
     ok, od = ol.OracleExtractor(2000)(img)
     np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
     ex.close()
+
+
+def test_rccl_gather_self_check_world1():
+    """with one visible GPU the exchange degrades to a self-check -- pack the per-frame records, gather them over
+    RCCL (backend "nccl") at world size 1, unpack, compare with the unsharded extraction"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from refactored_orb_slam2_amd import sharding
+    w, h, nf, F = 640, 480, 1000, 5
+    imgs = synth.sequence(w, h, F, seq=4)
+    ex = ORBextractor(nf)
+    single = ex.extract_batch(imgs)
+    cap = ex.max_keypoints(w, h)
+    dimg = torch.from_numpy(np.stack(imgs)).cuda()
+    kps = torch.zeros((F, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(F, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(dimg, kps, desc, n)
+    ex.sync()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ag = sharding.AsyncGather(n, kps, desc)       # the overlapped variant bench.py uses: really runs the collective
+        ag.launch(n, kps, desc)
+        n_all, k_all, d_all = ag.result()
+        torch.cuda.synchronize()
+        frames = sharding.unpack_records(n_all, k_all, d_all, F)
+        assert len(frames) == F
+        for (k, d), (k0, d0) in zip(frames, single):
+            np.testing.assert_array_equal(k, k0)
+            np.testing.assert_array_equal(d, d0)
+    finally:
+        dist.destroy_process_group()
+    ex.close()
