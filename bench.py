@@ -3,7 +3,8 @@
 
 One "step" = one batch of F synthetic KITTI-geometry stereo frames (1241x376, 2000 features, 8 levels)
 resident in HBM, pushed through the whole hot path on one GPU:
-    ORBextractor left + right  ->  Frame::ComputeStereoMatches  ->  SearchByProjection(cur, last)
+    ORBextractor left + right  ->  Frame::ComputeStereoMatches  ->  Frame::UnprojectStereo of every stereo point
+    ->  its projection into the next frame (ORBmatcher.cc:1270-1308)  ->  SearchByProjection(cur, last)
 N > 1 shards independent frames over ranks (one process per GPU, weak scaling: F frames per rank per step)
 and gathers the per-frame keypoint/descriptor records with one RCCL all_gather per step -- the only
 exchange the path has (BASELINE.json north_star).
