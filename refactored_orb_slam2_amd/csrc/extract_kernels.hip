@@ -339,22 +339,24 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
 
   const int tw = width - 6, th = rows - 6;  // tested region of the group: [3, width-3) x [3, rows-3)
   const int npix = (tw > 0 && th > 0) ? tw * th : 0;
-  const uint8_t* T = tile + xo;
 
   // ---- A1 (flattened over the tested region; the index advances without divisions).  Scalar bytes on purpose: on
   // gfx950 v_pk_*16 / v_perm_b32 / min / max all issue at 16 lanes per clock, the same as their scalar forms, so a packed
   // two-pixels-per-lane variant (tried: 78 VALU per 4 pixels) was slower than this one (tools/valu_bench.hip).
   {
-    int ty = (int)((tid + 0.5f) * (1.0f / (float)(tw > 0 ? tw : 1)));
-    int tx = tid - ty * tw;
-    const int sa = FG_THREADS / (tw > 0 ? tw : 1), sb = FG_THREADS - sa * tw;
+    const int ty0 = (int)((tid + 0.5f) * (1.0f / (float)(tw > 0 ? tw : 1)));
+    int tx = tid - ty0 * tw;
+    const int sa = FG_THREADS / (tw > 0 ? tw : 1), sb = FG_THREADS - sa * tw;   // FG_THREADS = sa * tw + sb, sb < tw
+    const int delta = sa * ORBFE_FG_PITCH + sb;
+    // the pixel's byte offset in the staged tile is carried along (one multiply per thread, not per pixel) and doubles as the
+    // survivor-list entry: sc uses the same offsets, so A2 / B address both planes with it directly
+    int off = (ty0 + 3) * ORBFE_FG_PITCH + tx + 3 + xo;
     typedef unsigned u16;  // 32-bit container, value in the low half
     // (processing two pixels per iteration with all 18 LDS reads up front was measured slower: the phase is bound by
     // VALU / SALU issue, not by LDS latency)
     for (int p = tid; p < npix; p += FG_THREADS) {
-      const int x = tx + 3, y = ty + 3;
-      const uint8_t* c = T + y * ORBFE_FG_PITCH + x;
-      const int v = c[0];
+      const uint8_t* c = tile + off;
+      const u16 v = c[0];
       const u16 q0 = c[3 * ORBFE_FG_PITCH], q8 = c[-3 * ORBFE_FG_PITCH];
       const u16 q2 = c[2 * ORBFE_FG_PITCH + 2], q10 = c[-2 * ORBFE_FG_PITCH - 2];
       const u16 q4 = c[3], q12 = c[-3];
@@ -362,12 +364,12 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
       const u16 d01 = max16(min16(q0, q8), min16(q2, q10)), d23 = max16(min16(q4, q12), min16(q6, q14));
       const u16 b01 = min16(max16(q0, q8), max16(q2, q10)), b23 = min16(max16(q4, q12), max16(q6, q14));
       const int dm = (int)max16(d01, d23), bm = (int)min16(b01, b23);
-      if (dm < v - min_th || bm > v + min_th) {
+      if (dm < (int)v - min_th || bm > (int)v + min_th) {
         const int idx = atomicAdd(&nlist, 1);
-        if (idx < clist_cap) clist[idx] = (uint16_t)((y << 8) | x);
+        if (idx < clist_cap) clist[idx] = (uint16_t)off;
       }
-      tx += sb; ty += sa;
-      while (tx >= tw) { tx -= tw; ty++; }
+      tx += sb; off += delta;
+      if (tx >= tw) { tx -= tw; off += ORBFE_FG_PITCH - tw; }
     }
   }
   __syncthreads();
@@ -375,25 +377,25 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
   // ---- A2: exact score of the survivors
   const int nl = min(nlist, clist_cap);
   for (int i = tid; i < nl; i += FG_THREADS) {
-    const int e = clist[i];
-    const int x = e & 0xff, y = e >> 8;
-    const uint8_t* c = T + y * ORBFE_FG_PITCH + x;
+    const int e = clist[i];   // byte offset of the pixel in the tile (and in sc)
+    const uint8_t* c = tile + e;
     const int v = c[0];
     unsigned d[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) d[k] = (unsigned)(v - (int)c[RDY[k] * ORBFE_FG_PITCH + RDX[k]]);
     const int sc16 = corner_score16_h(d);
-    if (sc16 >= min_th) sc[y * ORBFE_FG_PITCH + x] = (uint8_t)sc16;
+    if (sc16 >= min_th) sc[e] = (uint8_t)sc16;
   }
   __syncthreads();
 
   // ---- B: strict 3x3 NMS inside the survivor's own cell
   for (int i = tid; i < nl; i += FG_THREADS) {
     const int e = clist[i];
-    const int x = e & 0xff, y = e >> 8;
-    const uint8_t* s = sc + y * ORBFE_FG_PITCH + x;
+    const uint8_t* s = sc + e;
     const int v = s[0];
     if (v > 0) {
+      const int y = (int)((e + 0.5f) * (1.0f / ORBFE_FG_PITCH));   // exact: e < 66 * 192
+      const int x = e - y * ORBFE_FG_PITCH - xo;
       const int xr = x - 3;
       const int c = (xr >= wcell) + (xr >= 2 * wcell) + (xr >= 3 * wcell);
       const int lo = c * wcell + 3, hi = (c == ncell - 1) ? width - 3 : lo + wcell;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
         const int p = (2 * lane + w) * 32 + b;
         const int ty = (int)((p + 0.5f) * inv_twc);
         const int x = p - ty * twc + lo, y = ty + 3;
-        const uint32_t sv = sc[y * ORBFE_FG_PITCH + x];
+        const uint32_t sv = sc[y * ORBFE_FG_PITCH + x + xo];
         const uint32_t rx = (uint32_t)(x + g.x0 - ORBFE_EDGE), ry = (uint32_t)(y + g.y0 - ORBFE_EDGE);
         if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
         off++;
