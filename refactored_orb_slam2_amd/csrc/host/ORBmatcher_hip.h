@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "../../../include/orbfe.h"
@@ -215,6 +216,103 @@ int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMa
   for (int j = 0; j < F.N; j++)
     if (matchB[j] >= 0) vpMapPointMatches[(size_t)j] = vpMapPointsKF[(size_t)matchB[j]];   // :226
   return nmatches;
+}
+
+// SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)   L/src/ORBmatcher.cc:494-612 -- whole body.
+template <class KeyFrameT, class MapPointT>
+int SearchByBoWKeyFrames(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, float nnratio,
+                         bool checkOrientation) {
+  const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+  const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+  const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+  vpMatches12.assign((size_t)n1, static_cast<MapPointT*>(nullptr));
+  std::vector<orbfe_featvec_node> nodes1, nodes2;
+  std::vector<int32_t> idx1, idx2;
+  FlattenFeatureVector(pKF1->mFeatVec, nodes1, idx1);
+  FlattenFeatureVector(pKF2->mFeatVec, nodes2, idx2);
+  std::vector<uint8_t> valid1((size_t)n1), valid2((size_t)n2);
+  std::vector<float> ang1((size_t)n1), ang2((size_t)n2);
+  for (int i = 0; i < n1; i++) { valid1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad(); ang1[i] = pKF1->mvKeysUn[i].angle; }
+  for (int i = 0; i < n2; i++) { valid2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad(); ang2[i] = pKF2->mvKeysUn[i].angle; }
+  std::vector<int32_t> matchA((size_t)(n1 > 0 ? n1 : 1), -1);
+  int nmatches = 0;
+  const int rc = orbfe_search_by_bow_kf(pKF1->mDescriptors.ptr(0), ang1.data(), valid1.data(), n1, nodes1.data(), (int)nodes1.size(),
+                                        idx1.data(), pKF2->mDescriptors.ptr(0), ang2.data(), valid2.data(), n2, nodes2.data(),
+                                        (int)nodes2.size(), idx2.data(), nnratio, checkOrientation ? 1 : 0, matchA.data(), &nmatches);
+  if (rc != ORBFE_OK) {
+    fprintf(stderr, "ORBmatcher::SearchByBoW(KF,KF): liborbfe error %d: %s\n", rc, orbfe_last_error());
+    return 0;
+  }
+  for (int i = 0; i < n1; i++)
+    if (matchA[i] >= 0) vpMatches12[(size_t)i] = vpMapPoints2[(size_t)matchA[i]];   // :566
+  return nmatches;
+}
+
+// SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)   L/src/ORBmatcher.cc:614-764 -- everything after the
+// epipole (:622-630), which the caller passes as (ex, ey) together with F12 as nine row-major floats.
+// Members used: N, GetMapPoint(i), mvuRight, mvKeysUn, mDescriptors, mFeatVec; pKF2->mvScaleFactors, mvLevelSigma2.
+template <class KeyFrameT>
+int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, const float F12[9], float ex, float ey,
+                           std::vector<std::pair<size_t, size_t>>& vMatchedPairs, bool bOnlyStereo, bool checkOrientation) {
+  static_assert(sizeof(pKF1->mvKeysUn[0]) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
+  const int n1 = pKF1->N, n2 = pKF2->N;
+  std::vector<orbfe_featvec_node> nodes1, nodes2;
+  std::vector<int32_t> idx1, idx2;
+  FlattenFeatureVector(pKF1->mFeatVec, nodes1, idx1);
+  FlattenFeatureVector(pKF2->mFeatVec, nodes2, idx2);
+  std::vector<uint8_t> has1((size_t)(n1 > 0 ? n1 : 1)), has2((size_t)(n2 > 0 ? n2 : 1));
+  for (int i = 0; i < n1; i++) has1[i] = pKF1->GetMapPoint((size_t)i) != nullptr;
+  for (int i = 0; i < n2; i++) has2[i] = pKF2->GetMapPoint((size_t)i) != nullptr;
+  orbfe_epipolar ep;
+  memset(&ep, 0, sizeof(ep));
+  memcpy(ep.F12, F12, sizeof(ep.F12));
+  ep.ex = ex; ep.ey = ey;
+  for (size_t l = 0; l < pKF2->mvScaleFactors.size() && l < 8; l++) {
+    ep.scale_factors[l] = pKF2->mvScaleFactors[l];
+    ep.level_sigma2[l] = pKF2->mvLevelSigma2[l];
+  }
+  std::vector<int32_t> matchA((size_t)(n1 > 0 ? n1 : 1), -1);
+  int nmatches = 0;
+  const int rc = orbfe_search_for_triangulation(
+      reinterpret_cast<const orbfe_keypoint*>(pKF1->mvKeysUn.data()), pKF1->mDescriptors.ptr(0),
+      pKF1->mvuRight.empty() ? nullptr : pKF1->mvuRight.data(), has1.data(), n1, nodes1.data(), (int)nodes1.size(), idx1.data(),
+      reinterpret_cast<const orbfe_keypoint*>(pKF2->mvKeysUn.data()), pKF2->mDescriptors.ptr(0),
+      pKF2->mvuRight.empty() ? nullptr : pKF2->mvuRight.data(), has2.data(), n2, nodes2.data(), (int)nodes2.size(), idx2.data(), &ep,
+      bOnlyStereo ? 1 : 0, checkOrientation ? 1 : 0, matchA.data(), &nmatches);
+  vMatchedPairs.clear();
+  if (rc != ORBFE_OK) {
+    fprintf(stderr, "ORBmatcher::SearchForTriangulation: liborbfe error %d: %s\n", rc, orbfe_last_error());
+    return 0;
+  }
+  vMatchedPairs.reserve((size_t)nmatches);
+  for (int i = 0; i < n1; i++)
+    if (matchA[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)matchA[i]));   // :754-761
+  return nmatches;
+}
+
+// Frame::ComputeBoW (L/src/Frame.cc:412-417): mBowVec / mFeatVec from the device-side vocabulary transform.
+// BowVecT = DBoW2::BowVector (std::map<WordId, WordValue>), FeatVecT = DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>).
+template <class BowVecT, class FeatVecT>
+int ComputeBoW(orbfe_vocabulary* voc, const uint8_t* descriptors, int N, BowVecT& bowVec, FeatVecT& featVec, int levelsup = 4) {
+  bowVec.clear();
+  featVec.clear();
+  if (N <= 0) return ORBFE_OK;
+  std::vector<int32_t> bowIds((size_t)N), fvIdx((size_t)N);
+  std::vector<double> bowVals((size_t)N);
+  std::vector<orbfe_featvec_node> fvNodes((size_t)N);
+  int nBow = 0, nFv = 0;
+  const int rc = orbfe_compute_bow(voc, descriptors, N, levelsup, nullptr, nullptr, nullptr, bowIds.data(), bowVals.data(), &nBow,
+                                   fvNodes.data(), fvIdx.data(), &nFv);
+  if (rc != ORBFE_OK) {
+    fprintf(stderr, "Frame::ComputeBoW: liborbfe error %d: %s\n", rc, orbfe_last_error());
+    return rc;
+  }
+  for (int i = 0; i < nBow; i++) bowVec.insert(bowVec.end(), std::make_pair(bowIds[i], bowVals[i]));   // ascending ids
+  for (int i = 0; i < nFv; i++) {
+    auto& v = featVec[fvNodes[i].node_id];
+    v.assign(fvIdx.begin() + fvNodes[i].start, fvIdx.begin() + fvNodes[i].start + fvNodes[i].count);
+  }
+  return ORBFE_OK;
 }
 
 // SearchByProjection(Frame& cur, const Frame& last, th, bMono)   L/src/ORBmatcher.cc:1247-1383

@@ -324,6 +324,106 @@ int main(int argc, char** argv) {
     CHECK(nb == onb && nb > on / 8 && (int)matches.size() == on);
     for (int j = 0; j < on; j++) CHECK(matches[j] == (omatchB[j] >= 0 ? kf.mps[omatchB[j]] : nullptr));
     printf("SearchByBoW ok: %d matches\n", nb);
+
+    // ---- SearchByBoW(KF, KF), SearchForTriangulation and ComputeBoW through their adapters
+    struct MockKF2 {
+      int N = 0;
+      std::vector<MockMapPoint*> mps;
+      std::map<unsigned, std::vector<unsigned>> mFeatVec;
+      cv::Mat mDescriptors;
+      std::vector<cv::KeyPoint> mvKeysUn;
+      std::vector<float> mvuRight, mvScaleFactors, mvLevelSigma2;
+      std::vector<MockMapPoint*> GetMapPointMatches() { return mps; }
+      MockMapPoint* GetMapPoint(size_t i) { return mps[i]; }
+    };
+    MockKF2 k1, k2;
+    k1.N = k2.N = on;
+    k1.mDescriptors = desc; k1.mvKeysUn = keys; k1.mps = kf.mps; k1.mFeatVec = kf.mFeatVec;
+    k2.mDescriptors = fr.mDescriptors; k2.mvKeysUn = fr.mvKeys; k2.mFeatVec = fr.mFeatVec; k2.mps.assign(on, nullptr);
+    k2.mvScaleFactors = sf;
+    k2.mvLevelSigma2.resize(sf.size());
+    for (size_t l = 0; l < sf.size(); l++) k2.mvLevelSigma2[l] = sf[l] * sf[l];
+    k1.mvuRight.assign(on, -1.f); k2.mvuRight.assign(on, -1.f);
+    for (int i = 0; i < on; i++) {
+      if (i % 4) k2.mps[i] = &mps[(i * 5) % on];
+      if (i % 2) k1.mvuRight[i] = keys[i].pt.x - 12.f;
+      if (i % 3) k2.mvuRight[i] = fr.mvKeys[i].pt.x - 12.f;
+    }
+    std::vector<MockMapPoint*> m12;
+    const int nkk = ORB_SLAM2::orbfe_host::SearchByBoWKeyFrames(&k1, &k2, m12, 0.8f, true);
+    std::vector<uint8_t> vA(on), vB(on);
+    for (int i = 0; i < on; i++) { vA[i] = k1.mps[i] && !k1.mps[i]->isBad(); vB[i] = k2.mps[i] && !k2.mps[i]->isBad(); }
+    std::vector<int32_t> omA(on, -1);
+    const int onkk = oo_search_by_bow_kf(desc.ptr(0), angA.data(), vA.data(), on, nA.data(), (int)nA.size(), iA.data(), fr.mDescriptors.ptr(0),
+                                         angB.data(), vB.data(), on, nB.data(), (int)nB.size(), iB.data(), 0.8f, 1, omA.data());
+    CHECK(nkk == onkk && nkk > on / 16);
+    for (int i = 0; i < on; i++) CHECK(m12[i] == (omA[i] >= 0 ? k2.mps[omA[i]] : nullptr));
+    const float F12[9] = {0, 0, 0, 0, 0, -0.4f, 0, 0.4f, 0.001f};
+    std::vector<std::pair<size_t, size_t>> pairs;
+    const int ntri = ORB_SLAM2::orbfe_host::SearchForTriangulation(&k1, &k2, F12, 5000.f, 200.f, pairs, false, true);
+    oo_epipolar oep;
+    memset(&oep, 0, sizeof(oep));
+    memcpy(oep.F12, F12, sizeof(F12)); oep.ex = 5000.f; oep.ey = 200.f;
+    for (int l = 0; l < 8; l++) { oep.scale_factors[l] = sf[l]; oep.level_sigma2[l] = sf[l] * sf[l]; }
+    std::vector<uint8_t> hA(on), hB(on);
+    for (int i = 0; i < on; i++) { hA[i] = k1.mps[i] != nullptr; hB[i] = k2.mps[i] != nullptr; }
+    std::vector<oo_keypoint> okB(on);
+    memcpy(okB.data(), fr.mvKeys.data(), sizeof(oo_keypoint) * on);
+    std::vector<int32_t> otri(on, -1);
+    const int ontri = oo_search_for_triangulation(okeys.data(), desc.ptr(0), k1.mvuRight.data(), hA.data(), on, nA.data(), (int)nA.size(),
+                                                  iA.data(), okB.data(), fr.mDescriptors.ptr(0), k2.mvuRight.data(), hB.data(), on, nB.data(),
+                                                  (int)nB.size(), iB.data(), &oep, 0, 1, otri.data());
+    CHECK(ntri == ontri && (int)pairs.size() == ntri);
+    size_t pi = 0;
+    for (int i = 0; i < on; i++)
+      if (otri[i] >= 0) { CHECK(pi < pairs.size() && pairs[pi].first == (size_t)i && pairs[pi].second == (size_t)otri[i]); pi++; }
+    printf("SearchByBoW(KF,KF) ok: %d matches; SearchForTriangulation ok: %d pairs\n", nkk, ntri);
+
+    // ---- Frame::ComputeBoW through the adapter: a k = 4, L = 3 tree whose node descriptors are extracted descriptors
+    {
+      const int k = 4, L = 3;
+      std::vector<int32_t> parent(1, 0);
+      std::vector<uint8_t> leaf(1, 0), vdesc(32, 0);
+      std::vector<double> weight(1, 0.0);
+      std::vector<int> level_nodes(1, 0);
+      int next_desc = 0;
+      for (int lv = 1; lv <= L; lv++) {
+        std::vector<int> cur;
+        for (int pnode : level_nodes)
+          for (int c = 0; c < k; c++) {
+            cur.push_back((int)parent.size());
+            parent.push_back(pnode);
+            leaf.push_back(lv == L);
+            vdesc.insert(vdesc.end(), desc.ptr((next_desc * 13) % on), desc.ptr((next_desc * 13) % on) + 32);
+            weight.push_back(lv == L ? 0.25 + 0.01 * (next_desc % 37) : 0.0);
+            next_desc++;
+          }
+        level_nodes = cur;
+      }
+      orbfe_vocabulary* voc = nullptr;
+      CHECK(orbfe_vocabulary_create(k, L, 0, 0, (int)parent.size(), parent.data(), leaf.data(), vdesc.data(), weight.data(), -1, &voc) == ORBFE_OK);
+      oo_vocab* ov = oo_vocab_create(k, L, 0, 0, (int)parent.size(), parent.data(), leaf.data(), vdesc.data(), weight.data());
+      std::map<unsigned, double> bow;
+      std::map<unsigned, std::vector<unsigned>> fv;
+      CHECK(ORB_SLAM2::orbfe_host::ComputeBoW(voc, desc.ptr(0), on, bow, fv, 2) == ORBFE_OK);
+      std::vector<int32_t> obi(on), ofi(on);
+      std::vector<double> obv(on);
+      std::vector<oo_featvec_node> ofn(on);
+      int onb2 = 0, onf = 0;
+      oo_vocab_transform(ov, desc.ptr(0), on, 2, obi.data(), obv.data(), &onb2, ofn.data(), ofi.data(), &onf);
+      CHECK((int)bow.size() == onb2 && (int)fv.size() == onf && onb2 > 8);
+      int q = 0;
+      for (auto& kv : bow) { CHECK((int)kv.first == obi[q] && kv.second == obv[q]); q++; }
+      q = 0;
+      for (auto& kv : fv) {
+        CHECK((int)kv.first == ofn[q].node_id && (int)kv.second.size() == ofn[q].count);
+        for (int t = 0; t < ofn[q].count; t++) CHECK((int)kv.second[t] == ofi[ofn[q].start + t]);
+        q++;
+      }
+      orbfe_vocabulary_destroy(voc);
+      oo_vocab_destroy(ov);
+      printf("ComputeBoW ok: %d words, %d nodes\n", onb2, onf);
+    }
   }
   oo_extractor_destroy(orc);
   delete ext;

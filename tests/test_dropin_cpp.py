@@ -40,4 +40,4 @@ def test_dropin_parity_on_gpu(tmp_path, geom):
     img.tofile(p)
     r = subprocess.run([EXE, p, str(w), str(h), str(nf)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "dropin ok" in r.stdout and "SearchLocalPoints ok" in r.stdout and "SearchByBoW ok" in r.stdout
+    assert "dropin ok" in r.stdout and "SearchLocalPoints ok" in r.stdout and "SearchByBoW ok" in r.stdout and "SearchForTriangulation ok" in r.stdout and "ComputeBoW ok" in r.stdout
