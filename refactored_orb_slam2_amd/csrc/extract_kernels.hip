@@ -448,6 +448,282 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
   }
 }
 
+// max over the sixteen 9-arcs of the arc minimum of d[] (16-bit signed in 32-bit containers)
+__device__ __forceinline__ int arc9_maxmin_h(const unsigned d[16]) {
+  unsigned lo2[16], lo4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) lo2[i] = mini16(d[i], d[(i + 1) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) lo4[i] = mini16(lo2[i], lo2[(i + 2) & 15]);
+  unsigned A = 0x8000u;
+#pragma unroll
+  for (int i = 0; i < 16; i++) A = maxi16(A, mini16(mini16(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]));
+  return (int)(short)(A & 0xffffu);
+}
+
+// ---- FAST, second formulation (default): one WAVE per cell, no workgroup barriers.
+//
+// The phases of the per-cell pipeline (stage, quick test, exact score, NMS, ordered emission) have very different widths; in a
+// workgroup-wide kernel every phase boundary is a barrier at which most waves idle.  Here every wave owns a run of <= 4
+// horizontally adjacent cells and walks them one at a time entirely inside its own LDS slice (~5.4 KB: 28 waves per CU): all
+// synchronisation is the in-order execution of one wave's LDS operations, a compute unit holds independent waves in different
+// phases, and the global loads of the next cell of the run are in flight while the current one is processed.
+//   stage   cell ROI (<= 66 x 66) as bytes, shifted one column when that makes the tested region start on an even column (the
+//           shift happens in registers: v_alignbyte over one extra aligned dword; LDS stores stay 16-byte aligned)
+//   A1      SWAR quick test, two pixels per lane in 16-bit fields, add / sub / logic only (see below); the
+//           16-bit pairs are cut out of aligned dwords with v_perm_b32 (selectors per lane: the pair starts at byte 0 or 2),
+//           ten dwords per pair in five ds_read2_b32.  Lanes = (row in a band of RI rows, pixel pair): rows are 64 bytes apart,
+//           so the lanes of a 32-lane LDS group hit distinct banks.  Survivors -> 256-entry list with their polarity, scored (A2)
+//           and emptied whenever it is more than half full
+//   A2      exact cornerScore of one polarity -> score plane (tested region + 1-pixel zero frame) and a bitmap of scored pixels
+//   B + C   each lane takes the bitmap words w = lane, lane + 64: strict 3x3 NMS inside the cell, the two-threshold rule and the
+//           row-major emission run from registers (two packed wave scans give the output offsets)
+#define FC_LIST_CAP 256
+#ifndef FC_WAVES_PER_EU
+#define FC_WAVES_PER_EU 6
+#endif
+// LDS bytes of one wave's slice: byte tile, score plane, bitmap of scored pixels (nbw words), survivor list
+__host__ __device__ inline int fc_wave_lds(int rows_max, int pb, int sc_bytes, int nbw) {
+  return rows_max * pb + sc_bytes + nbw * 4 + FC_LIST_CAP * 2;
+}
+template <int PB, int NLD>   // PB: bytes per staged row (64 or 96); NLD: load rounds of 64 lanes x 16 bytes per cell
+__global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
+                                                          const FastGroup* __restrict__ runs, int n_runs, int total_cells,
+                                                          int rows_max, int sc_bytes, int nbw, int32_t* __restrict__ cell_cnt,
+                                                          uint32_t* __restrict__ slots, unsigned long long slots_per_image,
+                                                          int ini_th, int min_th, int xcd_run_shift) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
+  const int lane = threadIdx.x & (WAVE - 1), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* tile = fc_smem + wid * fc_wave_lds(rows_max, PB, sc_bytes, nbw);
+  uint8_t* sc = tile + rows_max * PB;
+  uint32_t* scb = reinterpret_cast<uint32_t*>(sc + sc_bytes);   // bitmap of scored pixels, row-major over the tested region
+  uint16_t* list = reinterpret_cast<uint16_t*>(scb + nbw);      // quick-test survivors (tile index | polarity)
+  const int img = blockIdx.y;
+  const int nblk = (n_runs + 3) >> 2;
+  const int q = blockIdx.x >> 3;
+  const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
+  const int bid = (xcd_run_shift < 0 || (int)blockIdx.x >= (nblk / unit) * unit)
+                      ? (int)blockIdx.x
+                      : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
+                            (q & ((1 << xcd_run_shift) - 1));
+  const int rid = bid * 4 + wid;
+  if (rid >= n_runs) return;   // no barriers below
+  const FastGroup g = runs[rid];
+  const int level = g.level;
+  const int pitch = pyr.pitch[level];
+  const uint8_t* plane = pyr.base[level] + (size_t)img * pyr.img_stride[level];
+  const uint32_t C = (uint32_t)(0x8000 - min_th - 1) * 0x00010001u;
+  const uint32_t tile_a = (uint32_t)(uintptr_t)tile;
+
+  uint4 pv[NLD];
+  uint32_t pe[NLD];
+  auto load_cell = [&](const CellDesc& cd) {
+    const int ndq = ((cd.x0 & 15) + (((cd.x0 & 15) + 3) & 1) + cd.cols + 15) >> 4;   // chunks of the SHIFTED row
+    const int items = cd.rows * ndq;
+    const float inv = 1.0f / (float)ndq;
+    const uint8_t* src = plane + (size_t)cd.y0 * pitch + (cd.x0 & ~15);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int i = lane + WAVE * k;
+      if (i < items) {
+        const int r = (int)((i + 0.5f) * inv), c = i - r * ndq;
+        const uint8_t* p = src + (size_t)r * pitch + 16 * c;
+        pv[k] = *reinterpret_cast<const uint4*>(p);
+        pe[k] = *reinterpret_cast<const uint32_t*>(p - 4);   // the dword in front (x0 >= 16: never before the row)
+      }
+    }
+  };
+
+#ifndef FC_PREFETCH
+#define FC_PREFETCH 1
+#endif
+  CellDesc cd = cells[g.first_cell];
+  if (FC_PREFETCH) load_cell(cd);
+  for (int k = 0; k < g.n_cells; k++) {
+    if (!FC_PREFETCH) {
+      cd = cells[g.first_cell + k];
+      load_cell(cd);
+    }
+    const int cols = cd.cols, rows = cd.rows;
+    const int xo = cd.x0 & 15, sh = (xo + 3) & 1, xs = xo + sh;
+    const int ndq = (xs + cols + 15) >> 4;
+    const int th = rows - 6, tw = cols - 6;
+    const int c_lo = xs + 3, c_hi = xs + cols - 3;
+    const int SCP = tw + 2;
+    const float inv_tw = 1.0f / (float)(tw > 0 ? tw : 1);
+    // ---- stage (shifted by `sh` columns), clear the score plane and the bitmaps
+    {
+      const int items = rows * ndq;
+      const float inv = 1.0f / (float)ndq;
+#pragma unroll
+      for (int kk = 0; kk < NLD; kk++) {
+        const int i = lane + WAVE * kk;
+        if (i < items) {
+          const int r = (int)((i + 0.5f) * inv), c = i - r * ndq;
+          uint4 d = pv[kk];
+          if (sh) {   // pixel j of the chunk moves to column j + 1: the first byte comes from the dword in front
+            d.w = __builtin_amdgcn_alignbyte(d.w, d.z, 3);
+            d.z = __builtin_amdgcn_alignbyte(d.z, d.y, 3);
+            d.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
+            d.x = __builtin_amdgcn_alignbyte(d.x, pe[kk], 3);
+          }
+          *reinterpret_cast<uint4*>(tile + r * PB + 16 * c) = d;
+        }
+      }
+      const int nsc = ((th + 2) * SCP + 15) >> 4;
+      for (int i = lane; i < nsc; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
+      for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
+    }
+    // the next cell of the run: its loads fly while this one is processed
+    CellDesc cdn = cd;
+    if (FC_PREFETCH && k + 1 < g.n_cells) {
+      cdn = cells[g.first_cell + k + 1];
+      load_cell(cdn);
+    }
+
+    // ---- A2 (called whenever the list is more than half full, and at the end): exact score of list[0 .. n), the polarity
+    //      (or, about once in 10^4, the two polarities) the quick test left possible
+    auto score_list = [&](int n) {
+      for (int i = lane; i < n; i += WAVE) {
+        const uint32_t en = list[i];
+        const int e = (int)(en & 0x3fffu);
+        const int y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
+        const int x = e - y * PB;
+        if (x >= c_hi) continue;   // the pair straddling the right edge of the tested region
+        const uint8_t* c = tile + e;
+        const int v = c[0];
+        unsigned d[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) d[kk] = (unsigned)(v - (int)c[RDY[kk] * PB + RDX[kk]]);
+        int s = 0;
+        if (en & 0x8000u) s = arc9_maxmin_h(d);   // dark: min over the arc of (v - q)
+        if (en & 0x4000u) {                       // bright: min over the arc of (q - v)
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) d[kk] = 0u - d[kk];
+          s = max(s, arc9_maxmin_h(d));
+        }
+        if (s - 1 >= min_th) {
+          const int ty = y - 3, tx = x - c_lo;
+          sc[(ty + 1) * SCP + tx + 1] = (uint8_t)(s - 1);
+          const int p = ty * tw + tx;
+          atomicOr(&scb[p >> 5], 1u << (p & 31));
+        }
+      }
+    };
+
+    // ---- A1
+    if (th > 0 && tw > 0) {
+      const int ppr = (tw + 1) >> 1;                 // <= 30
+      const int RI = WAVE / ppr;                     // rows per iteration, >= 2
+      const int rl = (int)((lane + 0.5f) * (1.0f / (float)ppr)), pl = lane - rl * ppr;
+      const bool lane_ok = rl < RI;
+      const int n_it = (th + RI - 1) / RI;
+      const int x = c_lo + 2 * pl;                   // even: the pair (x, x + 1) starts at byte 0 or 2 of its dword
+      const bool odd2 = (x & 2) != 0;
+      const uint32_t selV = odd2 ? 0x0c030c02u : 0x0c010c00u;    // (x, x+1) and (x, x+1) of rows +-3
+      const uint32_t selX = odd2 ? 0x0c010c00u : 0x0c030c02u;    // (x+-2, x+-2+1)
+      const uint32_t selM = odd2 ? 0x0c040c03u : 0x0c020c01u;    // (x-3, x-2) out of dwords {D(x)-1, D(x)}
+      const uint32_t selP = odd2 ? 0x0c020c01u : 0x0c040c03u;    // (x+3, x+4) out of dwords {D(x+2), D(x+2)+1}
+      int e = (3 + rl) * PB + x;                     // byte index of the pair's first pixel
+      // addresses of row (y - 3): the dword of x (minus one dword: the centre row reads {D-1, D}), of x + 2, of x - 2
+      uint32_t a0 = tile_a + rl * PB + ((x >> 2) << 2) - 4;
+      uint32_t ap = tile_a + rl * PB + (((x + 2) >> 2) << 2);
+      uint32_t am = tile_a + rl * PB + (((x - 2) >> 2) << 2);
+      int wcnt = 0;
+      for (int it = 0; it < n_it; it++, e += RI * PB, a0 += RI * PB, ap += RI * PB, am += RI * PB) {
+        const bool act = lane_ok && (it * RI + rl) < th;   // inactive lanes read in-range garbage: rows < rows_max + RI
+        unsigned long long p08, pc, pp, p62, p1014;
+        asm volatile(
+            "ds_read2_b32 %0, %5 offset0:1 offset1:%8\n\t"
+            "ds_read2_b32 %1, %5 offset0:%9 offset1:%10\n\t"
+            "ds_read2_b32 %2, %6 offset0:%11 offset1:%12\n\t"
+            "ds_read2_b32 %3, %6 offset0:%13 offset1:%14\n\t"
+            "ds_read2_b32 %4, %7 offset0:%13 offset1:%14\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(p08), "=&v"(pc), "=&v"(pp), "=&v"(p62), "=&v"(p1014)
+            : "v"(a0), "v"(ap), "v"(am), "n"(6 * PB / 4 + 1), "n"(3 * PB / 4), "n"(3 * PB / 4 + 1), "n"(3 * PB / 4),
+              "n"(3 * PB / 4 + 1), "n"(PB / 4), "n"(5 * PB / 4)
+            : "memory");
+        const uint32_t D0 = (uint32_t)(pc >> 32), Dm = (uint32_t)pc;
+        const uint32_t V = __builtin_amdgcn_perm(0u, D0, selV);
+        const uint32_t Q8 = __builtin_amdgcn_perm(0u, (uint32_t)p08, selV), Q0 = __builtin_amdgcn_perm(0u, (uint32_t)(p08 >> 32), selV);
+        const uint32_t Q12 = __builtin_amdgcn_perm(D0, Dm, selM);
+        const uint32_t Q4 = __builtin_amdgcn_perm((uint32_t)(pp >> 32), (uint32_t)pp, selP);
+        const uint32_t Q6 = __builtin_amdgcn_perm(0u, (uint32_t)p62, selX), Q2 = __builtin_amdgcn_perm(0u, (uint32_t)(p62 >> 32), selX);
+        const uint32_t Q10 = __builtin_amdgcn_perm(0u, (uint32_t)p1014, selX), Q14 = __builtin_amdgcn_perm(0u, (uint32_t)(p1014 >> 32), selX);
+        const uint32_t AD = V + C, AB = C - V;
+        const uint32_t dark = ((AD - Q0) | (AD - Q8)) & ((AD - Q2) | (AD - Q10)) & ((AD - Q4) | (AD - Q12)) & ((AD - Q6) | (AD - Q14));
+        const uint32_t brt = ((Q0 + AB) | (Q8 + AB)) & ((Q2 + AB) | (Q10 + AB)) & ((Q4 + AB) | (Q12 + AB)) & ((Q6 + AB) | (Q14 + AB));
+        const uint32_t G = act ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
+        const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
+        const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
+        const int n0 = __popcll(m0);
+        const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
+        const int i1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)(wcnt + n0)));
+        if (has0) list[i0] = (uint16_t)((G & 0xC000u) | (uint32_t)e);
+        if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (uint32_t)(e + 1));
+        wcnt += n0 + __popcll(m1);
+        if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
+          score_list(wcnt);
+          wcnt = 0;
+        }
+      }
+      score_list(wcnt);
+    }
+
+    // ---- B + C: NMS, two-threshold rule, row-major emission.  Lane l owns bitmap words l and l + 64.
+    {
+      uint32_t keep[2], hi[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int w = lane + WAVE * h;
+        uint32_t m = w < nbw ? scb[w] : 0u;
+        keep[h] = 0; hi[h] = 0;
+        while (m) {
+          const int b = __ffs((int)m) - 1;
+          m &= m - 1;
+          const int p = w * 32 + b;
+          const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
+          const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
+          const int v = s[0];
+          const bool kp = v > s[-SCP - 1] && v > s[-SCP] && v > s[-SCP + 1] && v > s[-1] && v > s[1] && v > s[SCP - 1] && v > s[SCP] &&
+                          v > s[SCP + 1];
+          if (kp) {
+            keep[h] |= 1u << b;
+            if (v >= ini_th) hi[h] |= 1u << b;
+          }
+        }
+      }
+      const int pk0 = (__popc(hi[0]) << 16) | __popc(keep[0]), pk1 = (__popc(hi[1]) << 16) | __popc(keep[1]);
+      const int in0 = wave_incl_scan(pk0), in1 = wave_incl_scan(pk1);
+      const int tot0 = __builtin_amdgcn_readlane(in0, WAVE - 1), tot1 = __builtin_amdgcn_readlane(in1, WAVE - 1);
+      const int total = tot0 + tot1;
+      const bool use_hi = (total >> 16) != 0;
+      const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
+      uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int ex = (h ? tot0 + in1 - pk1 : in0 - pk0);
+        int off = use_hi ? (ex >> 16) : (ex & 0xffff);
+        uint32_t mask = use_hi ? hi[h] : keep[h];
+        const int w = lane + WAVE * h;
+        while (mask) {
+          const int b = __ffs((int)mask) - 1;
+          mask &= mask - 1;
+          const int p = w * 32 + b;
+          const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
+          const uint32_t sv = sc[(ty + 1) * SCP + tx + 1];
+          const uint32_t rx = (uint32_t)(tx + 3 + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(ty + 3 + cd.y0 - ORBFE_EDGE);
+          if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
+          off++;
+        }
+      }
+      if (lane == 0) cell_cnt[(size_t)img * total_cells + g.first_cell + k] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
+    }
+    cd = cdn;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ octree
 // DistributeOctTree as an array algorithm.  The leaves of the quadtree are kept in an array in std::list
 // order (index 0 = list head); because every insertion in the reference is a push_front and the initial
@@ -1134,24 +1410,48 @@ void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* d
 }
 
 void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
-                              int total_cells, int tile_rows, int clist_cap, int32_t* cell_cnt, uint32_t* slots,
-                              unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s) {
+                              int total_cells, int tile_rows, int clist_cap, int cell_rows, int cell_span, int sc_max,
+                              int bits_max, int32_t* cell_cnt, uint32_t* slots, unsigned long long slots_per_image,
+                              int ini_th, int min_th, int n_images, hipStream_t s) {
   if (n_groups == 0) return;
-  static int run_shift = -2;
+  static int run_shift = -2, variant = -1;
   if (run_shift == -2) {
     const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order
     run_shift = ev ? atoi(ev) : 2;                   // runs of 4 groups (~16 cells) per XCD
+    const char* vv = getenv("ORBFE_FAST_VARIANT");   // A/B knob: 1 = workgroup per run of cells (byte tile, min/max quick test),
+    variant = vv ? atoi(vv) : 2;                     //          2 = wave per cell (default)
   }
-  const size_t lds = (size_t)2 * tile_rows * ORBFE_FG_PITCH + (size_t)ORBFE_FG_MAX * 256 * 4 + (size_t)clist_cap * 2;
-  static size_t lds_allowed = 48 * 1024;
-  if (lds > lds_allowed) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    lds_allowed = lds;
+  if (variant == 1) {
+    dim3 block(FG_THREADS), grid(n_groups, n_images);
+    const size_t lds = (size_t)2 * tile_rows * ORBFE_FG_PITCH + (size_t)ORBFE_FG_MAX * 256 * 4 + (size_t)clist_cap * 2;
+    static size_t lds_allowed = 48 * 1024;
+    if (lds > lds_allowed) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(fast_groups_kernel, grid, block, lds, s, pyr, cells, groups, n_groups, total_cells, tile_rows,
+                       clist_cap, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift);
+    return;
   }
-  dim3 block(FG_THREADS), grid(n_groups, n_images);
-  hipLaunchKernelGGL(fast_groups_kernel, grid, block, lds, s, pyr, cells, groups, n_groups, total_cells, tile_rows,
-                     clist_cap, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift);
+  // wave per run of cells: per-wave LDS slice = byte tile + score plane + bitmap + list
+  const int pb = cell_span <= 64 ? 64 : 96;
+  const int sc_bytes = (sc_max + 15) & ~15;
+  const int nbw = bits_max <= 64 * 32 ? 64 : 128;   // bitmap words (lane l owns words l and l + 64)
+  const size_t lds = (size_t)4 * fc_wave_lds(cell_rows, pb, sc_bytes, nbw);
+  const bool small = cell_rows * ((cell_span + 15) / 16) <= 3 * WAVE;   // a cell loads in three rounds of 64 lanes
+  dim3 grid4((n_groups + 3) / 4, n_images);
+#define FC_LAUNCH(PBV, NLDV)                                                                                                   \
+  hipLaunchKernelGGL((fast_cells_kernel<PBV, NLDV>), grid4, dim3(256), lds, s, pyr, cells, groups, n_groups, total_cells,       \
+                     cell_rows, sc_bytes, nbw, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift)
+  if (lds > 48 * 1024) {   // never for the configured datasets (22 KB at KITTI); the largest cell (66 x 66) needs 46 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<96, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<64, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (pb == 64 && small) FC_LAUNCH(64, 3);
+  else if (pb == 64) FC_LAUNCH(64, 7);
+  else FC_LAUNCH(96, 7);
+#undef FC_LAUNCH
 }
 
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s) {

@@ -84,6 +84,7 @@ struct orbfe_extractor {
   std::vector<CellDesc> cells;
   std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
   int fg_tile_rows = 0, fg_clist_cap = 0;
+  int fc_rows = 0, fc_span = 0, fc_sc = 0, fc_bits = 0;   // wave-per-cell FAST: largest cell ROI rows, (x0 & 15) + 1 + cols, score plane bytes
   std::vector<BlurTile> tiles;
   OctLevel oct[ORBFE_MAX_LEVELS]{};
   int total_cells = 0;
@@ -205,6 +206,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   e->groups.clear();
   e->fg_tile_rows = 0;
   e->fg_clist_cap = 0;
+  e->fc_rows = e->fc_span = e->fc_sc = e->fc_bits = 0;
   e->tiles.clear();
   static int fg_max = -1;
   if (fg_max < 0) {
@@ -256,6 +258,10 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
           const int tw = std::max(c.cols - 6, 0), th = std::max(c.rows - 6, 0);
           const int cap = std::max(((tw + 1) / 2) * ((th + 1) / 2), 1);  // NMS survivors are never 8-adjacent
           c.slot_cap = (int16_t)cap;
+          e->fc_rows = std::max(e->fc_rows, (int)c.rows);
+          e->fc_span = std::max(e->fc_span, (c.x0 & 15) + 1 + (int)c.cols);
+          e->fc_sc = std::max(e->fc_sc, (th + 2) * (tw + 2));
+          e->fc_bits = std::max(e->fc_bits, tw * th);
           c.slot_off = (uint32_t)slot_off;
           slot_off += cap;
           level_slots += cap;
@@ -475,7 +481,8 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
     orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)e->d_groups.p, (int)e->groups.size(),
-                             e->total_cells, e->fg_tile_rows, e->fg_clist_cap, (int32_t*)e->d_cell_cnt.p,
+                             e->total_cells, e->fg_tile_rows, e->fg_clist_cap, e->fc_rows, e->fc_span, e->fc_sc, e->fc_bits,
+                             (int32_t*)e->d_cell_cnt.p,
                              (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast,
                              n_images, s);
   }

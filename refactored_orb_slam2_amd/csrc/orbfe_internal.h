@@ -104,8 +104,9 @@ struct BlurTile {
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s);
 void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
-                              int total_cells, int tile_rows, int clist_cap, int32_t* cell_cnt, uint32_t* slots,
-                              unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
+                              int total_cells, int tile_rows, int clist_cap, int cell_rows, int cell_span,
+                              int sc_max, int bits_max, int32_t* cell_cnt, uint32_t* slots, unsigned long long slots_per_image,
+                              int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
 void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
                        hipStream_t s);
