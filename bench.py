@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on MI355X: stereo frames/s of the ORB front end (extract + match).
+"""bench.py -- BASELINE.json's metric on MI355X: frames/s of the ORB front end (extract + match).
 
-One "step" = one batch of F synthetic KITTI-geometry stereo frames (1241x376, 2000 features, 8 levels)
-resident in HBM, pushed through the whole hot path on one GPU:
-    ORBextractor left + right  ->  Frame::ComputeStereoMatches  ->  Frame::UnprojectStereo of every stereo point
-    ->  its projection into the next frame (ORBmatcher.cc:1270-1308)  ->  SearchByProjection(cur, last)
-N > 1 shards independent frames over ranks (one process per GPU, weak scaling: F frames per rank per step)
-and gathers the per-frame keypoint/descriptor records with one RCCL all_gather per step -- the only
-exchange the path has (BASELINE.json north_star).
+One "step" = one batch of F synthetic frames resident in HBM, pushed through the whole hot path on one GPU.  Workloads
+(`--config`, the headline is the default):
+  kitti_stereo  1241x376, 2000 features, 8 levels (BASELINE.json's metric):
+                ORBextractor left + right -> Frame::ComputeStereoMatches -> Frame::UnprojectStereo of every stereo point
+                -> its projection into the next frame (ORBmatcher.cc:1270-1308) -> SearchByProjection(cur, last)
+  euroc_stereo  752x480, 2 x 1200 features: the same pipeline with the EuRoC camera
+  kitti_mono    1241x376, 1000 features, one extractor: extraction + SearchByProjection(cur, last, th = 15) against the
+                previous frame's keypoints un-projected at a constant depth
+  tum_bow       640x480, 1000 features: extraction + the Hamming brute force of SearchByBoW between consecutive frames
+                (descriptors grouped by a synthetic 100-bucket node id standing in for the missing vocabulary)
+`--gpus N` shards independent frames over N ranks (one process per GPU, weak scaling: F frames per rank per step) and
+gathers the per-frame keypoint/descriptor records with one RCCL all_gather per step -- the only exchange the path has.
+Started without a launcher (`WORLD_SIZE` unset) it spawns the N ranks itself before touching the GPU; under
+`python -m torch.distributed.run` it uses the ranks it is given.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP
-events on the launching stream) and, at N=1, `cpu_baseline` (the CPU oracle on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP events on the
+launching stream), at N=1 `cpu_baseline` (the CPU oracle on a bounded sample) and `e2e_frames_per_s` (host images in,
+host keypoints / descriptors / matches out, double-buffered over PCIe) -- `value` itself is HBM-resident.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,65 +35,170 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, NFEAT, NLEVELS = 1241, 376, 2000, 8
-MBF, FX = 386.1448, 718.856           # Source/Examples/Stereo/KITTI00-02.yaml: Camera.bf, Camera.fx
-TH_STEREO = 7.0                       # Tracking::TrackWithMotionModel: th = 7 for stereo (Tracking.cc:793-798)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
-
-
-def level_pixels(ex):
-    return [ex.level_size(l, W, H) for l in range(NLEVELS)]
-
-
-FY, CX, CY = 718.856, 607.1928, 185.2157   # KITTI00-02.yaml
+NLEVELS = 8
+# camera rows: Source/Examples/Stereo/KITTI00-02.yaml, EuRoC.yaml; Monocular/KITTI00-02.yaml; RGB-D/TUM1.yaml
+CONFIGS = {
+    "kitti_stereo": dict(w=1241, h=376, nfeat=2000, stereo=True, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157,
+                         bf=386.1448, th=7.0, match="projection",
+                         label="kitti_stereo_1241x376_2000feat_8lvl: 2x ORBextractor + ComputeStereoMatches + "
+                               "SearchByProjection(cur,last)"),
+    "euroc_stereo": dict(w=752, h=480, nfeat=1200, stereo=True, fx=435.2046959714599, fy=435.2046959714599,
+                         cx=367.4517211914062, cy=252.2008514404297, bf=47.90639384423901, th=7.0, match="projection",
+                         label="euroc_stereo_752x480_2x1200feat_8lvl: 2x ORBextractor + ComputeStereoMatches + "
+                               "SearchByProjection(cur,last)"),
+    "kitti_mono": dict(w=1241, h=376, nfeat=1000, stereo=False, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157,
+                       bf=0.0, th=15.0, match="projection",
+                       label="kitti_mono_1241x376_1000feat_8lvl: ORBextractor + SearchByProjection(cur,last,th=15)"),
+    "tum_bow": dict(w=640, h=480, nfeat=1000, stereo=False, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989,
+                    bf=40.0, th=15.0, match="bow",
+                    label="tum_640x480_1000feat_8lvl: ORBextractor + SearchByBoW Hamming brute force (100 node groups) "
+                          "between consecutive frames"),
+}
+W, H, NFEAT = CONFIGS["kitti_stereo"]["w"], CONFIGS["kitti_stereo"]["h"], CONFIGS["kitti_stereo"]["nfeat"]   # the headline workload
+MBF, FX, TH_STEREO = CONFIGS["kitti_stereo"]["bf"], CONFIGS["kitti_stereo"]["fx"], CONFIGS["kitti_stereo"]["th"]   # th = 7: Tracking.cc:793-798
 SHIFT_X = -2.0                             # synth.sequence: the image content moves 2 px per frame
+MONO_DEPTH = 10.0                          # kitti_mono: depth at which the previous frame's keypoints are un-projected
 
 
-def camera_records(n, sf):
+def camera_records(n, sf, cfg=None):
     """Synthetic camera for the motion-model search: identity pose, and a principal point that moves with the image
-    content (SHIFT_X px per frame), so that re-projecting the last frame's stereo points into the current frame
+    content (SHIFT_X px per frame), so that re-projecting the last frame's points into the current frame
     (UnprojectStereo -> Rcw*x3Dw+tcw -> pinhole) lands on the known image motion for every depth."""
     from refactored_orb_slam2_amd._lib import TRACK_POSE_DTYPE, UNPROJECT_CAM_DTYPE
+    cfg = cfg or CONFIGS["kitti_stereo"]
     cams = np.zeros(n, UNPROJECT_CAM_DTYPE); poses = np.zeros(n, TRACK_POSE_DTYPE)
     eye = np.eye(3, dtype=np.float32).reshape(9)
-    cams["Rwc"] = eye; cams["cx"] = CX; cams["cy"] = CY
-    cams["invfx"] = np.float32(1) / np.float32(FX); cams["invfy"] = np.float32(1) / np.float32(FY)
-    poses["Rcw"] = eye; poses["fx"] = FX; poses["fy"] = FY; poses["cx"] = np.float32(CX) + np.float32(SHIFT_X); poses["cy"] = CY
-    poses["mbf"] = MBF; poses["max_x"] = W; poses["max_y"] = H; poses["th"] = TH_STEREO
-    poses["scale_factors"] = np.asarray(sf, np.float32)[:8]
+    cams["Rwc"] = eye; cams["cx"] = cfg["cx"]; cams["cy"] = cfg["cy"]
+    cams["invfx"] = np.float32(1) / np.float32(cfg["fx"]); cams["invfy"] = np.float32(1) / np.float32(cfg["fy"])
+    poses["Rcw"] = eye; poses["fx"] = cfg["fx"]; poses["fy"] = cfg["fy"]
+    poses["cx"] = np.float32(cfg["cx"]) + np.float32(SHIFT_X); poses["cy"] = cfg["cy"]
+    poses["mbf"] = cfg["bf"]; poses["max_x"] = cfg["w"]; poses["max_y"] = cfg["h"]; poses["th"] = cfg["th"]
+    poses["scale_factors"][:, :len(sf)] = np.asarray(sf, np.float32)
     return cams, poses
 
 
-def cpu_baseline(sample_frames: int):
-    """The CPU oracle (scalar C restatement of the reference path, 1 thread) on a bounded sample."""
+def node_ids(desc):
+    """Stand-in for the DBoW2 node id of a descriptor (the vocabulary file is missing from the reference checkout):
+    bucket = (desc[0] + 256 * desc[1]) % 100.  Works on numpy arrays and torch tensors alike."""
+    return (desc[..., 0].astype("int32") + 256 * desc[..., 1].astype("int32")) % 100 if isinstance(desc, np.ndarray) \
+        else (desc[..., 0].to(dtype=__import__("torch").int32) + 256 * desc[..., 1].to(dtype=__import__("torch").int32)) % 100
+
+
+def _cpu_frames(cfg, frames, seq):
+    """One worker's share of the CPU baseline: the whole per-frame path of `cfg` on the oracle.  Returns seconds."""
     from refactored_orb_slam2_amd import synth
     from tests import oracle_lib as ol
-    pairs = synth.sequence(W, H, sample_frames, seq=0, stereo=True)
-    oL, oR = ol.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7), ol.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7)
+    W, H, NF = cfg["w"], cfg["h"], cfg["nfeat"]
+    data = synth.sequence(W, H, frames, seq=seq, stereo=cfg["stereo"])
+    oL = ol.OracleExtractor(NF, 1.2, NLEVELS, 20, 7)
+    oR = ol.OracleExtractor(NF, 1.2, NLEVELS, 20, 7) if cfg["stereo"] else None
     sf, isf = oL.scale_factors, oL.inv_scale_factors
-    mb = MBF / FX
-    cams, poses = camera_records(1, sf)
+    cams, poses = camera_records(1, sf, cfg)
     prev = None
+    pool = None
+    if cfg["stereo"]:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(1)   # right extractor on a second thread, as Frame::Frame does (Frame.cc:87-90)
     t0 = time.perf_counter()
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(2)   # left and right extractor on two threads, as Frame::Frame does (Frame.cc:87-90)
-    for (L, R) in pairs:
-        fut = pool.submit(oR, R)   # ctypes releases the GIL inside the C oracle
-        kL, dL = oL(L)
-        kR, dR = fut.result()
-        planesL = [oL.level_pixels(l) for l in range(NLEVELS)]
-        planesR = [oR.level_pixels(l) for l in range(NLEVELS)]
-        _, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, MBF, mb)
-        if prev is not None:
-            q = ol.track_queries(poses[:1], prev)     # projection of the last frame's map points (ORBmatcher.cc:1270-1308)
-            ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(q, True)
-        prev = ol.unproject_stereo(cams[:1], kL, dL, depth)   # Frame::UnprojectStereo for every stereo point
+    for item in data:
+        if cfg["stereo"]:
+            L, R = item
+            fut = pool.submit(oR, R)   # ctypes releases the GIL inside the C oracle
+            kL, dL = oL(L)
+            kR, dR = fut.result()
+            planesL = [oL.level_pixels(l) for l in range(NLEVELS)]
+            planesR = [oR.level_pixels(l) for l in range(NLEVELS)]
+            _, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, planesL, planesR, sf, isf, cfg["bf"], cfg["bf"] / cfg["fx"])
+        else:
+            kL, dL = oL(item)
+            ur, depth = None, np.full(len(kL), MONO_DEPTH, np.float32)
+        if cfg["match"] == "projection":
+            if prev is not None:
+                q = ol.track_queries(poses[:1], prev)     # projection of the last frame's map points (ORBmatcher.cc:1270-1308)
+                ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(q, True)
+            prev = ol.unproject_stereo(cams[:1], kL, dL, depth)   # Frame::UnprojectStereo for every point with depth
+        else:
+            if prev is not None:
+                ol.hamming_bf(prev[1], dL, node_ids(prev[1]), node_ids(dL))
+            prev = (kL, dL)
     dt = time.perf_counter() - t0
-    pool.shutdown()
-    return {"value": round(sample_frames / dt, 3), "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": f"{sample_frames} synthetic KITTI-geometry stereo frames (left || right extraction on two threads as in "
-                      f"Frame.cc:87-90, then stereo match + UnprojectStereo + SearchByProjection vs previous frame on one), "
-                      f"oracle/orb_oracle.c -O2 scalar, {dt:.1f} s"}
+    if pool:
+        pool.shutdown()
+    return dt
+
+
+def _cpu_worker(args):
+    name, frames, seq = args
+    return _cpu_frames(CONFIGS[name], frames, seq)
+
+
+def cpu_baseline(name: str, sample_frames: int):
+    """The CPU oracle (scalar C restatement of the reference path) on a bounded sample, with the reference's own threading
+    (two extractor threads per stereo frame), plus a frame-parallel run on all host cores for context."""
+    import multiprocessing as mp
+    import platform
+    cfg = CONFIGS[name]
+    dt = _cpu_frames(cfg, sample_frames, 0)
+    threads = 2 if cfg["stereo"] else 1
+    nproc = os.cpu_count() or 1
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    flags = ""
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CFLAGS"):
+                flags = line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    out = {"value": round(sample_frames / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{sample_frames} synthetic frames of {cfg['label'].split(':')[0]} through oracle/orb_oracle.c "
+                     f"({'left || right extraction on two threads as in Frame.cc:87-90, the rest on one' if cfg['stereo'] else 'one thread'}), {dt:.1f} s",
+           "nproc": nproc, "cpu_model": model or platform.processor(), "compiler": "gcc " + flags,
+           "note": "scalar restatement; OpenCV's SIMD FAST / resize / GaussianBlur would make the real reference faster"}
+    # all cores, frame-parallel: every worker process runs whole frames (for stereo with its two extractor threads)
+    workers = max(1, nproc // threads)
+    per = max(2, min(sample_frames, 24))
+    try:
+        ctx = mp.get_context("fork")
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            pool.map(_cpu_worker, [(name, per, 100 + i) for i in range(workers)])
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(workers * per / wall, 3), "unit": "frames/s", "cores": workers * threads,
+                            "sample": f"{workers} worker processes x {per} frames, frame-parallel, {wall:.1f} s wall (incl. input synthesis)"}
+    except Exception as exc:   # the headline row above stands on its own
+        out["all_cores"] = {"error": str(exc)}
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """Start n ranks of this script (one process per GPU) before anything touched the GPU in this process."""
+    import torch
+    have = torch.cuda.device_count()   # does not initialise the GPU on this image
+    share = os.environ.get("ORBFE_BENCH_SHARE_DEVICE") == "1"
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} but only {have} device(s) visible (ORBFE_BENCH_SHARE_DEVICE=1 rehearses the ranks on "
+              f"fewer devices)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -92,13 +207,19 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["ORBFE_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: ~1 s of timed region)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="stereo frames per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=240, help="stereo frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="kitti_stereo")
+    ap.add_argument("--cpu-sample", type=int, default=160, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--e2e-steps", type=int, default=12, help="steps of the PCIe-inclusive measurement (0 = skip)")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
                     help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))   # the parent never initialises the GPU; children report through their exit codes
 
     import torch
     import torch.distributed as dist
@@ -106,15 +227,18 @@ def main():
     from refactored_orb_slam2_amd.matcher import Matcher, track_queries_batch, unproject_stereo_batch
     from refactored_orb_slam2_amd.sharding import AsyncGather
 
+    cfg = CONFIGS[args.config]
+    W, H, NFEAT, STEREO = cfg["w"], cfg["h"], cfg["nfeat"], cfg["stereo"]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the number of ranks")
     # rehearsal switches for boxes with fewer GPUs than ranks (not used by the driver): ORBFE_BENCH_SHARE_DEVICE=1 maps
-    # every rank to the visible devices round-robin, ORBFE_BENCH_BACKEND=gloo replaces RCCL for the gather
-    backend = os.environ.get("ORBFE_BENCH_BACKEND", "nccl")
-    if os.environ.get("ORBFE_BENCH_SHARE_DEVICE") == "1":
+    # every rank to the visible devices round-robin (the gather then runs over gloo through host memory)
+    share = os.environ.get("ORBFE_BENCH_SHARE_DEVICE") == "1" and torch.cuda.device_count() < world
+    backend = os.environ.get("ORBFE_BENCH_BACKEND", "gloo" if share else "nccl")   # RCCL refuses two ranks on one device
+    if share:
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -126,12 +250,15 @@ def main():
             dist.init_process_group(backend)
 
     F = args.frames
-    # ---- synthetic input, resident in HBM before the timed region (each rank its own sequence)
-    pairs = synth.sequence(W, H, F, seq=rank, stereo=True)
-    dL = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
-    dR = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    # ---- synthetic input (each rank its own sequence), resident in HBM before the timed region; the pinned host copy
+    #      feeds the PCIe-inclusive measurement
+    data = synth.sequence(W, H, F, seq=rank, stereo=STEREO)
+    hL = torch.from_numpy(np.stack([p[0] for p in data] if STEREO else data)).pin_memory()
+    hR = torch.from_numpy(np.stack([p[1] for p in data])).pin_memory() if STEREO else None
 
-    exL, exR = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local), ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
+    exL = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
+    exR = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if STEREO else None
+    extractors = [e for e in (exL, exR) if e is not None]
     mt = Matcher(local)
     import atexit
 
@@ -140,7 +267,7 @@ def main():
             torch.cuda.synchronize()
         except Exception:
             pass
-        for hnd in (exL, exR, mt):
+        for hnd in extractors + [mt]:
             try:
                 hnd.close()
             except Exception:
@@ -148,52 +275,66 @@ def main():
 
     atexit.register(_close_handles)
     cap = exL.max_keypoints(W, H)
-    mk = lambda: (torch.zeros((F, cap, 28), dtype=torch.uint8, device=dev),
-                  torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev), torch.zeros(F, dtype=torch.int32, device=dev))
-    kl, dl, nl = mk()
-    kr, dr, nr = mk()
-    ur = torch.zeros((F, cap), dtype=torch.float32, device=dev)
-    depth = torch.zeros((F, cap), dtype=torch.float32, device=dev)
-    n_stereo = torch.zeros(F, dtype=torch.int32, device=dev)
-    blocked = torch.zeros((F, cap), dtype=torch.uint8, device=dev)
-    assigned = torch.zeros((F, cap), dtype=torch.int32, device=dev)
-    n_track = torch.zeros(F, dtype=torch.int32, device=dev)
-    cams_np, poses_np = camera_records(F, exL.GetScaleFactors())
+    cams_np, poses_np = camera_records(F, exL.GetScaleFactors(), cfg)
     t_cams = torch.from_numpy(cams_np.view(np.uint8).reshape(F, -1)).to(dev)
     t_poses = torch.from_numpy(poses_np.view(np.uint8).reshape(F, -1)).to(dev)
-    pts = torch.zeros((F, cap, 60), dtype=torch.uint8, device=dev)      # orbfe_last_point records
-    q = torch.zeros((F, cap, 68), dtype=torch.uint8, device=dev)        # orbfe_query records
-    nq = torch.zeros(F, dtype=torch.int32, device=dev)
-    mb = MBF / FX
-    # three explicit HIP streams: torch's default stream is the NULL stream, which the C ABI reads as "use the
-    # handle's own stream"; the whole step therefore runs on named streams ordered by events
+    mb = cfg["bf"] / cfg["fx"]
+
+    class Buffers:
+        """One set of device inputs and outputs of a step (two sets double-buffer the PCIe-inclusive run)."""
+
+        def __init__(self):
+            z = lambda *s, dt=torch.uint8: torch.zeros(s, dtype=dt, device=dev)
+            self.dL = hL.to(dev)
+            self.dR = hR.to(dev) if STEREO else None
+            self.kl, self.dl, self.nl = z(F, cap, 28), z(F, cap, 32), z(F, dt=torch.int32)
+            if STEREO:
+                self.kr, self.dr, self.nr = z(F, cap, 28), z(F, cap, 32), z(F, dt=torch.int32)
+            self.ur = z(F, cap, dt=torch.float32) if STEREO else None
+            self.depth = z(F, cap, dt=torch.float32) if STEREO else torch.full((F, cap), MONO_DEPTH, dtype=torch.float32, device=dev)
+            self.n_stereo = z(F, dt=torch.int32)
+            self.blocked, self.assigned, self.n_track = z(F, cap), z(F, cap, dt=torch.int32), z(F, dt=torch.int32)
+            self.pts, self.q, self.nq = z(F, cap, 60), z(F, cap, 68), z(F, dt=torch.int32)   # orbfe_last_point / orbfe_query
+            self.bf = z(F, cap, 12)                                                          # orbfe_bf_match records
+            self.grp = z(F, cap, dt=torch.int32)
+
+    B0 = Buffers()
+    # explicit HIP streams: torch's default stream is the NULL stream, which the C ABI reads as "use the handle's own
+    # stream"; the whole step therefore runs on named streams ordered by events
     sM, sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     evL, evR = torch.cuda.Event(), torch.cuda.Event()
 
-    def step():
-        with torch.cuda.stream(sM):
-            _step(sM)
-
-    def _step(cur):
-        if args.lr_streams == 2:
+    def _step(cur, B):
+        if STEREO and args.lr_streams == 2:
             sL.wait_stream(cur); sR.wait_stream(cur)
-            exL.extract_batch_device(dL, kl, dl, nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90: two threads)
-            exR.extract_batch_device(dR, kr, dr, nr, stream=sR)   # ORBextractor right
+            exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90: two threads)
+            exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)   # ORBextractor right
             evL.record(sL); evR.record(sR)
             cur.wait_event(evL); cur.wait_event(evR)
         else:
-            exL.extract_batch_device(dL, kl, dl, nl, stream=cur)
-            exR.extract_batch_device(dR, kr, dr, nr, stream=cur)
-        mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, MBF, mb, ur, depth, n_stereo, stream=cur)  # ComputeStereoMatches
-        unproject_stereo_batch(kl, dl, nl, depth, t_cams, 1, pts, cur)   # Frame::UnprojectStereo: the stereo points of every frame
-        track_queries_batch(t_poses, pts, nl, 1, q, nq, cur)             # projected into the next frame (ORBmatcher.cc:1270-1308)
-        blocked.zero_(); assigned.fill_(-1)
-        mt.proj_match_batch(kl, dl, nl, ur, (0.0, float(W), 0.0, float(H)), q, nq, 1, 0.9, True, blocked, assigned,
-                            n_track, stream=cur)              # SearchByProjection(cur, last, th=7)
+            exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=cur)
+            if STEREO:
+                exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=cur)
+        if STEREO:
+            mt.stereo_match(exL, exR, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], mb, B.ur, B.depth, B.n_stereo, stream=cur)
+        if cfg["match"] == "projection":
+            unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, t_cams, 1, B.pts, cur)   # Frame::UnprojectStereo per keypoint with depth
+            track_queries_batch(t_poses, B.pts, B.nl, 1, B.q, B.nq, cur)               # projected into the next frame (:1270-1308)
+            B.blocked.zero_(); B.assigned.fill_(-1)
+            mt.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked,
+                                B.assigned, B.n_track, stream=cur)                    # SearchByProjection(cur, last, th)
+        else:
+            # SearchByBoW's brute force: frame f against frame f-1 (slices of the same buffers: no copies), grouped by node id
+            B.grp.copy_(node_ids(B.dl))
+            mt.hamming_bf_batch(B.dl[1:], B.nl[1:], B.dl[:-1], B.nl[:-1], B.grp[1:], B.grp[:-1], B.bf[1:], stream=cur)
         if world > 1:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
-            gatherer.launch(nl, kl, dl)
+            gatherer.launch(B.nl, B.kl, B.dl)
 
-    gatherer = AsyncGather(nl, kl, dl) if world > 1 else None
+    def step():
+        with torch.cuda.stream(sM):
+            _step(sM, B0)
+
+    gatherer = AsyncGather(B0.nl, B0.kl, B0.dl) if world > 1 else None
 
     def barrier():
         if gatherer is not None:
@@ -207,25 +348,34 @@ def main():
     for _ in range(max(args.warmup, 1) if args.warmup >= 0 else 0):
         step()
     barrier()
-    exL.device_status(); exR.device_status()
-    n_kp = int(nl.sum().item()) + int(nr.sum().item())
-    n_st = int(n_stereo.sum().item())
-    n_tr = int(n_track.sum().item())
+    for e in extractors:
+        e.device_status()
+    n_img = len(extractors) * F
+    n_kp = int(B0.nl.sum().item()) + (int(B0.nr.sum().item()) if STEREO else 0)
+    n_st = int(B0.n_stereo.sum().item())
+    n_tr = int(B0.n_track.sum().item()) if cfg["match"] == "projection" else int((B0.bf.view(torch.int32)[..., 0] >= 0).sum().item())
     # measured FAST candidates per image (for the algorithmic byte count of the FAST kernel)
     cand_per_img = float(np.mean([sum(len(exL.debug_candidates(i, l)[0]) for l in range(NLEVELS)) for i in range(min(F, 4))]))
 
     # all-stage event timing costs ~2 % of the step: a short untimed pass yields the stage breakdown (and names the
     # dominant kernel); inside the timed region only that kernel is bracketed by HIP events on its launch stream
-    exL.profile(True); exR.profile(True)
-    exL.stage_times(reset=True); exR.stage_times(reset=True)
+    def stage_sums():
+        tot = {}
+        for e in extractors:
+            for k, v in e.stage_times().items():
+                a = tot.get(k, (0.0, 0))
+                tot[k] = (a[0] + v[0], a[1] + v[1])
+        return tot
+
+    for e in extractors:
+        e.profile(True); e.stage_times(reset=True)
     for _ in range(3):
         step()
     barrier()
-    stage_all = {k: (a[0] + b[0], a[1] + b[1]) for (k, a), b in zip(exL.stage_times().items(), exR.stage_times().values())}
-    stage_ms_all = {k: (v[0] / max(v[1] // 2 if k == "pyramid" else v[1], 1)) for k, v in stage_all.items()}
+    stage_ms_all = {k: (v[0] / max(v[1] // 2 if k == "pyramid" else v[1], 1)) for k, v in stage_sums().items()}
     dom = max(stage_ms_all, key=lambda k: stage_ms_all[k])
-    exL.profile(True, [dom]); exR.profile(True, [dom])
-    exL.stage_times(reset=True); exR.stage_times(reset=True)
+    for e in extractors:
+        e.profile(True, [dom]); e.stage_times(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -236,11 +386,51 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    stL, stR = exL.stage_times(), exR.stage_times()
-    exL.profile(False); exR.profile(False)
+    st_dom = stage_sums()[dom]
+    for e in extractors:
+        e.profile(False)
+
+    # ---- PCIe-inclusive rate (N = 1): pinned host images in, host keypoints / descriptors / match results out, two buffer
+    #      sets: the H2D copy of step i+1 and the D2H copy of step i-1 run beside the kernels of step i
+    e2e = None
+    if world == 1 and args.e2e_steps > 0:
+        Bs = [B0, Buffers()]
+        sH, sD = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        host_out = [[torch.empty_like(t, device="cpu").pin_memory() for t in
+                     ([b.kl, b.dl, b.nl, b.assigned] + ([b.ur, b.depth] if STEREO else []))] for b in Bs]
+        ev_in = [torch.cuda.Event() for _ in Bs]; ev_done = [torch.cuda.Event() for _ in Bs]; ev_out = [torch.cuda.Event() for _ in Bs]
+
+        def e2e_run(n):
+            for i in range(n):
+                j = i & 1
+                b = Bs[j]
+                with torch.cuda.stream(sH):
+                    sH.wait_event(ev_done[j])                 # the kernels that read this input set have finished
+                    b.dL.copy_(hL, non_blocking=True)
+                    if STEREO:
+                        b.dR.copy_(hR, non_blocking=True)
+                    ev_in[j].record(sH)
+                with torch.cuda.stream(sM):
+                    sM.wait_event(ev_in[j]); sM.wait_event(ev_out[j])   # inputs here, previous results of this set copied out
+                    _step(sM, b)
+                    ev_done[j].record(sM)
+                with torch.cuda.stream(sD):
+                    sD.wait_event(ev_done[j])
+                    srcs = [b.kl, b.dl, b.nl, b.assigned] + ([b.ur, b.depth] if STEREO else [])
+                    for dst, src in zip(host_out[j], srcs):
+                        dst.copy_(src, non_blocking=True)
+                    ev_out[j].record(sD)
+            torch.cuda.synchronize()
+
+        for ev in ev_done + ev_out:
+            ev.record(sM)
+        e2e_run(2)
+        t1 = time.perf_counter()
+        e2e_run(args.e2e_steps)
+        e2e = F * args.e2e_steps / (time.perf_counter() - t1)
 
     if rank == 0:
-        px = level_pixels(exL)
+        px = [exL.level_size(l, W, H) for l in range(NLEVELS)]
         sumP = sum(w * h for w, h in px)
         P0, P7 = px[0][0] * px[0][1], px[-1][0] * px[-1][1]
         # algorithmic bytes per image and per kernel; one launch processes F images
@@ -252,40 +442,49 @@ def main():
             "describe": NFEAT * (749 + 512 + 60),
         }
         per_launch_ms = dict(stage_ms_all)   # untimed 3-step pass (every stage)
-        cnt = stL[dom][1] + stR[dom][1]
-        if dom == "pyramid":
-            cnt //= 2  # two timed groups (level-0 copy, resize chain) per batch
-        per_launch_ms[dom] = (stL[dom][0] + stR[dom][0]) / max(cnt, 1)   # the dominant kernel: live, over the timed region
+        cnt = st_dom[1] // 2 if dom == "pyramid" else st_dom[1]   # pyramid: two timed groups (level-0 copy, resize chain) per batch
+        per_launch_ms[dom] = st_dom[0] / max(cnt, 1)              # the dominant kernel: live, over the timed region
         achieved = alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed PMC pass (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-        # runs: profiles/r01_pmc_counters.md), scaled to this launch's image count; null if no pass covers the kernel
-        traffic = None
+        # HBM-side traffic of the dominant kernel: FETCH_SIZE (x2 for 16-byte-per-lane streams on gfx950) + WRITE_SIZE from the
+        # committed PMC pass of THIS kernel build (profiles/r02_pmc_dominant.json), scaled to this launch's image count;
+        # null when the pass covers another kernel or configuration
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fast.json")))
-            if pmc["kernel"].startswith(dom):
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_dominant.json")))
+            if pmc["stage"] == dom and pmc["config"] == args.config:
                 traffic = int((pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
+                traffic_src = f"committed rocprofv3 --pmc pass ({pmc['kernel']}), not measured in this run"
         except Exception:
-            traffic = None
+            pass
         value = world * F * args.steps / dt
         out = {
             "metric": "frames/s (extract+match) at KITTI 1241×376, 2000 feat; 1/2/4/8 GPU + CPU ref",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "kitti_stereo_1241x376_2000feat_8lvl: 2x ORBextractor + ComputeStereoMatches + "
-                                   "SearchByProjection(cur,last)", "stereo_frames_per_gpu_per_step": F,
-                       "images_per_step": 2 * F * world, "parallelism": f"frame-shard x{world}",
-                       "keypoints_per_image": round(n_kp / (2 * F), 1), "stereo_matches_per_frame": round(n_st / F, 1),
-                       "tracked_per_frame": round(n_tr / F, 1)},
+            "config": {"workload": cfg["label"], "name": args.config, "frames_per_gpu_per_step": F,
+                       "images_per_step": n_img * world, "parallelism": f"frame-shard x{world}",
+                       "collective": (f"{backend} all_gather of padded per-frame records, world size {dist.get_world_size()}" if world > 1 else "none"),
+                       "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
+                       "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
+        if e2e is not None:
+            out["e2e_frames_per_s"] = round(e2e, 1)
+            out["e2e_note"] = "pinned host images -> H2D -> step -> D2H of keypoints, descriptors, counts, matches (and mvuRight / mvDepth), double-buffered"
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
+        # the gathered records of the last step == every rank's own records at its slot (the collective moved the right bytes)
+        n_all, k_all, d_all = gatherer.result()
+        mine = slice(rank * F, (rank + 1) * F)
+        ok = bool((n_all[mine].to(B0.nl.device) == B0.nl).all()) and bool((d_all[mine].to(B0.dl.device) == B0.dl).all())
+        if not ok:
+            raise SystemExit(f"rank {rank}: gathered records differ from the local ones")
         dist.barrier()
         dist.destroy_process_group()
 

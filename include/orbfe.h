@@ -233,9 +233,9 @@ typedef struct orbfe_frustum {
   float fx, fy, cx, cy, mbf;
   float min_x, max_x, min_y, max_y;   /* mnMinX, mnMaxX, mnMinY, mnMaxY */
   float log_scale_factor;             /* mfLogScaleFactor */
-  int32_t n_levels;                   /* mnScaleLevels, 1..8 (ORBFE_ERR_INVALID otherwise) */
-  float scale_factors[8];             /* mvScaleFactors */
-} orbfe_frustum;                      /* 136 bytes */
+  int32_t n_levels;                   /* mnScaleLevels, 1..ORBFE_MAX_LEVELS (ORBFE_ERR_INVALID otherwise) */
+  float scale_factors[ORBFE_MAX_LEVELS]; /* mvScaleFactors */
+} orbfe_frustum;                      /* 168 bytes */
 
 /* The MapPoint members the path reads (L/include/MapPoint.h); 72 bytes */
 typedef struct orbfe_map_point {
@@ -291,13 +291,13 @@ typedef struct orbfe_last_point {      /* LastFrame keypoint i with its map poin
   uint8_t desc[32];                    /* pMP->GetDescriptor() */
 } orbfe_last_point;
 
-typedef struct orbfe_track_pose {      /* CurrentFrame members read by :1257-1308; 128 bytes */
+typedef struct orbfe_track_pose {      /* CurrentFrame members read by :1257-1308; 160 bytes */
   float Rcw[9], tcw[3];                /* CurrentFrame.mTcw */
   float fx, fy, cx, cy, mbf;
   float min_x, max_x, min_y, max_y;
   int32_t forward, backward;           /* bForward, bBackward (:1267-1268; tlc = Rlw*twc + tlw stays with the caller) */
   float th;
-  float scale_factors[8];              /* CurrentFrame.mvScaleFactors */
+  float scale_factors[ORBFE_MAX_LEVELS]; /* CurrentFrame.mvScaleFactors */
 } orbfe_track_pose;
 
 /* One record per keypoint of every frame: map point = UnprojectStereo(i) when d_depth > 0 (valid = 0 otherwise), descriptor /
@@ -339,21 +339,22 @@ int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA, const uint
  * (:983-1009), SearchBySim3 (both directions, :1118-1147, 1194-1223): for every query the FIRST minimum-distance keypoint
  * of KeyFrame::GetFeaturesInArea(u, v, radius) (L/src/KeyFrame.cc:526-567) whose octave lies in [min_level, max_level]
  * (nPredictedLevel-1 .. nPredictedLevel).  gate: ORBFE_GATE_NONE, or ORBFE_GATE_FUSE_CHI2 = Fuse's reprojection test with
- * u_r = the projected right coordinate and inv_level_sigma2 = mvInvLevelSigma2 (e2 * invSigma2 > 7.8 stereo / 5.99 mono).
+ * u_r = the projected right coordinate and inv_level_sigma2 = mvInvLevelSigma2, n_levels (<= ORBFE_MAX_LEVELS) floats
+ * (e2 * invSigma2 > 7.8 stereo / 5.99 mono).
  * best_idx[q] = keypoint index or -1, best_dist[q] = its distance (256 if none): the caller applies TH_LOW / TH_HIGH and
  * the map bookkeeping (Replace / AddObservation / the mutual check) in query order.  HOST pointers, synchronous. */
 enum { ORBFE_GATE_NONE = 1, ORBFE_GATE_FUSE_CHI2 = 2 };
 int orbfe_proj_best(const orbfe_frame_view* keyframe, const orbfe_query* q, int nq, int gate, const float* inv_level_sigma2,
-                    int32_t* best_idx, int32_t* best_dist);
+                    int n_levels, int32_t* best_idx, int32_t* best_dist);
 
 /* SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo) (L/src/ORBmatcher.cc:614-764)
  * with CheckDistEpipolarLine (:137-159).  The epipole (:622-630) is computed by the caller. */
 typedef struct orbfe_epipolar {
   float F12[9];               /* row-major */
   float ex, ey;               /* epipole of pKF1's camera centre in pKF2's image */
-  float scale_factors[8];     /* pKF2->mvScaleFactors */
-  float level_sigma2[8];      /* pKF2->mvLevelSigma2 */
-} orbfe_epipolar;             /* 108 bytes */
+  float scale_factors[ORBFE_MAX_LEVELS];  /* pKF2->mvScaleFactors */
+  float level_sigma2[ORBFE_MAX_LEVELS];   /* pKF2->mvLevelSigma2 */
+} orbfe_epipolar;             /* 172 bytes */
 /* keys = mvKeysUn, u_right = mvuRight (NULL = monocular: all -1), has_mp[i] = (GetMapPoint(i) != NULL); FeatureVectors as in
  * orbfe_search_by_bow.  matchA[i] = index in pKF2 matched to feature i of pKF1, or -1 (vMatchedPairs = the pairs
  * (i, matchA[i]) in ascending i).  No match blocks another (vbMatched2 is never set in the reference); among the

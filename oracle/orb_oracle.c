@@ -1026,7 +1026,7 @@ void oo_track_query(const oo_track_pose* P, const oo_last_point* lp, oo_query* q
   if (u < P->min_x || u > P->max_x) return;
   if (v < P->min_y || v > P->max_y) return;
   const int nLastOctave = lp->octave;
-  const float radius = P->th * P->scale_factors[nLastOctave & 7];
+  const float radius = P->th * P->scale_factors[nLastOctave];   /* :1297, unmasked as in the reference */
   q->u = u; q->v = v; q->radius = radius;
   q->u_r = u - P->mbf * invzc;
   if (P->forward) { q->min_level = nLastOctave; q->max_level = -1; }

@@ -148,7 +148,7 @@ typedef struct oo_frustum {      /* the Frame members isInFrustum reads (L/inclu
   float min_x, max_x, min_y, max_y;   /* mnMinX .. mnMaxY */
   float log_scale_factor;        /* mfLogScaleFactor */
   int32_t n_levels;              /* mnScaleLevels */
-  float scale_factors[8];        /* mvScaleFactors */
+  float scale_factors[OO_MAX_LEVELS];        /* mvScaleFactors */
 } oo_frustum;
 typedef struct oo_map_point {    /* the MapPoint members the path reads (L/include/MapPoint.h) */
   float pos[3], normal[3];       /* mWorldPos, mNormalVector */
@@ -180,7 +180,7 @@ typedef struct oo_last_point { float pos[3]; int32_t valid, observed, octave; fl
 typedef struct oo_track_pose {
   float Rcw[9], tcw[3], fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y;
   int32_t forward, backward;
-  float th, scale_factors[8];
+  float th, scale_factors[OO_MAX_LEVELS];
 } oo_track_pose;
 /* record of keypoint kp with depth z: map point = UnprojectStereo when z > 0 */
 void oo_unproject_stereo(const oo_unproject_cam* cam, const oo_keypoint* kp, float z, const uint8_t* desc, int observed,
@@ -222,7 +222,7 @@ void oo_proj_best(const oo_frame* kf, const oo_query* q, int nq, int gate, const
                   int32_t* best_dist);
 /* SearchForTriangulation: ORBmatcher.cc:614-764 with CheckDistEpipolarLine :137-159.  has_mp: GetMapPoint(i) != NULL; u_right may
  * be NULL (monocular).  matchA[i] = vMatches12[i].  Returns nmatches. */
-typedef struct oo_epipolar { float F12[9], ex, ey, scale_factors[8], level_sigma2[8]; } oo_epipolar;
+typedef struct oo_epipolar { float F12[9], ex, ey, scale_factors[OO_MAX_LEVELS], level_sigma2[OO_MAX_LEVELS]; } oo_epipolar;
 int oo_search_for_triangulation(const oo_keypoint* keysA, const uint8_t* descA, const float* u_rightA, const uint8_t* has_mpA, int nA,
                                 const oo_featvec_node* nodesA, int n_nodesA, const int32_t* idxA, const oo_keypoint* keysB,
                                 const uint8_t* descB, const float* u_rightB, const uint8_t* has_mpB, int nB,

@@ -28,7 +28,7 @@ CAND_DTYPE = np.dtype([("idx", "<i4"), ("dist", "<i4")])
 FRUSTUM_DTYPE = np.dtype(
     [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("Ow", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"),
      ("cy", "<f4"), ("mbf", "<f4"), ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"),
-     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("scale_factors", "<f4", (8,))]
+     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("scale_factors", "<f4", (16,))]
 )
 MAP_POINT_DTYPE = np.dtype(
     [("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"), ("skip", "<i4"),
@@ -37,16 +37,16 @@ MAP_POINT_DTYPE = np.dtype(
 TRACK_DTYPE = np.dtype(
     [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
 )
-EPIPOLAR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ex", "<f4"), ("ey", "<f4"), ("scale_factors", "<f4", (8,)), ("level_sigma2", "<f4", (8,))])
+EPIPOLAR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ex", "<f4"), ("ey", "<f4"), ("scale_factors", "<f4", (16,)), ("level_sigma2", "<f4", (16,))])
 UNPROJECT_CAM_DTYPE = np.dtype([("Rwc", "<f4", (9,)), ("Ow", "<f4", (3,)), ("cx", "<f4"), ("cy", "<f4"), ("invfx", "<f4"), ("invfy", "<f4")])
 LAST_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("valid", "<i4"), ("observed", "<i4"), ("octave", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
 TRACK_POSE_DTYPE = np.dtype(
     [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("mbf", "<f4"),
      ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"), ("forward", "<i4"), ("backward", "<i4"),
-     ("th", "<f4"), ("scale_factors", "<f4", (8,))]
+     ("th", "<f4"), ("scale_factors", "<f4", (16,))]
 )
-assert UNPROJECT_CAM_DTYPE.itemsize == 64 and LAST_POINT_DTYPE.itemsize == 60 and TRACK_POSE_DTYPE.itemsize == 128
-assert FRUSTUM_DTYPE.itemsize == 136 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
+assert UNPROJECT_CAM_DTYPE.itemsize == 64 and LAST_POINT_DTYPE.itemsize == 60 and TRACK_POSE_DTYPE.itemsize == 160
+assert FRUSTUM_DTYPE.itemsize == 168 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
 BF_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_dist", "<i4")])
 
 
@@ -168,7 +168,7 @@ def lib():
     L.orbfe_vocabulary_info.argtypes = [vp, pi, pi, pi, pi]
     L.orbfe_bow_transform_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.orbfe_compute_bow.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, pi, vp, vp, pi]
-    L.orbfe_proj_best.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, vp]
+    L.orbfe_proj_best.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, ci, vp, vp]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp, pi]
     L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]

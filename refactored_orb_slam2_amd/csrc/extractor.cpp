@@ -187,6 +187,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     return ORBFE_ERR_INVALID;
   }
   const int nl = e->prm.n_levels;
+  e->plan_w = e->plan_h = 0;   // the tables below are rewritten in place: a plan that fails half-way must not pass for the old one
   size_t off = 0;
   for (int l = 0; l < nl; l++) {
     LevelGeom& g = e->lg[l];

@@ -11,7 +11,7 @@
 #define MP_DW (int)(sizeof(orbfe_map_point) / 4)   // 18
 #define Q_DW (int)(sizeof(orbfe_query) / 4)        // 17
 #define TR_DW (int)(sizeof(orbfe_track) / 4)       // 6
-static_assert(sizeof(orbfe_last_point) == 60 && sizeof(orbfe_track_pose) == 128 && sizeof(orbfe_unproject_cam) == 64, "record layout");
+static_assert(sizeof(orbfe_last_point) == 60 && sizeof(orbfe_track_pose) == 160 && sizeof(orbfe_unproject_cam) == 64, "record layout");
 static_assert(sizeof(orbfe_map_point) == 72 && sizeof(orbfe_query) == 68 && sizeof(orbfe_track) == 24, "record layout");
 
 // glibc 2.35 logf (__logf_data, LOGF_TABLE_BITS = 4): {invc, logc} pairs.  Same constants as the oracle's oo_logf; the
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(FQ_THREADS) void frustum_queries_kernel(const orbfe
       float r = ((double)tr.view_cos > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos (:130-135)
       if ((double)th != 1.0) r *= th;
       q.u = tr.proj_x; q.v = tr.proj_y; q.u_r = tr.proj_xr;
-      q.radius = r * fr.scale_factors[tr.level & 7];   // n_levels <= 8 (checked on the host entry point)
+      q.radius = r * fr.scale_factors[tr.level];   // predict_scale clamps to n_levels - 1 < ORBFE_MAX_LEVELS
       q.min_level = tr.level - 1;
       q.max_level = tr.level;
       q.valid = 1;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
           const int oct = lp.octave;
           q.u = u; q.v = v;
           q.u_r = u - P.mbf * invzc;                                   // :1327
-          q.radius = P.th * P.scale_factors[oct & 7];                  // :1297
+          q.radius = P.th * P.scale_factors[oct & (ORBFE_MAX_LEVELS - 1)];   // :1297 (the mask only guards memory: octave < nLevels <= 16)
           if (P.forward) { q.min_level = oct; q.max_level = -1; }      // GetFeaturesInArea(u, v, radius, nLastOctave)
           else if (P.backward) { q.min_level = 0; q.max_level = oct; }
           else { q.min_level = oct - 1; q.max_level = oct + 1; }

@@ -125,7 +125,7 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
   fr.min_x = F.mnMinX; fr.max_x = F.mnMaxX; fr.min_y = F.mnMinY; fr.max_y = F.mnMaxY;
   fr.log_scale_factor = F.mfLogScaleFactor;
   fr.n_levels = F.mnScaleLevels;
-  for (int l = 0; l < F.mnScaleLevels && l < 8; l++) fr.scale_factors[l] = F.mvScaleFactors[l];
+  for (int l = 0; l < F.mnScaleLevels && l < ORBFE_MAX_LEVELS; l++) fr.scale_factors[l] = F.mvScaleFactors[l];
   std::vector<orbfe_map_point> mp(n);
   for (size_t i = 0; i < n; i++) {
     MapPointT* pMP = vpLocalMapPoints[i];
@@ -267,7 +267,7 @@ int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, const float F12[9],
   memset(&ep, 0, sizeof(ep));
   memcpy(ep.F12, F12, sizeof(ep.F12));
   ep.ex = ex; ep.ey = ey;
-  for (size_t l = 0; l < pKF2->mvScaleFactors.size() && l < 8; l++) {
+  for (size_t l = 0; l < pKF2->mvScaleFactors.size() && l < ORBFE_MAX_LEVELS; l++) {
     ep.scale_factors[l] = pKF2->mvScaleFactors[l];
     ep.level_sigma2[l] = pKF2->mvLevelSigma2[l];
   }

@@ -278,7 +278,7 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
         if (ok) {
           const float kpr = ur ? ur[idx] : -1.0f;
           const float ex = x - kp.x, ey = y - kp.y;
-          const float invs = inv_sigma2[kp.octave & 7];
+          const float invs = inv_sigma2[kp.octave & (ORBFE_MAX_LEVELS - 1)];   // the mask only guards memory
           if (kpr >= 0) {
             const float er = q.u_r - kpr;
             const float e2 = ex * ex + ey * ey + er * er;
@@ -308,7 +308,7 @@ template <int GATE>
 __global__ __launch_bounds__(256) void proj_best_kernel(FrameBatch F, QueryBatch Q, const float* __restrict__ inv_sigma2,
                                                         int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist) {
   __shared__ float s_inv[ORBFE_MAX_LEVELS];
-  if (threadIdx.x < 8) s_inv[threadIdx.x] = inv_sigma2 ? inv_sigma2[threadIdx.x] : 0.f;
+  if (threadIdx.x < ORBFE_MAX_LEVELS) s_inv[threadIdx.x] = inv_sigma2 ? inv_sigma2[threadIdx.x] : 0.f;
   __syncthreads();
   const int f = blockIdx.y;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -737,12 +737,12 @@ __global__ __launch_bounds__(64) void triangulation_match_kernel(TriParams T) {
         const orbfe_keypoint kp2 = T.keysB[idx2];
         if (!bStereo1 && !T.stereoB[idx2]) {
           const float distex = T.ep.ex - kp2.x, distey = T.ep.ey - kp2.y;
-          if (distex * distex + distey * distey < 100 * T.ep.scale_factors[kp2.octave & 7]) continue;
+          if (distex * distex + distey * distey < 100 * T.ep.scale_factors[kp2.octave & (ORBFE_MAX_LEVELS - 1)]) continue;
         }
         const float num = la * kp2.x + lb * kp2.y + lc;
         if (den == 0) continue;
         const float dsqr = num * num / den;
-        if (!((double)dsqr < 3.84 * (double)T.ep.level_sigma2[kp2.octave & 7])) continue;
+        if (!((double)dsqr < 3.84 * (double)T.ep.level_sigma2[kp2.octave & (ORBFE_MAX_LEVELS - 1)])) continue;
         const unsigned k = ((unsigned)dist << 16) | (unsigned)(0xffff - i2);
         key = min(key, k);
       }

@@ -389,7 +389,7 @@ extern "C" int orbfe_search_local_points(const orbfe_frame_view* f, const orbfe_
                                          int n_points, float th, float nnratio, orbfe_track* track, uint8_t* blocked,
                                          int32_t* assigned, int* n_to_match, int* n_matches) {
   if (!frame_ok(f) || !fr || n_points < 0 || (n_points > 0 && (!mp || !track)) || !blocked || !assigned || !n_to_match ||
-      !n_matches || fr->n_levels < 1 || fr->n_levels > 8)  // orbfe_frustum::scale_factors holds 8 levels
+      !n_matches || fr->n_levels < 1 || fr->n_levels > ORBFE_MAX_LEVELS)
     return ORBFE_ERR_INVALID;
   *n_to_match = 0;
   *n_matches = 0;
@@ -475,13 +475,17 @@ static int bow_impl(const uint8_t* descA, const float* angleA, const uint8_t* va
   int sequential = 0;
   {
     std::vector<uint8_t> seen((size_t)nB, 0);
-    for (const BowPair& pr : pairs)
-      for (int t = 0; t < pr.countB && !sequential; t++) {
+    for (const BowPair& pr : pairs) {   // a malformed FeatureVector must not index past the descriptor arrays on the device
+      if (pr.startA < 0 || pr.countA < 0 || pr.startB < 0 || pr.countB < 0) return ORBFE_ERR_INVALID;
+      for (int t = 0; t < pr.countA; t++)
+        if (idxA[pr.startA + t] < 0 || idxA[pr.startA + t] >= nA) return ORBFE_ERR_INVALID;
+      for (int t = 0; t < pr.countB; t++) {
         const int j = idxB[pr.startB + t];
         if (j < 0 || j >= nB) return ORBFE_ERR_INVALID;
         if (seen[j]) sequential = 1;
         seen[j] = 1;
       }
+    }
   }
   orbfe_matcher* m;
   int rc;
@@ -556,9 +560,9 @@ extern "C" int orbfe_search_by_bow_kf(const uint8_t* descA, const float* angleA,
 
 // Independent arg-min searches (Fuse, Fuse(Sim3), SearchBySim3), host pointers, synchronous
 extern "C" int orbfe_proj_best(const orbfe_frame_view* f, const orbfe_query* q, int nq, int gate, const float* inv_level_sigma2,
-                               int32_t* best_idx, int32_t* best_dist) {
+                               int n_levels, int32_t* best_idx, int32_t* best_dist) {
   if (!frame_ok(f) || nq < 0 || (nq > 0 && (!q || !best_idx || !best_dist)) || (gate != ORBFE_GATE_NONE && gate != ORBFE_GATE_FUSE_CHI2) ||
-      (gate == ORBFE_GATE_FUSE_CHI2 && !inv_level_sigma2))
+      (gate == ORBFE_GATE_FUSE_CHI2 && (!inv_level_sigma2 || n_levels < 1 || n_levels > ORBFE_MAX_LEVELS)))
     return ORBFE_ERR_INVALID;
   for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
   if (nq == 0 || f->n == 0) return ORBFE_OK;
@@ -571,7 +575,11 @@ extern "C" int orbfe_proj_best(const orbfe_frame_view* f, const orbfe_query* q, 
   if ((rc = stage_host(m, f, q, nq, s))) return rc;
   if ((rc = ensure_proj_scratch(m, 1, f->n, nq))) return rc;
   if ((rc = mb_alloc(m->lp_cnt, 64))) return rc;
-  if (gate == ORBFE_GATE_FUSE_CHI2) HIPCHK(hipMemcpyAsync(m->lp_cnt.p, inv_level_sigma2, 8 * sizeof(float), hipMemcpyHostToDevice, s));
+  float inv16[ORBFE_MAX_LEVELS] = {0};
+  if (gate == ORBFE_GATE_FUSE_CHI2) {
+    memcpy(inv16, inv_level_sigma2, sizeof(float) * n_levels);
+    HIPCHK(hipMemcpyAsync(m->lp_cnt.p, inv16, sizeof(inv16), hipMemcpyHostToDevice, s));
+  }
   FrameBatch fb;
   fill_frame_batch(m, fb, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
                    f->u_right ? (const float*)m->h_ur.p : nullptr, f->n, f->min_x, f->max_x, f->min_y, f->max_y);
@@ -617,6 +625,7 @@ extern "C" int orbfe_search_for_triangulation(const orbfe_keypoint* keysA, const
   {
     std::vector<uint8_t> seen((size_t)nA, 0);
     for (const BowPair& pr : pairs) {
+      if (pr.startA < 0 || pr.countA < 0 || pr.startB < 0 || pr.countB < 0) return ORBFE_ERR_INVALID;
       for (int t = 0; t < pr.countA; t++) {
         const int j = idxA[pr.startA + t];
         if (j < 0 || j >= nA) return ORBFE_ERR_INVALID;

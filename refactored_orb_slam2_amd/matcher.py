@@ -3,8 +3,8 @@
 Method names and argument meaning follow Source/Libraries/ORB_SLAM2/include/ORBmatcher.h:34-114; SLAM
 objects (Frame, MapPoint, KeyFrame) are replaced by plain arrays: a FrameView carries mvKeysUn /
 mDescriptors / mvuRight / image bounds, queries carry one projected map point each (``QUERY_DTYPE``).
-PyTorch is used only to hold device memory.  All distance / window / assignment work runs in HIP kernels;
-SearchByBoW's order-dependent pass replays on the host over the device-computed distance matrix.
+PyTorch is used only to hold device memory.  All distance / window / assignment work runs in HIP kernels, the
+order-dependent passes (greedy assignment, SearchByBoW's per-node replay, the rotation histogram) included.
 """
 from __future__ import annotations
 
@@ -64,7 +64,7 @@ def make_frustum(Rcw, tcw, fx, fy, cx, cy, mbf, bounds, scale_factor, n_levels) 
     sf = np.ones(8, np.float32)
     for i in range(1, n_levels):
         sf[i] = np.float32(sf[i - 1] * np.float32(scale_factor))
-    fr["scale_factors"][0] = sf
+    fr["scale_factors"][0, :len(sf)] = sf
     return fr
 
 
@@ -180,7 +180,7 @@ class ORBmatcher:
         bi = np.full(len(q), -1, np.int32); bd = np.full(len(q), 256, np.int32)
         inv = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
         _lib.check(self._L.orbfe_proj_best(C.byref(keyframe.c), _lib.ptr(q), len(q), 2 if inv is not None else 1, _lib.ptr(inv),
-                                           _lib.ptr(bi), _lib.ptr(bd)), "orbfe_proj_best")
+                                           0 if inv is None else len(inv), _lib.ptr(bi), _lib.ptr(bd)), "orbfe_proj_best")
         return bi, bd
 
     # ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): ORBmatcher.cc:388-492
@@ -339,10 +339,20 @@ class Matcher:
             bounds[3], _lib.ptr(queries), _lib.ptr(nq), queries.shape[1], mode, nnratio, int(check_ori), _lib.ptr(blocked),
             _lib.ptr(assigned), _lib.ptr(n_matches), s), "orbfe_proj_match_batch_device")
 
+    @staticmethod
+    def hamming_bf_batch(descA, nA, descB, nB, groupA, groupB, out, stream=None):
+        """The brute force inside SearchByBoW (ORBmatcher.cc:201-222) for a batch of frame pairs, device-resident
+        (torch CUDA tensors): descA / descB (S,cap,32) u8, nA / nB (S) i32, groupA / groupB (S,cap) i32 node ids or None,
+        out (S,cap,12) u8 = orbfe_bf_match records (best index, best and second-best distance) per row of A."""
+        S, cap = descA.shape[0], descA.shape[1]
+        _lib.check(_lib.lib().orbfe_hamming_bf_device(_lib.ptr(descA), _lib.ptr(nA), cap, cap, _lib.ptr(descB), _lib.ptr(nB),
+                                                      descB.shape[1], _lib.ptr(groupA), _lib.ptr(groupB), None, S, _lib.ptr(out),
+                                                      _lib.stream_handle(stream)), "orbfe_hamming_bf_device")
+
     def search_local_points_batch(self, kps, desc, n, u_right, bounds, frustums, points, n_points, th, nnratio, track,
                                   blocked, assigned, n_to_match, n_matches, stream=None):
         """Tracking::SearchLocalPoints for a batch of frames, everything device-resident (torch CUDA tensors):
-        frustums (F,136) u8, points (F,pcap,72) u8, n_points (F) i32, track (F,pcap,24) u8; the rest as proj_match_batch."""
+        frustums (F,168) u8, points (F,pcap,72) u8, n_points (F) i32, track (F,pcap,24) u8; the rest as proj_match_batch."""
         F, cap = desc.shape[0], desc.shape[1]
         s = _lib.stream_handle(stream)
         _lib.check(self._L.orbfe_search_local_points_batch_device(

@@ -32,8 +32,12 @@ class AsyncGather:
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
-        self.snap = [torch.empty_like(t) for t in (n, kps, desc)]
-        self.out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        # RCCL moves device tensors; the gloo rehearsal path (CPU tests, several ranks on one GPU -- RCCL refuses two ranks
+        # per device) stages the records through host memory
+        self.on_host = dist.get_backend(group) != "nccl" and n.is_cuda
+        dev = "cpu" if self.on_host else n.device
+        self.snap = [torch.empty_like(t, device=dev) for t in (n, kps, desc)]
+        self.out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
                     for t in (n, kps, desc)]
         self.pending = []
 
@@ -43,10 +47,13 @@ class AsyncGather:
         self.pending = []
 
     def launch(self, n, kps, desc):
+        import torch
         import torch.distributed as dist
         self.wait()  # the snapshot / output buffers are free again
         for s, t in zip(self.snap, (n, kps, desc)):
-            s.copy_(t, non_blocking=True)
+            s.copy_(t, non_blocking=not self.on_host)
+        if self.on_host:
+            torch.cuda.current_stream().synchronize()
         self.pending = [dist.all_gather_into_tensor(o, s, group=self.group, async_op=True)
                         for o, s in zip(self.out, self.snap)]
 

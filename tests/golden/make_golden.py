@@ -101,7 +101,7 @@ def tracking_fixture():
     pts = ol.unproject_stereo(cam, k0, d0, depth)
     pose["Rcw"][0] = R.reshape(9); pose["tcw"][0] = t + np.array([0.01, 0.0, 0.02], np.float32)
     pose["fx"] = 517.3; pose["fy"] = 516.5; pose["cx"] = 316.6; pose["cy"] = 255.3; pose["mbf"] = 40.0
-    pose["max_x"] = w; pose["max_y"] = h; pose["th"] = 15.0; pose["scale_factors"][0] = sf
+    pose["max_x"] = w; pose["max_y"] = h; pose["th"] = 15.0; pose["scale_factors"][0, :len(sf)] = sf
     tq = ol.track_queries(pose, pts)
     t_nm, t_assigned, _ = ol.OracleFrame(k1, d1, sf, 0, w, 0, h, None).search_by_projection_frame(tq, True)
     # relocalisation search with the same queries, caller's distance bound

@@ -29,7 +29,7 @@ assert QUERY_DTYPE.itemsize == 68
 FRUSTUM_DTYPE = np.dtype(
     [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("Ow", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"),
      ("cy", "<f4"), ("mbf", "<f4"), ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"),
-     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("scale_factors", "<f4", (8,))]
+     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("scale_factors", "<f4", (16,))]
 )
 MAP_POINT_DTYPE = np.dtype(
     [("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"), ("skip", "<i4"),
@@ -38,15 +38,15 @@ MAP_POINT_DTYPE = np.dtype(
 TRACK_DTYPE = np.dtype(
     [("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")]
 )
-EPIPOLAR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ex", "<f4"), ("ey", "<f4"), ("scale_factors", "<f4", (8,)), ("level_sigma2", "<f4", (8,))])
+EPIPOLAR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ex", "<f4"), ("ey", "<f4"), ("scale_factors", "<f4", (16,)), ("level_sigma2", "<f4", (16,))])
 UNPROJECT_CAM_DTYPE = np.dtype([("Rwc", "<f4", (9,)), ("Ow", "<f4", (3,)), ("cx", "<f4"), ("cy", "<f4"), ("invfx", "<f4"), ("invfy", "<f4")])
 LAST_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("valid", "<i4"), ("observed", "<i4"), ("octave", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
 TRACK_POSE_DTYPE = np.dtype(
     [("Rcw", "<f4", (9,)), ("tcw", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("mbf", "<f4"),
      ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"), ("forward", "<i4"), ("backward", "<i4"),
-     ("th", "<f4"), ("scale_factors", "<f4", (8,))]
+     ("th", "<f4"), ("scale_factors", "<f4", (16,))]
 )
-assert FRUSTUM_DTYPE.itemsize == 136 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
+assert FRUSTUM_DTYPE.itemsize == 168 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
 
 GRID_COLS, GRID_ROWS = 64, 48
 MAX_LEVELS = 16
@@ -304,6 +304,33 @@ def distribute_octree(x, y, score, minX, maxX, minY, maxY, N):
 def descriptor_distance(a, b) -> int:
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().oo_descriptor_distance(_p(a), _p(b))
+
+
+_POPC = np.array([bin(i).count("1") for i in range(256)], np.uint16)
+
+
+def hamming_bf(A, B, groupA=None, groupB=None):
+    """Best / second-best of every row of A over B as the loops of SearchByBoW walk them (ORBmatcher.cc:201-222, distance
+    :1542-1556): first minimum in index order, second-smallest distance; optional node-id groups.  Returns
+    (best_idx [-1 = none], best_dist [256], second_dist [256]).  numpy restatement (byte arithmetic only)."""
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32); B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    bi = np.full(len(A), -1, np.int32); bd = np.full(len(A), 256, np.int32); sd = np.full(len(A), 256, np.int32)
+    if len(A) == 0 or len(B) == 0:
+        return bi, bd, sd
+    for i0 in range(0, len(A), 256):
+        a = A[i0:i0 + 256]
+        d = _POPC[a[:, None, :] ^ B[None, :, :]].sum(axis=2).astype(np.int32)
+        if groupA is not None:
+            d = np.where(np.asarray(groupA)[i0:i0 + 256, None] == np.asarray(groupB)[None, :], d, 1 << 20)
+        order = np.argsort(d, axis=1, kind="stable")[:, :2]
+        rows = np.arange(len(a))
+        b0 = d[rows, order[:, 0]]
+        ok = b0 < (1 << 20)
+        bi[i0:i0 + 256] = np.where(ok, order[:, 0], -1); bd[i0:i0 + 256] = np.where(ok, b0, 256)
+        if B.shape[0] > 1:
+            b1 = d[rows, order[:, 1]]
+            sd[i0:i0 + 256] = np.where(b1 < (1 << 20), b1, 256)
+    return bi, bd, sd
 
 
 class OracleFrame:

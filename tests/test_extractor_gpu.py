@@ -247,3 +247,23 @@ def test_rccl_gather_self_check_world1():
     finally:
         dist.destroy_process_group()
     ex.close()
+
+
+def test_bench_spawns_its_ranks_and_checks_the_gather():
+    """`bench.py --gpus 2` started without a launcher must produce two ranks by itself (one process each; on this one-GPU box
+    both share the device and the gather runs over gloo, because RCCL refuses two ranks per device) and print n_gpus = 2.  Every
+    rank compares its slot of the gathered records with its own records before the line is printed (bench.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBFE_BENCH_SHARE_DEVICE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--frames", "8", "--cpu-sample", "0",
+                        "--e2e-steps", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "frame-shard x2" and out["value"] > 0
+    assert "all_gather" in out["config"]["collective"]

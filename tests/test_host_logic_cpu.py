@@ -68,7 +68,7 @@ def test_bench_camera_reprojects_the_known_image_motion():
     depth = np.where(rng.random(n) < 0.7, np.float32(bench.MBF) / disparity, -1).astype(np.float32)
     sf = ol.OracleExtractor(100).scale_factors
     cams, poses = bench.camera_records(2, sf)
-    assert cams.dtype.itemsize == 64 and poses.dtype.itemsize == 128
+    assert cams.dtype.itemsize == 64 and poses.dtype.itemsize == 160
     pts = ol.unproject_stereo(cams[:1], kp, desc, depth)
     q = ol.track_queries(poses[1:2], pts)
     ok = depth > 0

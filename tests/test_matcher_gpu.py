@@ -284,7 +284,7 @@ def test_unproject_and_track_queries_device(mode):
         poses["fx"][j] = 458.654; poses["fy"][j] = 457.296; poses["cx"][j] = 367.215; poses["cy"][j] = 248.375; poses["mbf"][j] = 47.9
         poses["min_x"][j] = 0; poses["max_x"][j] = w; poses["min_y"][j] = 0; poses["max_y"][j] = h
         poses["forward"][j] = mode == "forward"; poses["backward"][j] = mode == "backward"
-        poses["th"][j] = 15.0; poses["scale_factors"][j] = sf
+        poses["th"][j] = 15.0; poses["scale_factors"][j, :len(sf)] = sf
     dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape + (-1,)) if a.dtype.names else a).cuda()
     t_kps, t_desc, t_n, t_depth, t_cams, t_poses = dev(kps), dev(desc), dev(n), dev(depth), dev(cams), dev(poses)
     t_pts = torch.zeros((F, cap, 60), dtype=torch.uint8, device="cuda")
@@ -518,8 +518,8 @@ def test_search_for_triangulation(only_stereo, mono):
     ep = np.zeros(1, ol.EPIPOLAR_DTYPE)
     ep["F12"][0] = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32) * np.float32(0.37)
     ep["ex"] = 9000.0 if not mono else 300.0; ep["ey"] = 240.0      # mono: some keypoints fall inside the epipole exclusion disc
-    ep["scale_factors"][0] = sf
-    ep["level_sigma2"][0] = (sf * sf).astype(np.float32)
+    ep["scale_factors"][0, :len(sf)] = sf
+    ep["level_sigma2"][0, :len(sf)] = (sf * sf).astype(np.float32)
     urA = None if mono else np.where(rng.random(len(k0)) < 0.5, k0["x"] - np.float32(20), -1).astype(np.float32)
     urB = None if mono else np.where(rng.random(len(k1)) < 0.5, k1["x"] - np.float32(20), -1).astype(np.float32)
     hasA = (rng.random(len(k0)) < 0.3).astype(np.uint8); hasB = (rng.random(len(k1)) < 0.3).astype(np.uint8)

@@ -83,7 +83,7 @@ def _test_frustum(w=640, h=480):
     fr["fx"] = 500; fr["fy"] = 500; fr["cx"] = 320; fr["cy"] = 240; fr["mbf"] = 40
     fr["min_x"] = 0; fr["max_x"] = w; fr["min_y"] = 0; fr["max_y"] = h
     fr["log_scale_factor"] = ol.lib().oo_logf(np.float32(1.2)); fr["n_levels"] = 8
-    fr["scale_factors"][0] = np.cumprod(np.r_[1, [np.float32(1.2)] * 7]).astype(np.float32)
+    fr["scale_factors"][0, :8] = np.cumprod(np.r_[1, [np.float32(1.2)] * 7]).astype(np.float32)
     return fr
 
 
@@ -135,7 +135,7 @@ def test_unproject_and_track_query_known_answers():
     pose["Rcw"][0] = np.eye(3, dtype=np.float32).reshape(9); pose["tcw"][0] = [-1, -2, -3]      # same camera
     pose["fx"] = 500; pose["fy"] = 500; pose["cx"] = 318; pose["cy"] = 240; pose["mbf"] = 40    # principal point moved by -2
     pose["max_x"] = 640; pose["max_y"] = 480; pose["th"] = 7
-    pose["scale_factors"][0] = np.cumprod(np.r_[1, [np.float32(1.2)] * 7]).astype(np.float32)
+    pose["scale_factors"][0, :8] = np.cumprod(np.r_[1, [np.float32(1.2)] * 7]).astype(np.float32)
     q = ol.track_queries(pose, pts)
     assert q["valid"].tolist() == [1, 0, 0]                        # point 1 projects to u = 818 > 640, point 2 has no map point
     assert (q["u"][0], q["v"][0], q["u_r"][0], q["radius"][0]) == (318.0, 240.0, 314.0, 7.0)
