@@ -347,6 +347,56 @@ enum { ORBFE_GATE_NONE = 1, ORBFE_GATE_FUSE_CHI2 = 2 };
 int orbfe_proj_best(const orbfe_frame_view* keyframe, const orbfe_query* q, int nq, int gate, const float* inv_level_sigma2,
                     int n_levels, int32_t* best_idx, int32_t* best_dist);
 
+/* ---- whole-function projection searches of the keyframe-rate callers ---------------------------------
+ * Fuse (L/src/ORBmatcher.cc:766-907), Fuse with Sim3 (:909-1027), SearchBySim3 (:1029-1245, one direction per call),
+ * SearchByProjection(KeyFrame*, Scw, ...) (:275-386) and SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist)
+ * (:1385-1504) share one shape: project every candidate map point into a camera, gate it (depth, image bounds, distance
+ * range, viewing angle), predict its pyramid level, query the window and take the best descriptor.  orbfe_kf_search runs
+ * all of that on the device; what stays with the caller is the pose algebra in front (decomposing Scw, composing
+ * sR21 / t21: a handful of 3x3 products) and the map bookkeeping behind (Replace / AddObservation / AddMapPoint,
+ * vpReplacePoint, the mutual check), which must replay in point order on the SLAM objects. */
+enum {
+  ORBFE_KF_FUSE = 1,       /* :766-907   float 1/z, KeyFrame::IsInImage, normal gate, chi-square gate, <= TH_LOW is the caller's */
+  ORBFE_KF_FUSE_SIM3 = 2,  /* :909-1027  double 1.0/z, IsInImage, normal gate, no chi-square gate */
+  ORBFE_KF_SIM3 = 3,       /* :1029-1245 second transform (sR21, t21), dist3D = |p3Dc2|, no normal gate */
+  ORBFE_KF_LOOP = 4,       /* :275-386   float 1/z, IsInImage, normal gate; vpMatched blocks (sequential), accept <= max_dist */
+  ORBFE_KF_RELOC = 5       /* :1385-1504 no depth gate, double 1.0/z, (fx*xc)*invzc, Frame bounds (< min || > max), levels
+                              [l-1, l+1], occupied keypoints block, accept <= max_dist, rotation histogram */
+};
+typedef struct orbfe_kf_camera {
+  float R[9], t[3];         /* p1 = R * p3Dw + t   (Rcw, tcw; SearchBySim3: R1w, t1w) */
+  float R2[9], t2[3];       /* ORBFE_KF_SIM3 only: p2 = R2 * p1 + t2   (sR21, t21) */
+  float Ow[3];              /* camera centre: dist3D = |p3Dw - Ow| (unused by ORBFE_KF_SIM3) */
+  float fx, fy, cx, cy, mbf;
+  float min_x, max_x, min_y, max_y;   /* mnMinX .. mnMaxY of the keyframe / frame searched in */
+  float log_scale_factor;             /* mfLogScaleFactor */
+  int32_t n_levels;                   /* mnScaleLevels, 1..ORBFE_MAX_LEVELS */
+  float th;                           /* radius = th * mvScaleFactors[nPredictedLevel] */
+  float scale_factors[ORBFE_MAX_LEVELS];
+} orbfe_kf_camera;                    /* 220 bytes */
+typedef struct orbfe_kf_point {       /* one candidate map point; 72 bytes */
+  float pos[3], normal[3];            /* GetWorldPos(), GetNormal() */
+  float min_distance, max_distance;   /* mfMinDistance, mfMaxDistance (un-scaled, see orbfe_map_point) */
+  int32_t skip;                       /* the reference `continue`s before projecting (NULL, isBad(), already found ...) */
+  float angle;                        /* ORBFE_KF_RELOC: pKF->mvKeysUn[i].angle for the rotation histogram */
+  uint8_t desc[32];                   /* GetDescriptor() */
+} orbfe_kf_point;
+typedef struct orbfe_kf_result {      /* 24 bytes */
+  int32_t best_idx;                   /* keypoint of the first minimum distance among the gated candidates, -1 = none.
+                                         ORBFE_KF_LOOP / RELOC: the keypoint this point was ASSIGNED to (-1 = none / removed) */
+  int32_t best_dist;                  /* its distance (256 = none); LOOP / RELOC: unspecified */
+  int32_t level;                      /* nPredictedLevel, -1 when a gate rejected the point */
+  float u, v, u_r;                    /* the projection (u_r = u - mbf * invz) */
+} orbfe_kf_result;
+/* keyframe = mvKeysUn / mDescriptors / mvuRight / bounds of the KeyFrame (Frame for ORBFE_KF_RELOC) searched in;
+ * inv_level_sigma2 = mvInvLevelSigma2 (ORBFE_KF_FUSE, n_levels floats, else NULL).  blocked (LOOP: vpMatched[idx] != NULL;
+ * RELOC: CurrentFrame.mvpMapPoints[idx] != NULL) is read and updated, NULL for the other modes.  check_orientation and
+ * max_dist (TH_LOW / ORBdist) apply to LOOP / RELOC.  *n_matches: LOOP / RELOC = the reference's return value, otherwise the
+ * number of points with a candidate.  HOST pointers, synchronous. */
+int orbfe_kf_search(const orbfe_frame_view* keyframe, const float* inv_level_sigma2, const orbfe_kf_camera* cam,
+                    const orbfe_kf_point* points, int n_points, int mode, int check_orientation, int max_dist,
+                    uint8_t* blocked, orbfe_kf_result* results, int* n_matches);
+
 /* SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo) (L/src/ORBmatcher.cc:614-764)
  * with CheckDistEpipolarLine (:137-159).  The epipole (:622-630) is computed by the caller. */
 typedef struct orbfe_epipolar {

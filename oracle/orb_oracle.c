@@ -1314,6 +1314,207 @@ void oo_proj_best(const oo_frame* kf, const oo_query* q, int nq, int gate, const
   free(vIndices);
 }
 
+/* ---- whole-function restatements of the keyframe-rate projection searches -------------------------------------------------
+ * Each function below walks its candidate points in order exactly as the reference loop does and returns, per point, the
+ * keypoint the reference would act on (best_idx, -1 = none), its distance, the predicted level and the projection.  The pose
+ * algebra in front of the loops (decomposing Scw, composing sR21 / t21) and the map bookkeeping behind them (Replace,
+ * AddObservation, AddMapPoint, vpReplacePoint, the mutual check) are the caller's: they act on SLAM objects.
+ * cv::Mat expressions as in oo_is_in_frustum: A*x + b = small-matrix gemm (float dot, double epilogue), cv::norm and
+ * Mat::dot accumulate in double. */
+static void kf_gemm3(const float* R, const float* x, const float* t, float* out) {
+  for (int r = 0; r < 3; r++) {
+    const float* a = R + 3 * r;
+    const float d = a[0] * x[0] + a[1] * x[1] + a[2] * x[2];
+    out[r] = (float)((double)d * 1.0 + (double)t[r] * 1.0);
+  }
+}
+static float kf_norm3(const float* v) {
+  double s = 0;
+  for (int k = 0; k < 3; k++) { const double e = (double)v[k]; s += e * e; }
+  return (float)sqrt(s);
+}
+static int kf_is_in_image(const oo_kf_camera* c, float x, float y) {   /* KeyFrame::IsInImage, L/src/KeyFrame.cc:569-571 */
+  return x >= c->min_x && x < c->max_x && y >= c->min_y && y < c->max_y;
+}
+static void kf_res_init(oo_kf_result* r) { r->best_idx = -1; r->best_dist = 256; r->level = -1; r->u = r->v = r->u_r = 0.f; }
+
+/* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th): L/src/ORBmatcher.cc:781-884 (the loop body up to the map update) */
+void oo_fuse(const oo_frame* kf, const float* inv_level_sigma2, const oo_kf_camera* cam, const oo_kf_point* pts, int n, oo_kf_result* res) {
+  int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (kf->n ? kf->n : 1));
+  for (int i = 0; i < n; i++) {
+    kf_res_init(&res[i]);
+    const oo_kf_point* pMP = &pts[i];
+    if (pMP->skip) continue;                                  /* !pMP, isBad(), IsInKeyFrame(pKF)  :784-788 */
+    float p3Dc[3];
+    kf_gemm3(cam->R, pMP->pos, cam->t, p3Dc);                 /* Rcw * p3Dw + tcw  :791 */
+    if (p3Dc[2] < 0.0f) continue;                             /* :794 */
+    const float invz = 1 / p3Dc[2];                           /* :797 */
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    const float u = cam->fx * x + cam->cx, v = cam->fy * y + cam->cy;
+    if (!kf_is_in_image(cam, u, v)) continue;                 /* :805 */
+    const float ur = u - cam->mbf * invz;                     /* :808 */
+    const float maxDistance = 1.2f * pMP->max_distance, minDistance = 0.8f * pMP->min_distance;
+    float PO[3];
+    for (int k = 0; k < 3; k++) PO[k] = pMP->pos[k] - cam->Ow[k];
+    const float dist3D = kf_norm3(PO);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;   /* :816 */
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)pMP->normal[k];
+    if (dot < 0.5 * dist3D) continue;                         /* :822 */
+    const int nPredictedLevel = oo_predict_scale(pMP->max_distance, dist3D, cam->log_scale_factor, cam->n_levels);
+    const float radius = cam->th * cam->scale_factors[nPredictedLevel];
+    res[i].level = nPredictedLevel; res[i].u = u; res[i].v = v; res[i].u_r = ur;
+    const int nI = oo_features_in_area(kf, u, v, radius, -1, -1, vIndices);   /* KeyFrame::GetFeaturesInArea: no level filter */
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < nI; k++) {
+      const int idx = vIndices[k];
+      const oo_keypoint* kp = &kf->keys_un[idx];
+      const int kpLevel = kp->octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (kf->u_right && kf->u_right[idx] >= 0) {             /* stereo reprojection error :845-856 */
+        const float ex = u - kp->x, ey = v - kp->y, er = ur - kf->u_right[idx];
+        const float e2 = ex * ex + ey * ey + er * er;
+        if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+      } else {
+        const float ex = u - kp->x, ey = v - kp->y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+      }
+      const int dist = oo_descriptor_distance(pMP->desc, kf->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    res[i].best_idx = bestIdx; res[i].best_dist = bestIdx >= 0 ? bestDist : 256;
+  }
+  free(vIndices);
+}
+
+/* Fuse(KeyFrame*, cv::Mat Scw, ...) :932-1008 (mode 0) and one direction of SearchBySim3 :1063-1146 / :1149-1222 (mode 1) */
+static void kf_independent(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, int sim3, oo_kf_result* res) {
+  int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (kf->n ? kf->n : 1));
+  for (int i = 0; i < n; i++) {
+    kf_res_init(&res[i]);
+    const oo_kf_point* pMP = &pts[i];
+    if (pMP->skip) continue;
+    float p3Dc[3];
+    kf_gemm3(cam->R, pMP->pos, cam->t, p3Dc);
+    if (sim3) {                                               /* p3Dc2 = sR21 * p3Dc1 + t21  :1076 */
+      float p2[3];
+      kf_gemm3(cam->R2, p3Dc, cam->t2, p2);
+      p3Dc[0] = p2[0]; p3Dc[1] = p2[1]; p3Dc[2] = p2[2];
+    }
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = (float)(1.0 / p3Dc[2]);                /* `1.0 / z`: double division  :945, :1083 */
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    const float u = cam->fx * x + cam->cx, v = cam->fy * y + cam->cy;
+    if (!kf_is_in_image(cam, u, v)) continue;
+    const float maxDistance = 1.2f * pMP->max_distance, minDistance = 0.8f * pMP->min_distance;
+    float dist3D;
+    if (sim3) {
+      dist3D = kf_norm3(p3Dc);                                /* cv::norm(p3Dc2)  :1097 */
+    } else {
+      float PO[3];
+      for (int k = 0; k < 3; k++) PO[k] = pMP->pos[k] - cam->Ow[k];
+      dist3D = kf_norm3(PO);
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      double dot = 0;
+      for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)pMP->normal[k];
+      if (dot < 0.5 * dist3D) continue;                       /* :969 */
+    }
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const int nPredictedLevel = oo_predict_scale(pMP->max_distance, dist3D, cam->log_scale_factor, cam->n_levels);
+    const float radius = cam->th * cam->scale_factors[nPredictedLevel];
+    res[i].level = nPredictedLevel; res[i].u = u; res[i].v = v; res[i].u_r = u - cam->mbf * invz;
+    const int nI = oo_features_in_area(kf, u, v, radius, -1, -1, vIndices);
+    int bestDist = 0x7fffffff, bestIdx = -1;                  /* INT_MAX  :988, :1120 */
+    for (int k = 0; k < nI; k++) {
+      const int idx = vIndices[k];
+      const int kpLevel = kf->keys_un[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist = oo_descriptor_distance(pMP->desc, kf->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    res[i].best_idx = bestIdx; res[i].best_dist = bestIdx >= 0 ? bestDist : 256;
+  }
+  free(vIndices);
+}
+void oo_fuse_sim3(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, oo_kf_result* res) { kf_independent(kf, cam, pts, n, 0, res); }
+void oo_search_by_sim3_dir(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, oo_kf_result* res) { kf_independent(kf, cam, pts, n, 1, res); }
+
+/* SearchByProjection(KeyFrame*, cv::Mat Scw, vpPoints, vpMatched, th): L/src/ORBmatcher.cc:298-383.  matched[idx] != 0 <=>
+ * vpMatched[idx] != NULL (updated).  res[i].best_idx = the keypoint point i was written to.  Returns nmatches. */
+int oo_search_by_projection_loop(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, int th_low, uint8_t* matched,
+                                 oo_kf_result* res) {
+  int nmatches = 0;
+  int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (kf->n ? kf->n : 1));
+  for (int i = 0; i < n; i++) {
+    kf_res_init(&res[i]);
+    const oo_kf_point* pMP = &pts[i];
+    if (pMP->skip) continue;                                  /* isBad() || spAlreadyFound.count(pMP)  :302 */
+    float p3Dc[3];
+    kf_gemm3(cam->R, pMP->pos, cam->t, p3Dc);
+    if (p3Dc[2] < 0.0) continue;
+    const float invz = 1 / p3Dc[2];                           /* :317 */
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    const float u = cam->fx * x + cam->cx, v = cam->fy * y + cam->cy;
+    if (!kf_is_in_image(cam, u, v)) continue;
+    const float maxDistance = 1.2f * pMP->max_distance, minDistance = 0.8f * pMP->min_distance;
+    float PO[3];
+    for (int k = 0; k < 3; k++) PO[k] = pMP->pos[k] - cam->Ow[k];
+    const float dist = kf_norm3(PO);
+    if (dist < minDistance || dist > maxDistance) continue;
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)pMP->normal[k];
+    if (dot < 0.5 * dist) continue;
+    const int nPredictedLevel = oo_predict_scale(pMP->max_distance, dist, cam->log_scale_factor, cam->n_levels);
+    const float radius = cam->th * cam->scale_factors[nPredictedLevel];
+    res[i].level = nPredictedLevel; res[i].u = u; res[i].v = v; res[i].u_r = u - cam->mbf * invz;
+    const int nI = oo_features_in_area(kf, u, v, radius, -1, -1, vIndices);
+    if (nI == 0) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < nI; k++) {
+      const int idx = vIndices[k];
+      if (matched[idx]) continue;                             /* :358 */
+      const int kpLevel = kf->keys_un[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int d = oo_descriptor_distance(pMP->desc, kf->desc + (size_t)idx * 32);
+      if (d < bestDist) { bestDist = d; bestIdx = idx; }
+    }
+    if (bestDist <= th_low) {                                 /* :377 */
+      matched[bestIdx] = 1;
+      res[i].best_idx = bestIdx; res[i].best_dist = bestDist;
+      nmatches++;
+    }
+  }
+  free(vIndices);
+  return nmatches;
+}
+
+/* the projection part of SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist): L/src/ORBmatcher.cc:1403-1437
+ * -> the query oo_search_by_projection_keyframe consumes (valid = 0 where the reference `continue`s) */
+void oo_reloc_query(const oo_kf_camera* cam, const oo_kf_point* pMP, oo_query* q) {
+  memset(q, 0, sizeof(*q));
+  if (pMP->skip) return;
+  float x3Dc[3];
+  kf_gemm3(cam->R, pMP->pos, cam->t, x3Dc);
+  const float xc = x3Dc[0], yc = x3Dc[1];
+  const float invzc = (float)(1.0 / x3Dc[2]);
+  const float u = cam->fx * xc * invzc + cam->cx;
+  const float v = cam->fy * yc * invzc + cam->cy;
+  if (u < cam->min_x || u > cam->max_x) return;
+  if (v < cam->min_y || v > cam->max_y) return;
+  float PO[3];
+  for (int k = 0; k < 3; k++) PO[k] = pMP->pos[k] - cam->Ow[k];
+  const float dist3D = kf_norm3(PO);
+  const float maxDistance = 1.2f * pMP->max_distance, minDistance = 0.8f * pMP->min_distance;
+  if (dist3D < minDistance || dist3D > maxDistance) return;
+  const int nPredictedLevel = oo_predict_scale(pMP->max_distance, dist3D, cam->log_scale_factor, cam->n_levels);
+  q->u = u; q->v = v; q->u_r = u - cam->mbf * invzc;
+  q->radius = cam->th * cam->scale_factors[nPredictedLevel];
+  q->min_level = nPredictedLevel - 1; q->max_level = nPredictedLevel + 1;
+  q->valid = 1; q->blocks = 1; q->angle = pMP->angle;
+  memcpy(q->desc, pMP->desc, 32);
+}
+
 /* ORBmatcher::CheckDistEpipolarLine: L/src/ORBmatcher.cc:137-159 */
 static int check_dist_epipolar_line(const oo_keypoint* kp1, const oo_keypoint* kp2, const float* F12, const float* level_sigma2) {
   const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];

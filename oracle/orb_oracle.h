@@ -173,6 +173,22 @@ void oo_local_point_query(const oo_frustum* fr, const oo_map_point* mp, const oo
 int oo_search_local_points(const oo_frame* f, const oo_frustum* fr, const oo_map_point* mp, int n, float th, float nnratio,
                            oo_track* track, uint8_t* blocked, int32_t* assigned, int* n_to_match);
 
+/* ---- keyframe-rate projection searches, whole loops (ORBmatcher.cc:766-1245, 275-386, 1385-1504) */
+typedef struct oo_kf_camera {
+  float R[9], t[3], R2[9], t2[3], Ow[3];
+  float fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y, log_scale_factor;
+  int32_t n_levels;
+  float th, scale_factors[OO_MAX_LEVELS];
+} oo_kf_camera;
+typedef struct oo_kf_point { float pos[3], normal[3], min_distance, max_distance; int32_t skip; float angle; uint8_t desc[32]; } oo_kf_point;
+typedef struct oo_kf_result { int32_t best_idx, best_dist, level; float u, v, u_r; } oo_kf_result;
+void oo_fuse(const oo_frame* kf, const float* inv_level_sigma2, const oo_kf_camera* cam, const oo_kf_point* pts, int n, oo_kf_result* res);
+void oo_fuse_sim3(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, oo_kf_result* res);
+void oo_search_by_sim3_dir(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, oo_kf_result* res);
+int oo_search_by_projection_loop(const oo_frame* kf, const oo_kf_camera* cam, const oo_kf_point* pts, int n, int th_low, uint8_t* matched,
+                                 oo_kf_result* res);
+void oo_reloc_query(const oo_kf_camera* cam, const oo_kf_point* pMP, oo_query* q);
+
 /* ---- motion-model tracking: Frame::UnprojectStereo (Frame.cc:668-679) and the projection part of
  * SearchByProjection(cur, last) (ORBmatcher.cc:1257-1308) */
 typedef struct oo_unproject_cam { float Rwc[9], Ow[3], cx, cy, invfx, invfy; } oo_unproject_cam;

@@ -48,6 +48,19 @@ TRACK_POSE_DTYPE = np.dtype(
 assert UNPROJECT_CAM_DTYPE.itemsize == 64 and LAST_POINT_DTYPE.itemsize == 60 and TRACK_POSE_DTYPE.itemsize == 160
 assert FRUSTUM_DTYPE.itemsize == 168 and MAP_POINT_DTYPE.itemsize == 72 and TRACK_DTYPE.itemsize == 24
 BF_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_dist", "<i4")])
+# orbfe_kf_camera / orbfe_kf_point / orbfe_kf_result: the whole-function keyframe-rate searches (orbfe_kf_search)
+KF_CAMERA_DTYPE = np.dtype(
+    [("R", "<f4", (9,)), ("t", "<f4", (3,)), ("R2", "<f4", (9,)), ("t2", "<f4", (3,)), ("Ow", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"),
+     ("cx", "<f4"), ("cy", "<f4"), ("mbf", "<f4"), ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"),
+     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("th", "<f4"), ("scale_factors", "<f4", (16,))]
+)
+KF_POINT_DTYPE = np.dtype(
+    [("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"), ("skip", "<i4"),
+     ("angle", "<f4"), ("desc", "u1", (32,))]
+)
+KF_RESULT_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("level", "<i4"), ("u", "<f4"), ("v", "<f4"), ("u_r", "<f4")])
+assert KF_CAMERA_DTYPE.itemsize == 220 and KF_POINT_DTYPE.itemsize == 72 and KF_RESULT_DTYPE.itemsize == 24
+KF_FUSE, KF_FUSE_SIM3, KF_SIM3, KF_LOOP, KF_RELOC = 1, 2, 3, 4, 5
 
 
 class OrbfeError(RuntimeError):
@@ -82,7 +95,7 @@ EXPORTS = [
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
-    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
+    "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_kf_search", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
     "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow",
@@ -169,6 +182,7 @@ def lib():
     L.orbfe_bow_transform_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.orbfe_compute_bow.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, pi, vp, vp, pi]
     L.orbfe_proj_best.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, ci, vp, vp]
+    L.orbfe_kf_search.argtypes = [C.POINTER(FrameView), vp, vp, vp, ci, ci, ci, ci, vp, vp, pi]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp, pi]
     L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]

@@ -267,6 +267,104 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
   for (int i = tid; i < cnt * Q_DW; i += 256) out[i] = rec[i];
 }
 
+// ---- projection prologue of Fuse / Fuse(Sim3) / SearchBySim3 / SearchByProjection(KF,Scw) / SearchByProjection(Frame,KF,...)
+// (L/src/ORBmatcher.cc:785-816, 925-977, 1075-1113 & 1155-1192, 296-345, 1406-1437): thread per candidate map point.  Every
+// float expression is written in the operation order of the mode's reference lines (`1 / z` is a float division, `1.0 / z` a
+// double one; Fuse multiplies X * invz first, the relocalisation search fx * xc first); cv::Mat products are the small-matrix
+// gemm (float dot, double alpha/beta epilogue), cv::norm / Mat::dot accumulate in double -- as in frustum_queries_kernel.
+static_assert(sizeof(orbfe_kf_camera) == 220 && sizeof(orbfe_kf_point) == 72 && sizeof(orbfe_kf_result) == 24, "record layout");
+__global__ __launch_bounds__(256) void kf_queries_kernel(const orbfe_kf_camera* __restrict__ camp, const orbfe_kf_point* __restrict__ points,
+                                                         int n, int mode, orbfe_query* __restrict__ queries,
+                                                         orbfe_kf_result* __restrict__ results) {
+  __shared__ orbfe_kf_camera cam;
+  if (threadIdx.x < (int)(sizeof(orbfe_kf_camera) / 4))
+    reinterpret_cast<uint32_t*>(&cam)[threadIdx.x] = reinterpret_cast<const uint32_t*>(camp)[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const orbfe_kf_point mp = points[i];
+  orbfe_query q;
+  uint32_t* qw = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+  for (int j = 0; j < Q_DW; j++) qw[j] = 0u;
+  orbfe_kf_result res;
+  res.best_idx = -1; res.best_dist = 256; res.level = -1; res.u = 0.f; res.v = 0.f; res.u_r = 0.f;
+  if (!mp.skip) {
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float t = cam.R[3 * r] * mp.pos[0] + cam.R[3 * r + 1] * mp.pos[1] + cam.R[3 * r + 2] * mp.pos[2];
+      Pc[r] = (float)((double)t * 1.0 + (double)cam.t[r] * 1.0);
+    }
+    if (mode == ORBFE_KF_SIM3) {   // p3Dc2 = sR21 * p3Dc1 + t21 (:1075) / p3Dc1 = sR12 * p3Dc2 + t12 (:1155)
+      float P2[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float t = cam.R2[3 * r] * Pc[0] + cam.R2[3 * r + 1] * Pc[1] + cam.R2[3 * r + 2] * Pc[2];
+        P2[r] = (float)((double)t * 1.0 + (double)cam.t2[r] * 1.0);
+      }
+      Pc[0] = P2[0]; Pc[1] = P2[1]; Pc[2] = P2[2];
+    }
+    bool ok = mode == ORBFE_KF_RELOC || !(Pc[2] < 0.0f);   // "Depth must be positive"; the relocalisation search has no such test
+    float invz = 0.f, u = 0.f, v = 0.f;
+    if (ok) {
+      if (mode == ORBFE_KF_FUSE || mode == ORBFE_KF_LOOP) invz = 1.0f / Pc[2];        // `1 / z`   (:797, :317)
+      else invz = (float)(1.0 / (double)Pc[2]);                                        // `1.0 / z` (:945, :1083, :1163, :1413)
+      if (mode == ORBFE_KF_RELOC) {                                                    // fx * xc * invzc + cx (:1415-1416)
+        u = cam.fx * Pc[0] * invz + cam.cx;
+        v = cam.fy * Pc[1] * invz + cam.cy;
+        ok = !(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y);   // :1418-1421
+      } else {                                                                         // x = X * invz; u = fx * x + cx
+        const float x = Pc[0] * invz, y = Pc[1] * invz;
+        u = cam.fx * x + cam.cx;
+        v = cam.fy * y + cam.cy;
+        ok = u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y;       // KeyFrame::IsInImage (KeyFrame.cc:569-571)
+      }
+    }
+    if (ok) {
+      const float maxDistance = 1.2f * mp.max_distance, minDistance = 0.8f * mp.min_distance;   // Get{Max,Min}DistanceInvariance
+      double s = 0.0, dot = 0.0;
+      if (mode == ORBFE_KF_SIM3) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) s += (double)Pc[k] * (double)Pc[k];   // cv::norm(p3Dc2) (:1097)
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float PO = mp.pos[k] - cam.Ow[k];
+          s += (double)PO * (double)PO;
+          dot += (double)PO * (double)mp.normal[k];
+        }
+      }
+      const float dist3D = (float)sqrt(s);
+      ok = !(dist3D < minDistance || dist3D > maxDistance);
+      if (ok && (mode == ORBFE_KF_FUSE || mode == ORBFE_KF_FUSE_SIM3 || mode == ORBFE_KF_LOOP))
+        ok = !(dot < 0.5 * (double)dist3D);   // "Viewing angle must be less than 60 deg": PO.dot(Pn) < 0.5 * dist
+      if (ok) {
+        const int level = predict_scale(mp.max_distance, dist3D, cam.log_scale_factor, cam.n_levels);
+        q.u = u; q.v = v;
+        q.u_r = u - cam.mbf * invz;   // Fuse :808
+        q.radius = cam.th * cam.scale_factors[level];
+        q.min_level = level - 1;
+        q.max_level = mode == ORBFE_KF_RELOC ? level + 1 : level;
+        q.valid = 1;
+        q.blocks = 1;
+        q.angle = mp.angle;
+#pragma unroll
+        for (int j = 0; j < 8; j++) reinterpret_cast<uint32_t*>(q.desc)[j] = reinterpret_cast<const uint32_t*>(mp.desc)[j];
+        res.level = level; res.u = u; res.v = v; res.u_r = q.u_r;
+      }
+    }
+  }
+  queries[i] = q;
+  results[i] = res;
+}
+
+void orbfe_launch_kf_queries(const orbfe_kf_camera* cam, const orbfe_kf_point* points, int n, int mode, orbfe_query* queries,
+                             orbfe_kf_result* results, hipStream_t s) {
+  if (n < 1) return;
+  hipLaunchKernelGGL(kf_queries_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cam, points, n, mode, queries, results);
+}
+
 void orbfe_launch_unproject_stereo(const orbfe_keypoint* kps, const uint8_t* desc, const int32_t* n, const float* depth, int cap,
                                    const orbfe_unproject_cam* cams, int observed, orbfe_last_point* points, int n_frames,
                                    hipStream_t s) {

@@ -80,6 +80,8 @@ void orbfe_launch_track_queries(const orbfe_track_pose* poses, const orbfe_last_
 void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,
                                   int p_cap, float th, float viewing_cos_limit, orbfe_track* track, orbfe_query* queries,
                                   int32_t* n_to_match, int n_frames, hipStream_t s);
+void orbfe_launch_kf_queries(const orbfe_kf_camera* cam, const orbfe_kf_point* points, int n, int mode, orbfe_query* queries,
+                             orbfe_kf_result* results, hipStream_t s);
 void orbfe_launch_bow(const BowParams& p, int n_pairs, int max_countB, hipStream_t s);
 struct TriParams {
   BowParams b;   // pairs, descriptors, idx arrays, matchA, counters, push arrays, check_ori, sequential, n_pairs (validA / validB: candidate masks)

@@ -594,6 +594,95 @@ extern "C" int orbfe_proj_best(const orbfe_frame_view* f, const orbfe_query* q, 
   return ORBFE_OK;
 }
 
+// Fuse / Fuse(Sim3) / SearchBySim3 / SearchByProjection(KF,Scw) / SearchByProjection(Frame,KF,...) from the projection on
+// (L/src/ORBmatcher.cc:766-1245, 275-386, 1385-1504): prologue kernel -> queries in HBM -> window search, host pointers
+extern "C" int orbfe_kf_search(const orbfe_frame_view* f, const float* inv_level_sigma2, const orbfe_kf_camera* cam,
+                               const orbfe_kf_point* points, int n_points, int mode, int check_orientation, int max_dist,
+                               uint8_t* blocked, orbfe_kf_result* results, int* n_matches) {
+  const bool seq = mode == ORBFE_KF_LOOP || mode == ORBFE_KF_RELOC;   // earlier points block later ones
+  if (!frame_ok(f) || !cam || n_points < 0 || (n_points > 0 && (!points || !results)) || !n_matches || mode < ORBFE_KF_FUSE ||
+      mode > ORBFE_KF_RELOC || cam->n_levels < 1 || cam->n_levels > ORBFE_MAX_LEVELS || (mode == ORBFE_KF_FUSE && !inv_level_sigma2) ||
+      (seq && f->n > 0 && !blocked))
+    return ORBFE_ERR_INVALID;
+  *n_matches = 0;
+  for (int i = 0; i < n_points; i++) {
+    results[i].best_idx = -1; results[i].best_dist = 256; results[i].level = -1;
+    results[i].u = results[i].v = results[i].u_r = 0.f;
+  }
+  if (n_points == 0) return ORBFE_OK;
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  if ((rc = mb_alloc(m->lp_pts, sizeof(orbfe_kf_point) * (size_t)n_points))) return rc;
+  if ((rc = mb_alloc(m->lp_track, sizeof(orbfe_kf_result) * (size_t)n_points))) return rc;
+  if ((rc = mb_alloc(m->lp_fr, sizeof(orbfe_kf_camera)))) return rc;
+  if ((rc = mb_alloc(m->lp_q, sizeof(orbfe_query) * (size_t)n_points))) return rc;
+  if ((rc = mb_alloc(m->lp_cnt, 64))) return rc;
+  HIPCHK(hipMemcpyAsync(m->lp_pts.p, points, sizeof(orbfe_kf_point) * (size_t)n_points, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(m->lp_fr.p, cam, sizeof(orbfe_kf_camera), hipMemcpyHostToDevice, s));
+  if ((rc = stage_host(m, f, nullptr, 0, s))) return rc;
+  const int32_t np = n_points;
+  HIPCHK(hipMemcpyAsync(m->h_nq.p, &np, 4, hipMemcpyHostToDevice, s));
+  orbfe_launch_kf_queries((const orbfe_kf_camera*)m->lp_fr.p, (const orbfe_kf_point*)m->lp_pts.p, n_points, mode,
+                          (orbfe_query*)m->lp_q.p, (orbfe_kf_result*)m->lp_track.p, s);
+  HIPCHK(hipMemcpyAsync(results, m->lp_track.p, sizeof(orbfe_kf_result) * (size_t)n_points, hipMemcpyDeviceToHost, s));
+  if (f->n == 0) {
+    HIPCHK(hipStreamSynchronize(s));
+    return launch_ok();
+  }
+  const int cap = f->n;
+  if (!seq) {
+    if ((rc = ensure_proj_scratch(m, 1, cap, n_points))) return rc;
+    float inv16[ORBFE_MAX_LEVELS] = {0};
+    const int gate = mode == ORBFE_KF_FUSE ? ORBFE_GATE_FUSE_CHI2 : ORBFE_GATE_NONE;
+    if (gate == ORBFE_GATE_FUSE_CHI2) {
+      memcpy(inv16, inv_level_sigma2, sizeof(float) * cam->n_levels);
+      HIPCHK(hipMemcpyAsync(m->lp_cnt.p, inv16, sizeof(inv16), hipMemcpyHostToDevice, s));
+    }
+    FrameBatch fb;
+    fill_frame_batch(m, fb, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
+                     (f->u_right && gate == ORBFE_GATE_FUSE_CHI2) ? (const float*)m->h_ur.p : nullptr, cap, f->min_x, f->max_x,
+                     f->min_y, f->max_y);
+    QueryBatch qb{(const orbfe_query*)m->lp_q.p, (const int32_t*)m->h_nq.p, n_points};
+    orbfe_launch_grid_build(fb, 1, s);
+    orbfe_launch_proj_best(fb, qb, gate, (const float*)m->lp_cnt.p, (int32_t*)m->n_cand.p, (int32_t*)m->push_idx.p, 1, s);
+    if ((rc = launch_ok())) return rc;
+    std::vector<int32_t> bi((size_t)n_points), bd((size_t)n_points);
+    HIPCHK(hipMemcpyAsync(bi.data(), m->n_cand.p, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(bd.data(), m->push_idx.p, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int cnt = 0;
+    for (int i = 0; i < n_points; i++) {
+      results[i].best_idx = bi[i];
+      results[i].best_dist = bd[i];
+      cnt += bi[i] >= 0;
+    }
+    *n_matches = cnt;
+    return ORBFE_OK;
+  }
+  // sequential modes: the greedy resolver of SearchByProjection(cur, last) with the caller's distance bound, no stereo gate
+  std::vector<int32_t> assigned((size_t)cap, -2);
+  HIPCHK(hipMemcpyAsync(m->h_blocked.p, blocked, cap, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(m->h_assigned.p, assigned.data(), sizeof(int32_t) * cap, hipMemcpyHostToDevice, s));
+  rc = proj_enqueue(m, 1, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p, nullptr, cap,
+                    f->min_x, f->max_x, f->min_y, f->max_y, (const orbfe_query*)m->lp_q.p, (const int32_t*)m->h_nq.p, n_points, 1,
+                    0.f, mode == ORBFE_KF_RELOC ? check_orientation : 0, (uint8_t*)m->h_blocked.p, (int32_t*)m->h_assigned.p,
+                    (int32_t*)m->h_nm.p, true, s, max_dist);
+  if (rc) return rc;
+  int32_t nm = 0;
+  HIPCHK(hipMemcpyAsync(blocked, m->h_blocked.p, cap, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(assigned.data(), m->h_assigned.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&nm, m->h_nm.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int j = 0; j < cap; j++)
+    if (assigned[j] >= 0 && assigned[j] < n_points) results[assigned[j]].best_idx = j;
+  *n_matches = nm;
+  return ORBFE_OK;
+}
+
 // SearchForTriangulation (L/src/ORBmatcher.cc:614-764), host pointers, synchronous
 extern "C" int orbfe_search_for_triangulation(const orbfe_keypoint* keysA, const uint8_t* descA, const float* u_rightA,
                                               const uint8_t* has_mpA, int nA, const orbfe_featvec_node* nodesA, int n_nodesA,

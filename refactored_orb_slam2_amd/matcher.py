@@ -61,9 +61,9 @@ def make_frustum(Rcw, tcw, fx, fy, cx, cy, mbf, bounds, scale_factor, n_levels) 
     fr["min_x"], fr["max_x"], fr["min_y"], fr["max_y"] = [np.float32(b) for b in bounds]
     fr["log_scale_factor"] = np.log(np.float32(scale_factor), dtype=np.float32)
     fr["n_levels"] = n_levels
-    sf = np.ones(8, np.float32)
+    sf = np.ones(n_levels, np.float32)
     for i in range(1, n_levels):
-        sf[i] = np.float32(sf[i - 1] * np.float32(scale_factor))
+        sf[i] = np.float32(np.float64(sf[i - 1]) * np.float64(np.float32(scale_factor)))   # float * double -> float (ORBextractor.cc:417)
     fr["scale_factors"][0, :len(sf)] = sf
     return fr
 
@@ -182,6 +182,25 @@ class ORBmatcher:
         _lib.check(self._L.orbfe_proj_best(C.byref(keyframe.c), _lib.ptr(q), len(q), 2 if inv is not None else 1, _lib.ptr(inv),
                                            0 if inv is None else len(inv), _lib.ptr(bi), _lib.ptr(bd)), "orbfe_proj_best")
         return bi, bd
+
+    # ---- Fuse / Fuse(Sim3) / SearchBySim3 / SearchByProjection(KF,Scw) / SearchByProjection(Frame,KF,...) from the projection on
+    def KeyFrameSearch(self, keyframe: FrameView, camera: np.ndarray, points: np.ndarray, mode: int, inv_level_sigma2=None,
+                       blocked=None, max_dist: int = TH_LOW):
+        """orbfe_kf_search: projects `points` (KF_POINT_DTYPE) with `camera` (KF_CAMERA_DTYPE), applies the gates of the
+        reference function named by `mode` (_lib.KF_*), predicts the level, queries the keyframe's window and picks the
+        best descriptor -- all on the device.  Returns (n_matches, results [KF_RESULT_DTYPE], blocked)."""
+        cam = np.ascontiguousarray(camera, _lib.KF_CAMERA_DTYPE).reshape(-1)[:1]
+        pts = np.ascontiguousarray(points, _lib.KF_POINT_DTYPE)
+        res = np.zeros(len(pts), _lib.KF_RESULT_DTYPE)
+        inv = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        blk = None
+        if mode in (_lib.KF_LOOP, _lib.KF_RELOC):
+            blk = np.zeros(max(keyframe.n, 1), np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8).copy()
+        nm = C.c_int(0)
+        _lib.check(self._L.orbfe_kf_search(C.byref(keyframe.c), _lib.ptr(inv), _lib.ptr(cam), _lib.ptr(pts), len(pts), int(mode),
+                                           int(self.mbCheckOrientation), int(max_dist), _lib.ptr(blk), _lib.ptr(res), C.byref(nm)),
+                   "orbfe_kf_search")
+        return nm.value, res, (None if blk is None else blk[:keyframe.n])
 
     # ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): ORBmatcher.cc:388-492
     def SearchForInitialization(self, f1: FrameView, f2: FrameView, prev_matched: np.ndarray, windowSize: int = 10):

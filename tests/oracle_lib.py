@@ -306,6 +306,55 @@ def descriptor_distance(a, b) -> int:
     return lib().oo_descriptor_distance(_p(a), _p(b))
 
 
+KF_CAMERA_DTYPE = np.dtype(
+    [("R", "<f4", (9,)), ("t", "<f4", (3,)), ("R2", "<f4", (9,)), ("t2", "<f4", (3,)), ("Ow", "<f4", (3,)), ("fx", "<f4"), ("fy", "<f4"),
+     ("cx", "<f4"), ("cy", "<f4"), ("mbf", "<f4"), ("min_x", "<f4"), ("max_x", "<f4"), ("min_y", "<f4"), ("max_y", "<f4"),
+     ("log_scale_factor", "<f4"), ("n_levels", "<i4"), ("th", "<f4"), ("scale_factors", "<f4", (16,))]
+)
+KF_POINT_DTYPE = np.dtype(
+    [("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"), ("skip", "<i4"),
+     ("angle", "<f4"), ("desc", "u1", (32,))]
+)
+KF_RESULT_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("level", "<i4"), ("u", "<f4"), ("v", "<f4"), ("u_r", "<f4")])
+assert KF_CAMERA_DTYPE.itemsize == 220 and KF_POINT_DTYPE.itemsize == 72 and KF_RESULT_DTYPE.itemsize == 24
+
+
+def kf_search(frame: "OracleFrame", cam, pts, mode, inv_level_sigma2=None, matched=None, th_low=50, check_orientation=True):
+    """Whole loops of Fuse (mode 1), Fuse(Sim3) (2), one direction of SearchBySim3 (3), SearchByProjection(KF,Scw) (4) and
+    SearchByProjection(Frame,KF,sAlreadyFound,th,ORBdist) (5) on the oracle.  Returns (n, results, matched)."""
+    cam = np.ascontiguousarray(cam, KF_CAMERA_DTYPE).reshape(-1)[:1]
+    pts = np.ascontiguousarray(pts, KF_POINT_DTYPE)
+    res = np.zeros(len(pts), KF_RESULT_DTYPE)
+    L = lib()
+    for fn in (L.oo_fuse, L.oo_fuse_sim3, L.oo_search_by_sim3_dir, L.oo_reloc_query):
+        fn.restype = None
+    L.oo_search_by_projection_loop.restype = C.c_int
+    if mode == 1:
+        inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        L.oo_fuse(C.byref(frame.f), _p(inv), _p(cam), _p(pts), len(pts), _p(res))
+        return int((res["best_idx"] >= 0).sum()), res, None
+    if mode == 2:
+        L.oo_fuse_sim3(C.byref(frame.f), _p(cam), _p(pts), len(pts), _p(res))
+        return int((res["best_idx"] >= 0).sum()), res, None
+    if mode == 3:
+        L.oo_search_by_sim3_dir(C.byref(frame.f), _p(cam), _p(pts), len(pts), _p(res))
+        return int((res["best_idx"] >= 0).sum()), res, None
+    fn_ = len(frame.kps)
+    m = np.zeros(max(fn_, 1), np.uint8) if matched is None else np.ascontiguousarray(matched, np.uint8).copy()
+    if mode == 4:
+        nm = L.oo_search_by_projection_loop(C.byref(frame.f), _p(cam), _p(pts), len(pts), int(th_low), _p(m), _p(res))
+        return nm, res, m[:fn_]
+    q = np.zeros(len(pts), QUERY_DTYPE)
+    for i in range(len(pts)):
+        L.oo_reloc_query(_p(cam), _p(pts[i:i + 1]), _p(q[i:i + 1]))
+    nm, assigned, m2 = frame.search_by_projection_keyframe(q, check_orientation, int(th_low), m[:fn_])
+    res["best_idx"] = -1
+    for j, a in enumerate(assigned):
+        if a >= 0:
+            res["best_idx"][a] = j
+    return nm, res, m2
+
+
 _POPC = np.array([bin(i).count("1") for i in range(256)], np.uint16)
 
 

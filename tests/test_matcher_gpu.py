@@ -198,7 +198,7 @@ def test_search_local_points_edge_cases():
     assert got[2].tobytes() == exp[2].tobytes() and got[0] == exp[0] and got[1] == exp[1]
     # more pyramid levels than the frustum record holds are rejected, not read out of bounds
     from refactored_orb_slam2_amd import _lib
-    bad = fr.copy(); bad["n_levels"] = 9
+    bad = fr.copy(); bad["n_levels"] = 17
     with pytest.raises(_lib.OrbfeError):
         m.SearchLocalPoints(fv, bad, mp)
     # a frame without keypoints still gets its track records
@@ -753,3 +753,139 @@ def test_sequence_driver_on_kitti_layout(tmp_path):
         kp = float(r.stdout.split("keypoints/left image: ")[1].split(",")[0])
         st = float(r.stdout.split("stereo matches/frame: ")[1].split(",")[0])
         assert 1990 < kp < 2030 and st > 800
+
+
+# ------------------------------------------------------------------------------------------------ whole-function A15
+def _kf_scene(seed, nlevels=8, w=640, h=480, nfeat=1000):
+    """A keyframe (extracted synthetic frame with a partial mvuRight), a camera looking at it and candidate map points that
+    project onto its keypoints (plus points that fail each gate: behind the camera, outside the image, out of the distance
+    range, oblique normals)."""
+    from refactored_orb_slam2_amd import _lib
+    from refactored_orb_slam2_amd.matcher import make_frustum
+    ex = ORBextractor(nfeat, 1.2, nlevels, 20, 7)
+    k, d = ex(synth.frame(w, h, seq=seed, f=0))
+    sf = ex.GetScaleFactors(); inv_s2 = ex.GetInverseScaleSigmaSquares()
+    ex.close()
+    rng = np.random.default_rng(seed)
+    R, t = synth.camera_pose(seed)
+    fr = make_frustum(R, t, 517.3, 516.5, 318.6, 255.3, 40.0, (0, w, 0, h), 1.2, nlevels)
+    mp = synth.local_map(k, d, fr, seed + 1, n_extra=300)
+    cam = np.zeros(1, _lib.KF_CAMERA_DTYPE)
+    for f in ("fx", "fy", "cx", "cy", "mbf", "min_x", "max_x", "min_y", "max_y", "log_scale_factor", "n_levels"):
+        cam[f] = fr[f]
+    cam["R"] = fr["Rcw"]; cam["t"] = fr["tcw"]; cam["Ow"] = fr["Ow"]; cam["scale_factors"] = fr["scale_factors"]
+    pts = np.zeros(len(mp), _lib.KF_POINT_DTYPE)
+    for f in ("pos", "normal", "min_distance", "max_distance", "skip", "desc"):
+        pts[f] = mp[f]
+    pts["angle"] = rng.uniform(0, 360, len(pts)).astype(np.float32)
+    ur = np.where(rng.random(len(k)) < 0.5, k["x"] - np.float32(20) + rng.normal(0, 1.5, len(k)).astype(np.float32), -1).astype(np.float32)
+    return k, d, sf, inv_s2, ur, cam, pts, (w, h)
+
+
+def _check_kf(res, ores, fields=("best_idx", "best_dist", "level", "u", "v", "u_r")):
+    for f in fields:
+        np.testing.assert_array_equal(res[f], ores[f], err_msg=f)
+
+
+@pytest.mark.parametrize("nlevels", [8, 12])
+def test_whole_function_fuse_sim3_loop_reloc(nlevels):
+    """ORBmatcher::Fuse, Fuse(Sim3), SearchBySim3 (one direction), SearchByProjection(KF,Scw) and SearchByProjection(Frame,KF,...)
+    from the projection on: prologue kernel + window search on the device == the oracle's restatement of the whole loops
+    (L/src/ORBmatcher.cc:766-1245, 275-386, 1385-1504).  12 levels: no octave is aliased onto the first eight."""
+    from refactored_orb_slam2_amd import _lib
+    k, d, sf, inv_s2, ur, cam, pts, (w, h) = _kf_scene(41 + nlevels, nlevels)
+    kf = FrameView(k, d, 0, w, 0, h, ur); okf = ol.OracleFrame(k, d, sf, 0, w, 0, h, ur)
+    kf_mono = FrameView(k, d, 0, w, 0, h); okf_mono = ol.OracleFrame(k, d, sf, 0, w, 0, h)
+    m = ORBmatcher(0.8, True)
+    # Fuse: th = 3 (LocalMapping) with the chi-square gate, stereo and monocular keyframe
+    cam["th"] = 3.0
+    for view, oview in ((kf, okf), (kf_mono, okf_mono)):
+        n, res, _ = m.KeyFrameSearch(view, cam, pts, _lib.KF_FUSE, inv_level_sigma2=inv_s2)
+        on, ores, _ = ol.kf_search(oview, cam, pts, 1, inv_level_sigma2=inv_s2)
+        _check_kf(res, ores); assert n == on and n > 300
+    # Fuse(Sim3): th = 4 (LoopClosing::SearchAndFuse)
+    cam["th"] = 4.0
+    n, res, _ = m.KeyFrameSearch(kf, cam, pts, _lib.KF_FUSE_SIM3)
+    on, ores, _ = ol.kf_search(okf, cam, pts, 2)
+    _check_kf(res, ores); assert n == on and n > 300
+    # SearchBySim3 direction: second transform = a small similarity, th = 7.5
+    cam3 = cam.copy(); cam3["th"] = 7.5
+    s12 = np.float32(1.03)
+    a = 0.01
+    R12 = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    cam3["R2"] = ((np.float32(1.0 / float(s12))) * R12.T).astype(np.float32).reshape(9)
+    cam3["t2"] = np.array([0.02, -0.01, 0.03], np.float32)
+    n, res, _ = m.KeyFrameSearch(kf, cam3, pts, _lib.KF_SIM3)
+    on, ores, _ = ol.kf_search(okf, cam3, pts, 3)
+    _check_kf(res, ores); assert n == on and n > 200
+    # SearchByProjection(KF, Scw, ...): th = 10, some keypoints already matched
+    cam["th"] = 10.0
+    rng = np.random.default_rng(5)
+    matched0 = (rng.random(len(k)) < 0.15).astype(np.uint8)
+    n, res, blk = m.KeyFrameSearch(kf, cam, pts, _lib.KF_LOOP, blocked=matched0, max_dist=50)
+    on, ores, oblk = ol.kf_search(okf, cam, pts, 4, matched=matched0, th_low=50)
+    _check_kf(res, ores, ("best_idx", "level", "u", "v")); assert n == on and n > 200
+    np.testing.assert_array_equal(blk, oblk)
+    # SearchByProjection(Frame, KF, sAlreadyFound, th, ORBdist): relocalisation, th = 10, ORBdist = 100, rotation histogram
+    for check in (True, False):
+        mm = ORBmatcher(0.9, check)
+        n, res, blk = mm.KeyFrameSearch(kf_mono, cam, pts, _lib.KF_RELOC, blocked=matched0, max_dist=100)
+        on, ores, _ = ol.kf_search(okf_mono, cam, pts, 5, matched=matched0, th_low=100, check_orientation=check)
+        _check_kf(res, ores, ("best_idx",)); assert n == on and n > 100
+
+
+def test_twelve_level_motion_model_and_triangulation():
+    """SearchByProjection(cur, last) through the device query preparation and SearchForTriangulation with a 12-level pyramid:
+    mvScaleFactors[octave] / mvLevelSigma2[octave] are indexed unmasked (L/src/ORBmatcher.cc:1297, 700-745)."""
+    import torch
+    from refactored_orb_slam2_amd import _lib
+    from refactored_orb_slam2_amd.matcher import search_for_triangulation, track_queries_batch, unproject_stereo_batch
+    w, h, nl = 752, 480, 12
+    ex = ORBextractor(1500, 1.2, nl, 20, 7)
+    a, b = synth.sequence(w, h, 2, seq=33)
+    (k0, d0), (k1, d1) = ex.extract_batch([a, b])
+    sf = ex.GetScaleFactors(); s2 = ex.GetScaleSigmaSquares()
+    ex.close()
+    assert k0["octave"].max() >= 9
+    rng = np.random.default_rng(3)
+    # motion model: oracle UnprojectStereo + track queries vs the device kernels
+    cam = np.zeros(1, _lib.UNPROJECT_CAM_DTYPE); pose = np.zeros(1, _lib.TRACK_POSE_DTYPE)
+    cam["Rwc"][0] = np.eye(3, dtype=np.float32).reshape(9); cam["cx"] = 367.4; cam["cy"] = 252.2
+    cam["invfx"] = np.float32(1) / np.float32(435.2); cam["invfy"] = np.float32(1) / np.float32(435.2)
+    pose["Rcw"][0] = np.eye(3, dtype=np.float32).reshape(9); pose["fx"] = 435.2; pose["fy"] = 435.2; pose["cx"] = 365.4; pose["cy"] = 252.2
+    pose["mbf"] = 47.9; pose["max_x"] = w; pose["max_y"] = h; pose["th"] = 7.0; pose["scale_factors"][0, :nl] = sf
+    depth = np.where(rng.random(len(k0)) < 0.8, rng.uniform(2, 30, len(k0)), -1).astype(np.float32)
+    opts = ol.unproject_stereo(cam, k0, d0, depth)
+    oq = ol.track_queries(pose, opts)
+    dev = "cuda"
+    capn = len(k0)
+    tk = torch.from_numpy(k0.view(np.uint8).reshape(1, capn, 28)).to(dev); td = torch.from_numpy(d0.reshape(1, capn, 32)).to(dev)
+    tn = torch.tensor([capn], dtype=torch.int32, device=dev); tdep = torch.from_numpy(depth.reshape(1, capn)).to(dev)
+    tc = torch.from_numpy(cam.view(np.uint8).reshape(1, -1)).to(dev); tp = torch.from_numpy(pose.view(np.uint8).reshape(1, -1)).to(dev)
+    pts = torch.zeros((1, capn, 60), dtype=torch.uint8, device=dev); q = torch.zeros((1, capn, 68), dtype=torch.uint8, device=dev)
+    nq = torch.zeros(1, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        unproject_stereo_batch(tk, td, tn, tdep, tc, 1, pts, s)
+        track_queries_batch(tp, pts, tn, 0, q, nq, s)
+    torch.cuda.synchronize()
+    assert q.cpu().numpy().reshape(-1)[: capn * 68].tobytes() == oq.tobytes()
+    nm, assigned, _ = ORBmatcher(0.9, True).SearchByProjectionFrame(FrameView(k1, d1, 0, w, 0, h), oq)
+    onm, oassigned, _ = ol.OracleFrame(k1, d1, sf, 0, w, 0, h).search_by_projection_frame(oq, True)
+    assert nm == onm and nm > 300
+    np.testing.assert_array_equal(assigned, oassigned)
+    # triangulation: 40 synthetic vocabulary buckets, epipolar gate with 12-level sigma tables
+    ga = {}; gb = {}
+    for i, dd in enumerate(d0):
+        ga.setdefault(int(dd[0]) % 40, []).append(i)
+    for i, dd in enumerate(d1):
+        gb.setdefault(int(dd[0]) % 40, []).append(i)
+    ep = np.zeros(1, _lib.EPIPOLAR_DTYPE)
+    ep["F12"][0] = np.array([0, 0, 0, 0, 0, -1e-2, 0, 1e-2, 0], np.float32)   # horizontal epipolar lines
+    ep["ex"] = -1e6; ep["ey"] = 240.0
+    ep["scale_factors"][0, :nl] = sf; ep["level_sigma2"][0, :nl] = s2
+    has0 = (rng.random(len(k0)) < 0.3).astype(np.uint8); has1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    nmt, mA = search_for_triangulation(k0, d0, None, has0, ga, k1, d1, None, has1, gb, ep, False, True)
+    onmt, omA = ol.search_for_triangulation(k0, d0, None, has0, ga, k1, d1, None, has1, gb, ep.astype(ol.EPIPOLAR_DTYPE), False, True)
+    assert nmt == onmt and nmt > 20
+    np.testing.assert_array_equal(mA, omA)
