@@ -59,7 +59,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
                               cv::OutputArray _descriptors) {
   if (_image.empty()) return;  // :981-982
   cv::Mat image = _image.getMat();
-  if (image.type() != cv::CV_8UC1 || !mpImpl) {
+  if (image.type() != CV_8UC1 || !mpImpl) {
     fprintf(stderr, "ORBextractor: %s\n", mpImpl ? "image must be CV_8UC1" : "no device handle");
     _keypoints.clear();
     _descriptors.release();
@@ -80,7 +80,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
   if (n == 0) {
     _descriptors.release();  // :999-1000
   } else {
-    _descriptors.create(n, 32, cv::CV_8U);
+    _descriptors.create(n, 32, CV_8U);
     cv::Mat d = _descriptors.getMat();
     for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
     _keypoints.resize((size_t)n);
@@ -94,12 +94,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
       int w = 0, h = 0;
       if (orbfe_pyramid_level_size(mpImpl, image.cols, image.rows, level, &w, &h) != ORBFE_OK) return;
       cv::Mat& temp = mvPadded[level];
-      temp.create(h + 2 * EDGE_THRESHOLD, w + 2 * EDGE_THRESHOLD, cv::CV_8U);
-#ifdef ORBFE_HAVE_OPENCV
+      temp.create(h + 2 * EDGE_THRESHOLD, w + 2 * EDGE_THRESHOLD, CV_8U);
       mvImagePyramid[level] = temp(cv::Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, w, h));
-#else
-      mvImagePyramid[level] = temp.roi(EDGE_THRESHOLD, EDGE_THRESHOLD, w, h);
-#endif
       dst[level] = mvImagePyramid[level].ptr(0);
       dstStride[level] = (int)mvImagePyramid[level].step;
     }

@@ -11,9 +11,9 @@
 //   Frame:    N, mvKeysUn, mDescriptors, mvuRight, mvpMapPoints, mvScaleFactors, mnMinX/mnMaxX/mnMinY/mnMaxY
 //   MapPoint: mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel, mTrackViewCos,
 //             isBad(), Observations(), GetDescriptor()
-//   SearchLocalPoints additionally -- Frame: mnId, mRcw, mtcw, mOw, fx, fy, cx, cy, mbf, mfLogScaleFactor, mnScaleLevels;
-//             MapPoint: mnLastFrameSeen, GetWorldPos(), GetNormal(), IncreaseVisible() and two trivial accessors the
-//             reference lacks, GetMinDistance() / GetMaxDistance() returning mfMinDistance / mfMaxDistance
+//   SearchLocalPoints additionally -- Frame: mnId, mTcw, GetCameraCenter(), fx, fy, cx, cy, mbf, mfLogScaleFactor, mnScaleLevels;
+//             MapPoint: mnLastFrameSeen, GetWorldPos(), GetNormal(), IncreaseVisible(), and the protected mfMinDistance /
+//             mfMaxDistance, reached through a pointer to member formed in a derived class (no change to MapPoint.h)
 #pragma once
 #include <stdio.h>
 #include <string.h>
@@ -106,6 +106,15 @@ int SearchByProjectionPoints(FrameT& F, const std::vector<MapPointT*>& vpMapPoin
 template <class MatT>
 inline const float* FloatRow(const MatT& M, int r) { return reinterpret_cast<const float*>(M.ptr(r)); }
 
+// MapPoint::mfMinDistance / mfMaxDistance are protected and only reachable scaled (GetM??DistanceInvariance), while
+// MapPoint::PredictScale divides the UN-scaled value: a pointer to member formed inside a derived class reads them without
+// touching MapPoint.h.  The struct is never instantiated.
+template <class MapPointT>
+struct ProtectedDistances : public MapPointT {
+  static float MapPointT::*Min() { return &ProtectedDistances::mfMinDistance; }
+  static float MapPointT::*Max() { return &ProtectedDistances::mfMaxDistance; }
+};
+
 // Second half of Tracking::SearchLocalPoints (L/src/Tracking.cc:1050-1078): replaces the isInFrustum loop and the
 // SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) call.  Projection, frustum tests, scale prediction, window
 // search and assignment all run on the GPU; the MapPoint fields isInFrustum writes, IncreaseVisible() and
@@ -116,10 +125,11 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
   const size_t n = vpLocalMapPoints.size();
   orbfe_frustum fr;
   memset(&fr, 0, sizeof(fr));
+  const auto Ow = F.GetCameraCenter();   // mOw (mRcw / mtcw are private: read them out of mTcw, Frame.cc:274-279)
   for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) fr.Rcw[3 * r + c] = FloatRow(F.mRcw, r)[c];
-    fr.tcw[r] = FloatRow(F.mtcw, r)[0];
-    fr.Ow[r] = FloatRow(F.mOw, r)[0];
+    for (int c = 0; c < 3; c++) fr.Rcw[3 * r + c] = FloatRow(F.mTcw, r)[c];
+    fr.tcw[r] = FloatRow(F.mTcw, r)[3];
+    fr.Ow[r] = FloatRow(Ow, r)[0];
   }
   fr.fx = F.fx; fr.fy = F.fy; fr.cx = F.cx; fr.cy = F.cy; fr.mbf = F.mbf;
   fr.min_x = F.mnMinX; fr.max_x = F.mnMaxX; fr.min_y = F.mnMinY; fr.max_y = F.mnMaxY;
@@ -136,8 +146,8 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     const auto P = pMP->GetWorldPos();
     const auto Pn = pMP->GetNormal();
     for (int r = 0; r < 3; r++) { e.pos[r] = FloatRow(P, r)[0]; e.normal[r] = FloatRow(Pn, r)[0]; }
-    e.min_distance = pMP->GetMinDistance();
-    e.max_distance = pMP->GetMaxDistance();
+    e.min_distance = pMP->*ProtectedDistances<MapPointT>::Min();
+    e.max_distance = pMP->*ProtectedDistances<MapPointT>::Max();
     e.observed = pMP->Observations() > 0;
     const auto d = pMP->GetDescriptor();
     memcpy(e.desc, d.ptr(0), 32);

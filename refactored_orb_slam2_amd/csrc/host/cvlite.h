@@ -1,6 +1,9 @@
 // cvlite.h -- the handful of OpenCV types the ORB front-end boundary mentions, for builds WITHOUT OpenCV
 // (this image has none).  Layout-compatible with the real ones where the C ABI relies on it (cv::KeyPoint is
 // 7 x 4 bytes).  When OpenCV is available compile with -DORBFE_HAVE_OPENCV and this file is not used.
+// The type codes are global macros, exactly as OpenCV defines them (CV_8UC1 is not a member of namespace cv), so the same
+// source compiles against either.  The host sources restrict themselves to the subset below: Mat(rows, cols, type),
+// create / release / empty / type / rows / cols / step / ptr / at<T>(r, c) / at<T>(i) / row / clone / operator()(Rect).
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -8,9 +11,14 @@
 #include <memory>
 #include <vector>
 
-namespace cv {
+#ifndef CV_8U
+#define CV_8U 0
+#define CV_32F 5
+#define CV_8UC1 0
+#define CV_32FC1 5
+#endif
 
-enum { CV_8U = 0, CV_8UC1 = 0, CV_32F = 5 };
+namespace cv {
 
 template <typename T>
 struct Point_ {
@@ -22,6 +30,12 @@ struct Point_ {
 typedef Point_<float> Point2f;
 typedef Point_<int> Point2i;
 typedef Point_<int> Point;
+
+struct Rect {
+  int x, y, width, height;
+  Rect() : x(0), y(0), width(0), height(0) {}
+  Rect(int x_, int y_, int w_, int h_) : x(x_), y(y_), width(w_), height(h_) {}
+};
 
 struct KeyPoint {
   Point2f pt;
@@ -36,40 +50,66 @@ struct KeyPoint {
 };
 static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint must be 28 bytes");
 
-// Reference-counted 8-bit matrix with an optional ROI view (enough for images, descriptors, pyramid levels).
+// Reference-counted single-channel matrix (CV_8U or CV_32F) with an optional ROI view: enough for images, descriptors,
+// pyramid levels and the small float matrices (poses, points) the matcher reads.
 class Mat {
  public:
   int rows = 0, cols = 0;
-  size_t step = 0;
+  size_t step = 0;   // bytes per row
   uint8_t* data = nullptr;
   Mat() {}
   Mat(int r, int c, int type) { create(r, c, type); }
-  Mat(int r, int c, int /*type*/, void* ext, size_t st = 0) : rows(r), cols(c), step(st ? st : (size_t)c), data((uint8_t*)ext) {}
-  void create(int r, int c, int /*type*/) {
-    if (r == rows && c == cols && buf_ && step == (size_t)c) return;
-    rows = r; cols = c; step = (size_t)c;
-    buf_.reset(new uint8_t[(size_t)r * c + 1], std::default_delete<uint8_t[]>());
+  Mat(int r, int c, int type, void* ext, size_t st = 0) : rows(r), cols(c), data((uint8_t*)ext), type_(type) {
+    step = st ? st : (size_t)c * elemSize();
+  }
+  static Mat zeros(int r, int c, int type) {
+    Mat m(r, c, type);
+    memset(m.data, 0, (size_t)r * m.step);
+    return m;
+  }
+  static Mat eye(int r, int c, int type) {
+    Mat m = zeros(r, c, type);
+    for (int i = 0; i < r && i < c; i++) {
+      if (type == CV_32F) m.at<float>(i, i) = 1.f;
+      else m.at<uint8_t>(i, i) = 1;
+    }
+    return m;
+  }
+  void create(int r, int c, int type) {
+    if (r == rows && c == cols && type == type_ && buf_ && step == (size_t)c * elemSize()) return;
+    rows = r; cols = c; type_ = type; step = (size_t)c * elemSize();
+    buf_.reset(new uint8_t[(size_t)r * step + 4], std::default_delete<uint8_t[]>());
     data = buf_.get();
   }
   void release() { rows = cols = 0; step = 0; data = nullptr; buf_.reset(); }
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-  int type() const { return CV_8UC1; }
-  size_t step1() const { return step; }
-  bool isContinuous() const { return step == (size_t)cols; }
+  int type() const { return type_; }
+  size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+  size_t step1() const { return step / elemSize(); }
+  bool isContinuous() const { return step == (size_t)cols * elemSize(); }
   uint8_t* ptr(int r = 0) { return data + (size_t)r * step; }
   const uint8_t* ptr(int r = 0) const { return data + (size_t)r * step; }
   template <typename T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data + (size_t)r * step); }
   template <typename T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + (size_t)r * step); }
   template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + (size_t)r * step + c * sizeof(T)); }
+  template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + (size_t)r * step + c * sizeof(T)); }
+  // single index: element i of a row or column vector
+  template <typename T> T& at(int i) { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+  template <typename T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
   Mat row(int r) const { Mat m = *this; m.rows = 1; m.data = data + (size_t)r * step; return m; }
-  Mat roi(int x, int y, int w, int h) const { Mat m = *this; m.rows = h; m.cols = w; m.data = data + (size_t)y * step + x; return m; }
+  Mat operator()(const Rect& r) const {
+    Mat m = *this;
+    m.rows = r.height; m.cols = r.width; m.data = data + (size_t)r.y * step + (size_t)r.x * elemSize();
+    return m;
+  }
   Mat clone() const {
-    Mat m(rows, cols, CV_8U);
-    for (int r = 0; r < rows; r++) memcpy(m.ptr(r), ptr(r), (size_t)cols);
+    Mat m(rows, cols, type_);
+    for (int r = 0; r < rows; r++) memcpy(m.ptr(r), ptr(r), (size_t)cols * elemSize());
     return m;
   }
 
  private:
+  int type_ = CV_8U;
   std::shared_ptr<uint8_t> buf_;
 };
 

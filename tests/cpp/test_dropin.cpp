@@ -30,25 +30,26 @@ struct MockMapPoint {
   int Observations() { return nObs; }
   cv::Mat GetDescriptor() { return desc.clone(); }
 };
-// float matrix stored in a cvlite byte Mat (rows x 4*cols bytes): what FloatRow() reads from a CV_32F cv::Mat
 static cv::Mat FloatMat(int rows, int cols, const float* v) {
-  cv::Mat m(rows, cols * 4, cv::CV_8U);
+  cv::Mat m(rows, cols, CV_32F);
   memcpy(m.data, v, sizeof(float) * rows * cols);
   return m;
 }
 struct MockLocalPoint : MockMapPoint {
   long unsigned int mnLastFrameSeen = 0;
-  float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 1}, minD = 0, maxD = 0;
+  float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 1};
   int nVisible = 0;
   cv::Mat GetWorldPos() { return FloatMat(3, 1, pos); }
   cv::Mat GetNormal() { return FloatMat(3, 1, nrm); }
-  float GetMinDistance() { return minD; }
-  float GetMaxDistance() { return maxD; }
   void IncreaseVisible(int n = 1) { nVisible += n; }
+  void SetDistances(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
+ protected:
+  float mfMinDistance = 0, mfMaxDistance = 0;   // protected, as in the reference's MapPoint
 };
 struct MockFrame {
   long unsigned int mnId = 7;
-  cv::Mat mRcw, mtcw, mOw;
+  cv::Mat mTcw, mOw;
+  cv::Mat GetCameraCenter() { return mOw.clone(); }
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mfLogScaleFactor = 0;
   int mnScaleLevels = 8;
   int N = 0;
@@ -72,7 +73,7 @@ struct MockFrameL : MockFrame {
 int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "--nodevice")) {
     ORB_SLAM2::ORBextractor ex(1000, 1.2f, 8, 20, 7);
-    cv::Mat im(64, 64, cv::CV_8U);
+    cv::Mat im(64, 64, CV_8U);
     memset(im.data, 0, 64 * 64);
     std::vector<cv::KeyPoint> keys(3);
     cv::Mat desc;
@@ -88,7 +89,7 @@ int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb");
   CHECK(f && fread(raw.data(), 1, raw.size(), f) == raw.size());
   fclose(f);
-  cv::Mat im(h, w, cv::CV_8U, raw.data());
+  cv::Mat im(h, w, CV_8U, raw.data());
 
   // --- as Tracking::Tracking does (L/src/Tracking.cc:118)
   ORB_SLAM2::ORBextractor* ext = new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7);
@@ -144,7 +145,7 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> flipped(raw.size());
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) flipped[(size_t)y * w + x] = raw[(size_t)y * w + (w - 1 - x)];
-    cv::Mat imR(h, w, cv::CV_8U, flipped.data());
+    cv::Mat imR(h, w, CV_8U, flipped.data());
     ORB_SLAM2::ORBextractor* extR = new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7);
     std::vector<cv::KeyPoint> keysL2, keysR2;
     cv::Mat descL2, descR2;
@@ -226,7 +227,11 @@ int main(int argc, char** argv) {
     const float R[9] = {ca, 0, sa, 0, 1, 0, -sa, 0, ca}, t[3] = {0.4f, -0.1f, 0.8f};
     float Ow[3];
     for (int r = 0; r < 3; r++) Ow[r] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
-    FL.mRcw = FloatMat(3, 3, R); FL.mtcw = FloatMat(3, 1, t); FL.mOw = FloatMat(3, 1, Ow);
+    {
+      float T[16] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2], 0, 0, 0, 1};
+      FL.mTcw = FloatMat(4, 4, T);
+      FL.mOw = FloatMat(3, 1, Ow);
+    }
     FL.fx = 718.856f; FL.fy = 718.856f; FL.cx = 0.5f * w + 2.25f; FL.cy = 0.5f * h - 1.5f; FL.mbf = 386.1448f;
     FL.mfLogScaleFactor = logf(1.2f);
     oo_frustum ofr;
@@ -247,8 +252,8 @@ int main(int argc, char** argv) {
       for (int r = 0; r < 3; r++) { PO[r] = p.pos[r] - Ow[r]; d2 += PO[r] * PO[r]; }
       const float dist = sqrtf(d2);
       for (int r = 0; r < 3; r++) p.nrm[r] = PO[r] / dist;
-      p.maxD = dist * powf(1.2f, (float)keys[i].octave - 0.4f);
-      p.minD = p.maxD / sf[7];
+      const float maxD = dist * powf(1.2f, (float)keys[i].octave - 0.4f), minD = maxD / sf[7];
+      p.SetDistances(minD, maxD);
       p.nObs = (i % 5) ? 2 : 0;
       p.bad = (i % 29) == 0;
       p.mnLastFrameSeen = (i % 13) ? 3 : FL.mnId;
@@ -260,7 +265,7 @@ int main(int argc, char** argv) {
       memset(&e, 0, sizeof(e));
       e.skip = p.bad || p.mnLastFrameSeen == FL.mnId;
       memcpy(e.pos, p.pos, 12); memcpy(e.normal, p.nrm, 12);
-      e.min_distance = p.minD; e.max_distance = p.maxD; e.observed = p.nObs > 0;
+      e.min_distance = minD; e.max_distance = maxD; e.observed = p.nObs > 0;
       memcpy(e.desc, p.desc.ptr(0), 32);
     }
     int ntm = 0;
@@ -300,7 +305,7 @@ int main(int argc, char** argv) {
     MockF fr;
     kf.mDescriptors = desc; kf.mvKeysUn = keys; kf.mps.assign(on, nullptr);
     fr.N = on; fr.mvKeys = keys;
-    fr.mDescriptors = cv::Mat(on, 32, cv::CV_8U);
+    fr.mDescriptors = cv::Mat(on, 32, CV_8U);
     for (int i = 0; i < on; i++) {
       memcpy(fr.mDescriptors.ptr(i), desc.ptr((i * 7 + 3) % on), 32);   // a permutation of the keyframe's descriptors ...
       if (i % 3 == 0) fr.mDescriptors.ptr(i)[i % 32] ^= 0x11;          // ... with a few flipped bits
