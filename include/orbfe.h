@@ -473,6 +473,13 @@ int orbfe_compute_bow(orbfe_vocabulary* v, const uint8_t* desc, int n, int level
                       int32_t* node_id, double* weight, int32_t* bow_ids, double* bow_vals, int* n_bow,
                       orbfe_featvec_node* fv_nodes, int32_t* fv_idx, int* n_fv_nodes);
 
+/* --------------------------------------------------------------------------------------- sequence driver helpers */
+/* Dependency-free PNG input for the dataset drivers (the reference reads with cv::imread(..., IMREAD_UNCHANGED),
+ * Source/Examples/Stereo/stereo_kitti.cc:88-89, and converts colour frames in Tracking::GrabImage*, L/src/Tracking.cc:
+ * 164-178): 8-bit greyscale, or 8-bit RGB(A) converted with cvtColor's RGB2GRAY weights; non-interlaced.  zlib only. */
+int orbfe_png_info(const char* path, int* w, int* h);
+int orbfe_png_read_gray(const char* path, uint8_t* dst, int stride, int cap_rows, int* w, int* h);
+
 #ifdef __cplusplus
 }
 #endif

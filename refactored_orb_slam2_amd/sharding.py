@@ -75,9 +75,10 @@ def gather_records(n, kps, desc, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return n, kps, desc
     world = dist.get_world_size(group)
+    on_host = dist.get_backend(group) != "nccl" and n.is_cuda   # gloo rehearsal: records go through host memory
     out = []
     for t in (n, kps, desc):
-        t = t.contiguous()
+        t = t.contiguous().cpu() if on_host else t.contiguous()
         g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(g, t, group=group)  # concatenation along dim 0, rank order
         out.append(g)

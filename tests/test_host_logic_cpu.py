@@ -139,3 +139,40 @@ def test_gather_records_identity_without_group():
     d = torch.zeros((4, 5, 32), dtype=torch.uint8)
     out = sharding.gather_records(n, k, d)
     assert out[0] is n and out[1] is k and out[2] is d
+
+
+def test_png_reader_decodes_all_filters_and_rgb(tmp_path):
+    """liborbfe's zlib PNG reader (sequence driver input): 8-bit grey with every filter type, RGB converted with cvtColor's
+    fixed-point RGB2GRAY weights; files written by PIL (adaptive filters) and by the driver test's minimal writer."""
+    import ctypes as C
+    from PIL import Image
+    from refactored_orb_slam2_amd import _lib
+    from tests.test_matcher_gpu import _write_png_gray
+    L = _lib.lib()
+
+    def read(path):
+        w, h = C.c_int(0), C.c_int(0)
+        assert L.orbfe_png_info(str(path).encode(), C.byref(w), C.byref(h)) == 0
+        out = np.empty((h.value, w.value), np.uint8)
+        assert L.orbfe_png_read_gray(str(path).encode(), out.ctypes.data_as(C.c_void_p), out.strides[0], h.value, C.byref(w), C.byref(h)) == 0
+        return out
+
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (97, 131)).astype(np.uint8)
+    img[20:60, 30:90] = 200
+    img[5:15] = np.arange(131, dtype=np.uint8)           # gradients: sub / up / paeth filters win on such rows
+    Image.fromarray(img).save(tmp_path / "pil.png")
+    _write_png_gray(tmp_path / "own.png", img)
+    np.testing.assert_array_equal(read(tmp_path / "pil.png"), img)
+    np.testing.assert_array_equal(read(tmp_path / "own.png"), img)
+    rgb = rng.integers(0, 256, (50, 70, 3)).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "rgb.png")
+    ref = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14)
+    np.testing.assert_array_equal(read(tmp_path / "rgb.png"), ref.astype(np.uint8))
+    # errors are codes, not crashes
+    w, h = C.c_int(0), C.c_int(0)
+    assert L.orbfe_png_info(str(tmp_path / "missing.png").encode(), C.byref(w), C.byref(h)) != 0
+    (tmp_path / "junk.png").write_bytes(b"not a png at all, really")
+    assert L.orbfe_png_info(str(tmp_path / "junk.png").encode(), C.byref(w), C.byref(h)) != 0
+    small = np.empty((10, 10), np.uint8)
+    assert L.orbfe_png_read_gray(str(tmp_path / "pil.png").encode(), small.ctypes.data_as(C.c_void_p), 10, 10, C.byref(w), C.byref(h)) == _lib.ERR_CAPACITY if hasattr(_lib, "ERR_CAPACITY") else True

@@ -733,26 +733,101 @@ def test_compute_bow_transform(tmp_path, k, L, ragged, weighting, scoring):
     vb.close()
 
 
+def _write_png_gray(path, img):
+    """minimal 8-bit greyscale PNG writer for the driver test (zlib only): filter types cycle through 0..4 so that the
+    library's reader is exercised on all of them"""
+    import struct, zlib
+    h, w = img.shape
+    rows = bytearray()
+    prev = np.zeros(w, np.int16)
+    for y in range(h):
+        cur = img[y].astype(np.int16)
+        ft = y % 5
+        left = np.concatenate([[0], cur[:-1]]); ul = np.concatenate([[0], prev[:-1]])
+        if ft == 0: f = cur
+        elif ft == 1: f = cur - left
+        elif ft == 2: f = cur - prev
+        elif ft == 3: f = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            f = cur - pred
+        rows += bytes([ft]) + (f & 0xff).astype(np.uint8).tobytes()
+        prev = cur
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                 chunk(b"IDAT", zlib.compress(bytes(rows), 6)) + chunk(b"IEND", b""))
+
+
 def test_sequence_driver_on_kitti_layout(tmp_path):
-    """examples/stereo_kitti.py on a synthetic sequence written in the KITTI directory layout (PNG + times.txt)."""
+    """examples/stereo_kitti.py on a synthetic sequence written in the KITTI directory layout (PNG + times.txt), read with the
+    library's zlib PNG reader: every frame's keypoints, descriptors, mvuRight / mvDepth and the SearchByProjection(cur, last)
+    assignment against the previous frame == the oracle; then the sharded mode (two ranks, contiguous chunks, one gather per
+    batch) delivers the same per-frame records."""
     import subprocess, sys, os
-    from PIL import Image
+    from refactored_orb_slam2_amd._lib import TRACK_POSE_DTYPE, UNPROJECT_CAM_DTYPE
     seq = tmp_path / "00"
     (seq / "image_0").mkdir(parents=True); (seq / "image_1").mkdir()
-    pairs = synth.sequence(1241, 376, 5, seq=20, stereo=True)
+    W, H, NF, N = 1241, 376, 2000, 5
+    pairs = synth.sequence(W, H, N, seq=20, stereo=True)
     with open(seq / "times.txt", "w") as f:
         for i, (L, R) in enumerate(pairs):
-            Image.fromarray(L).save(seq / "image_0" / f"{i:06d}.png")
-            Image.fromarray(R).save(seq / "image_1" / f"{i:06d}.png")
+            _write_png_gray(seq / "image_0" / f"{i:06d}.png", L)
+            _write_png_gray(seq / "image_1" / f"{i:06d}.png", R)
             f.write(f"{i * 0.1:e}\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["--batch", "4"]):
-        r = subprocess.run([sys.executable, os.path.join(root, "examples", "stereo_kitti.py"), str(seq)] + extra, capture_output=True, text=True)
+    drv = os.path.join(root, "examples", "stereo_kitti.py")
+    # ---- oracle, frame by frame
+    oL, oR = ol.OracleExtractor(NF), ol.OracleExtractor(NF)
+    sf, isf = oL.scale_factors, oL.inv_scale_factors
+    bf, fx, fy, cx, cy = 386.1448, 718.856, 718.856, 607.1928, 185.2157
+    cam = np.zeros(1, UNPROJECT_CAM_DTYPE); pose = np.zeros(1, TRACK_POSE_DTYPE)
+    eye = np.eye(3, dtype=np.float32).reshape(9)
+    cam["Rwc"] = eye; cam["cx"] = cx; cam["cy"] = cy; cam["invfx"] = np.float32(1) / np.float32(fx); cam["invfy"] = np.float32(1) / np.float32(fy)
+    pose["Rcw"] = eye; pose["fx"] = fx; pose["fy"] = fy; pose["cx"] = cx; pose["cy"] = cy; pose["mbf"] = bf
+    pose["max_x"] = W; pose["max_y"] = H; pose["th"] = 7.0; pose["scale_factors"][0, :8] = sf
+    exp = []
+    prev = None
+    for (L, R) in pairs:
+        kL, dL = oL(L); kR, dR = oR(R)
+        _, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, [oL.level_pixels(l) for l in range(8)], [oR.level_pixels(l) for l in range(8)],
+                                                 sf, isf, bf, bf / fx)
+        nm, assigned = 0, np.full(len(kL), -1, np.int32)
+        if prev is not None:
+            nm, assigned, _ = ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(ol.track_queries(pose, prev), True)
+        exp.append((kL, dL, ur, depth, nm, assigned))
+        prev = ol.unproject_stereo(cam, kL, dL, depth)
+    for extra in ([], ["--batch", "4"], ["--batch", "2"]):
+        dump = str(tmp_path / "dump.npz")
+        r = subprocess.run([sys.executable, drv, str(seq), "--dump", dump] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "median tracking time" in r.stdout and "Images in the sequence: 5" in r.stdout
-        kp = float(r.stdout.split("keypoints/left image: ")[1].split(",")[0])
-        st = float(r.stdout.split("stereo matches/frame: ")[1].split(",")[0])
-        assert 1990 < kp < 2030 and st > 800
+        g = np.load(dump)
+        for i, (kL, dL, ur, depth, nm, assigned) in enumerate(exp):
+            np.testing.assert_array_equal(g[f"kp_{i}"], kL, err_msg=f"keypoints of frame {i} ({extra})")
+            np.testing.assert_array_equal(g[f"desc_{i}"], dL)
+            np.testing.assert_array_equal(g[f"ur_{i}"], ur); np.testing.assert_array_equal(g[f"depth_{i}"], depth)
+            assert int(g[f"ntrack_{i}"]) == nm, (i, extra)
+            np.testing.assert_array_equal(g[f"assigned_{i}"], assigned)
+        assert exp[2][4] > 500
+    # ---- config C5 in small: two ranks, contiguous frame shards, gather of the padded per-frame records
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dump = str(tmp_path / "shard")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), drv, str(seq), "--shard", "--batch", "2", "--dump", dump], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "sharded over 2 ranks, 3 frames per rank" in r.stdout
+    for rank in (0, 1):
+        g = np.load(f"{dump}.rank{rank}.npz")
+        for i, (kL, dL, *_rest) in enumerate(exp):   # every rank holds every frame's gathered record
+            np.testing.assert_array_equal(g[f"g_kp_{i}"], kL, err_msg=f"gathered keypoints of frame {i} on rank {rank}")
+            np.testing.assert_array_equal(g[f"g_desc_{i}"], dL)
 
 
 # ------------------------------------------------------------------------------------------------ whole-function A15
