@@ -11,6 +11,7 @@
 // All arithmetic that decides an output bit is integer, or float/double evaluated exactly as the x86-64
 // reference build does (no FMA contraction: this file is compiled with -ffp-contract=off; IEEE divide).
 #include <stdlib.h>
+#include <string.h>
 
 #include "orbfe_internal.h"
 #include "../../include/orb_pattern_data.h"
@@ -1390,6 +1391,196 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   }
 }
 
+// ---- orientation + description, eight keypoints per wave ------------------------------------------------------------------
+// The per-keypoint work has two kinds of instructions: cooperative ones (patch staging, the 749-pixel moment sums, the 256
+// rotated comparisons) and wave-uniform ones (level bookkeeping, fastAtan2, the double-precision sin / cos: ~130 of the ~380
+// instructions of orient_describe_kernel, each of them computing ONE value on 64 lanes).  Here a wave takes eight consecutive
+// keypoint slots: phase 1 stages each raw 31 x 31 patch and leaves the keypoint's moments in lane k; phase 2 evaluates
+// fastAtan2 / sinf / cosf once, lane k for keypoint k; phase 3 stages each blurred 37 x 37 patch and samples the pattern with
+// (a, b) read from lane k.  The moments use v_dot4_u32_u8: a lane owns four (row, 4-column) items of the disc, the per-item
+// weights (u + 15, v + 15 and 1 inside the disc, 0 outside; a host-filled table) stay in registers for all eight keypoints, and
+// m10 = sum (u+15) I - 15 sum I, m01 = sum (v+15) I - 15 sum I -- integer, hence the same moments as the reference's loops.
+#define OD_K 8
+__device__ __attribute__((aligned(16))) uint32_t g_ic_w[256 * 3];   // [item][u-weights | v-weights | inside], item = row * 8 + 4-column group
+__global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P) {
+  __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int bx = blockIdx.x, img = blockIdx.y;
+  if (P.xcd_images) {   // whole images per XCD, see orient_describe_kernel
+    const unsigned gx = gridDim.x;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned grp = lin / (8u * gx);
+    if (8u * grp + 8u <= gridDim.y) {
+      const unsigned within = lin - grp * 8u * gx;
+      img = (int)(8u * grp + (within & 7u));
+      bx = (int)(within >> 3);
+    }
+  }
+  const int s0 = (bx * 4 + wv_id) * OD_K;
+  const int32_t* ln = P.lvl_n + (size_t)img * ORBFE_MAX_LEVELS;
+  if (s0 == 0 && lane == 0) {
+    int tot = 0;
+    for (int l = 0; l < P.n_levels; l++) tot += ln[l];
+    P.out_n[img] = tot;
+  }
+  if (s0 >= P.kp_per_image) return;
+  float4 pk[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
+  uint32_t wu[4], wv[4], w1[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int it = lane + WAVE * j;   // items >= 248 carry zero weights
+    wu[j] = g_ic_w[it * 3]; wv[j] = g_ic_w[it * 3 + 1]; w1[j] = g_ic_w[it * 3 + 2];
+  }
+  uint8_t* ori = &patch[wv_id][0];
+  uint8_t* dsc = ori + ORI_BYTES;
+
+  // slot bookkeeping, lane k for slot s0 + k: level, position, score and output index (-1 = no keypoint in this slot)
+  int i_out = -1, i_level = 0, i_cx = 0, i_cy = 0, i_score = 0;
+  {
+    const int slot = s0 + lane;
+    if (lane < OD_K && slot < P.kp_per_image) {
+      int level = 0;
+      for (int l = 1; l < P.n_levels; l++) level += slot >= P.kp_off[l] ? 1 : 0;   // kp_off ascends
+      const int idx = slot - P.kp_off[level];
+      int out = idx;
+      for (int l = 0; l < P.n_levels; l++) out += l < level ? ln[l] : 0;
+      if (idx < ln[level] && out < P.cap) {
+        const uint32_t e = P.lvl_kp[(size_t)img * P.kp_per_image + slot];
+        i_out = out; i_level = level;
+        i_cx = (int)(e & 0xfff) + ORBFE_EDGE; i_cy = (int)((e >> 12) & 0xfff) + ORBFE_EDGE; i_score = (int)(e >> 24);
+      }
+    }
+  }
+  const unsigned valid_mask = (unsigned)(__ballot(i_out >= 0) & 0xffu);
+  if (valid_mask == 0) return;
+
+  // the loads of keypoint k's raw patch (two 16-byte pieces per lane) / blurred patch (three)
+  auto issue_ori = [&](int k, uint4 vo[2]) {
+    const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
+    const int pitch = P.pyr.pitch[level];
+    const uint8_t* plane = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level];
+    const int ax_o = (cx - 15) & ~15;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = lane + WAVE * j;
+      const int r = i / 3, c = i - r * 3;
+      vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 16 * c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto issue_dsc = [&](int k, uint4 vd[3]) {
+    const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
+    const int bpitch = P.blur.pitch[level];
+    const uint8_t* bplane = P.blur.base[level] + (size_t)img * P.blur.img_stride[level];
+    const int ax_d = (cx - 18) & ~15;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i = lane + WAVE * j;
+      const int r = i >> 2, c = i & 3;
+      vd[j] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 16 * c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  // next valid slot after k (OD_K if none)
+  auto next_valid = [&](int k) { const unsigned m = valid_mask >> (k + 1); return m ? k + 1 + (__ffs((int)m) - 1) : OD_K; };
+  const int k_first = __ffs((int)valid_mask) - 1;
+
+  // ---- phase 1: moments of the keypoints, keypoint k's in lane k.  The loads of keypoint k + 1 are in flight while k is summed.
+  int m10v = 0, m01v = 0;
+  {
+    uint4 vn[2];
+    issue_ori(k_first, vn);
+    for (int k = k_first; k < OD_K; k = next_valid(k)) {
+      const int cx = __builtin_amdgcn_readlane(i_cx, k);
+      const int m = (cx - 15) & 15;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int i = lane + WAVE * j;
+        const int r = i / 3, c = i - r * 3;
+        if (i < 31 * 3) reinterpret_cast<uint4*>(ori)[r * (ORI_PITCH / 16) + c] = vn[j];
+      }
+      const int kn = next_valid(k);
+      if (kn < OD_K) issue_ori(kn, vn);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint32_t A = 0, B = 0, S = 0;
+      const uint32_t sh = (uint32_t)(m & 3);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int it = lane + WAVE * j;
+        const int r = it >> 3, c = it & 7;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(ori + (r < 31 ? r : 30) * ORI_PITCH + ((m + 4 * c) & ~3));
+        const uint32_t px = __builtin_amdgcn_alignbyte(q[1], q[0], sh);   // the four pixels u = -15 + 4c .. -12 + 4c of row v = r - 15
+        A = __builtin_amdgcn_udot4(px, wu[j], A, false);
+        B = __builtin_amdgcn_udot4(px, wv[j], B, false);
+        S = __builtin_amdgcn_udot4(px, w1[j], S, false);
+      }
+      const int At = __builtin_amdgcn_readlane(wave_incl_scan((int)A), 63), Bt = __builtin_amdgcn_readlane(wave_incl_scan((int)B), 63),
+                St = __builtin_amdgcn_readlane(wave_incl_scan((int)S), 63);
+      if (lane == k) { m10v = At - 15 * St; m01v = Bt - 15 * St; }
+      __builtin_amdgcn_wave_barrier();   // every lane has read the patch before the next keypoint overwrites it
+    }
+  }
+  // ---- phase 2: lane k computes keypoint k's angle and rotation; the first blurred patch is already on its way
+  uint4 wn[3];
+  issue_dsc(k_first, wn);
+  const float angle_v = fast_atan2_deg((float)m01v, (float)m10v);
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a_v, b_v;
+  glibc_sincosf(angle_v * factorPI, &b_v, &a_v);
+  // ---- phase 3: steered BRIEF on the blurred level
+  for (int k = k_first; k < OD_K; k = next_valid(k)) {
+    const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
+    const int out = __builtin_amdgcn_readlane(i_out, k), score = __builtin_amdgcn_readlane(i_score, k);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), k)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_v), k)),
+                angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), k));
+    const int ax_d = (cx - 18) & ~15;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i = lane + WAVE * j;
+      if (i < 37 * 4) reinterpret_cast<uint4*>(dsc)[i] = wn[j];
+    }
+    const int kn = next_valid(k);
+    if (kn < OD_K) issue_dsc(kn, wn);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t* bc = dsc + 18 * DSC_PITCH + (cx - ax_d);
+    uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
+      const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
+      const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
+      const int t0 = bc[ry0 * DSC_PITCH + rx0];
+      const int t1 = bc[ry1 * DSC_PITCH + rx1];
+      const unsigned long long bits = __ballot(t0 < t1);
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = bits;
+    }
+    if (lane < 7) {
+      float fx = (float)cx, fy = (float)cy;
+      if (level != 0) {
+        fx *= P.scale[level];
+        fy *= P.scale[level];
+      }
+      uint32_t wvv;
+      switch (lane) {
+        case 0: wvv = __float_as_uint(fx); break;
+        case 1: wvv = __float_as_uint(fy); break;
+        case 2: wvv = __float_as_uint(P.kp_size[level]); break;
+        case 3: wvv = __float_as_uint(angle); break;
+        case 4: wvv = __float_as_uint((float)score); break;
+        case 5: wvv = (uint32_t)level; break;
+        default: wvv = 0xFFFFFFFFu; break;
+      }
+      reinterpret_cast<uint32_t*>(P.out_kps + (size_t)img * P.cap + out)[lane] = wvv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
                         int h, int n_images, hipStream_t s) {
@@ -1466,19 +1657,45 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
 }
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
-  dim3 block(256), grid((p.kp_per_image + 3) / 4 > 0 ? (p.kp_per_image + 3) / 4 : 1, n_images);
-  static int xcd = -1;
-  if (xcd < 0) { const char* ev = getenv("ORBFE_DESC_XCD"); xcd = ev ? atoi(ev) : 1; }  // A/B knob
+  static int xcd = -1, variant = -1;
+  if (xcd < 0) {
+    const char* ev = getenv("ORBFE_DESC_XCD"); xcd = ev ? atoi(ev) : 1;               // A/B knob
+    const char* vv = getenv("ORBFE_DESC_VARIANT"); variant = vv ? atoi(vv) : 2;       // 1: wave per keypoint, 2: eight keypoints per wave
+  }
   DescribeParams pp = p;
   pp.xcd_images = xcd;
-  hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, pp);
+  if (variant == 1) {
+    dim3 block(256), grid((p.kp_per_image + 3) / 4 > 0 ? (p.kp_per_image + 3) / 4 : 1, n_images);
+    hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, pp);
+  } else {
+    const int per_block = 4 * OD_K;
+    dim3 block(256), grid((p.kp_per_image + per_block - 1) / per_block > 0 ? (p.kp_per_image + per_block - 1) / per_block : 1, n_images);
+    hipLaunchKernelGGL(orient_describe8_kernel, grid, block, 0, s, pp);
+  }
 }
 
 int orbfe_upload_pattern_floats() {
   static const int8_t pat[1024] = {ORB_PATTERN_INT8_1024};
   float f[1024];
   for (int i = 0; i < 1024; i++) f[i] = (float)pat[i];
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pattern_f), f, sizeof(f));
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_pattern_f), f, sizeof(f));
+  if (e != hipSuccess) return (int)e;
+  // weights of the moment sums: item = row * 8 + group, row v = r - 15, columns u = -15 + 4 * group + t
+  static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  uint32_t wtab[256 * 3];
+  memset(wtab, 0, sizeof(wtab));
+  for (int it = 0; it < 248; it++) {
+    const int v = (it >> 3) - 15;
+    for (int t = 0; t < 4; t++) {
+      const int u = -15 + 4 * (it & 7) + t;
+      const bool inside = u <= 15 && abs(u) <= umax[abs(v)];
+      if (!inside) continue;
+      wtab[it * 3] |= (uint32_t)(u + 15) << (8 * t);
+      wtab[it * 3 + 1] |= (uint32_t)(v + 15) << (8 * t);
+      wtab[it * 3 + 2] |= 1u << (8 * t);
+    }
+  }
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ic_w), wtab, sizeof(wtab));
 }
 
 int orbfe_set_octree_lds(size_t lds_bytes) {
