@@ -192,6 +192,165 @@ __global__ __launch_bounds__(256) void pyr_resize_lds16_kernel(const uint8_t* __
   }
 }
 
+// bits 32..47 of the product of two 24-bit operands
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// Same tile, staging and arithmetic as pyr_resize_lds16_kernel, restated twice over:
+// (1) per-pixel work for the vector ALU:
+//   * a thread's four destination pixels read source columns s0 .. s0+7 of a row (scale factors <= 2): three aligned LDS
+//     dwords, two v_alignbyte to start the window at s0, and per pixel one v_perm (bytes s0_i, s0_i+1 into 16-bit fields)
+//     + one v_dot2_u32_u16 against (c0, c1) -- instead of two single-byte LDS gathers and two multiplies per row;
+//   * the horizontal result of a source row is computed once and reused by the next destination row when that row's upper
+//     tap is this row's lower one (a wave = one destination row, so the test is wave-uniform);
+//   * (b * (t >> 4)) >> 16 == mul_hi_u24(b << 12, t & ~15): one full-rate instruction per tap.
+//   At the right border the table gives s1 = s0 with c1 = 0 (build_taps): byte s0+1 is then whatever follows in LDS, times 0.
+// (2) persistent workgroups: with one 4 KB tile per workgroup the seven launches of a pyramid ran at the rate workgroups can
+//   be dispatched (~630 per microsecond, measured with the body removed), not at the memory rate.  Here a workgroup walks
+//   tiles L, L + gridDim.x, ... and the source window of the NEXT tile is already in flight (held in registers) while the
+//   current one is interpolated out of LDS.
+struct ResizeGeom {
+  int x0, y0, bz, sxa, ncols16, sy_first, nrows;
+};
+template <int TROWS, int SROWS>
+__global__ __launch_bounds__(256) void pyr_resize_dot_kernel(const uint8_t* __restrict__ src, int spitch,
+                                                              unsigned long long simg, uint8_t* __restrict__ dst,
+                                                              int dpitch, unsigned long long dimg, int dw, int dh,
+                                                              const ResizeTap* __restrict__ xt,
+                                                              const ResizeTap* __restrict__ yt, int tiles_x, int tiles_y,
+                                                              int n_tiles) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[SROWS * RS_COLS + 16];
+  constexpr int NLD = (SROWS + 6) / 7;   // staging passes: at least 7 rows per pass (ncols16 <= 35)
+  const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const int tid = wv * 64 + lane;
+  auto geom = [&](int t) {
+    ResizeGeom g;
+    const int bx = t % tiles_x, r = t / tiles_x;
+    const int by = r % tiles_y;
+    g.bz = r / tiles_y;
+    g.x0 = bx * 256;
+    g.y0 = by * TROWS;
+    const int xl = min(g.x0 + 255, dw - 1), yl = min(g.y0 + TROWS - 1, dh - 1);
+    g.sxa = xt[g.x0].s0 & ~15;
+    g.ncols16 = ((xt[xl].s1 - g.sxa) >> 4) + 1;   // <= 35
+    g.sy_first = yt[g.y0].s0;
+    g.nrows = yt[yl].s1 - g.sy_first + 1;         // <= SROWS
+    return g;
+  };
+  // thread -> (row r0 + k * rpp, 16-byte column c) of the window: one division per tile, all loads issued back to back
+  auto fetch = [&](const ResizeGeom& g, uint4 (&v)[NLD], int& r0, int& c, int& rpp) {
+    rpp = 256 / g.ncols16;
+    r0 = (int)((tid + 0.5f) * (1.0f / (float)g.ncols16));
+    c = tid - r0 * g.ncols16;
+    if (r0 < rpp) {
+      const uint8_t* p = src + (size_t)g.bz * simg + (size_t)g.sy_first * spitch + g.sxa + 16 * c;
+#pragma unroll
+      for (int k = 0; k < NLD; k++) {
+        const int r = r0 + k * rpp;
+        v[k] = r < g.nrows ? *reinterpret_cast<const uint4*>(p + (size_t)r * spitch) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+
+  int t = (int)blockIdx.x;
+  if (t >= n_tiles) return;
+  ResizeGeom g = geom(t);
+  uint4 v[NLD];
+  int r0, c, rpp;
+  fetch(g, v, r0, c, rpp);
+  for (;;) {
+    // horizontal taps of this tile (L2 hits; overlap the wait for the window)
+    const int x4 = g.x0 + lane * 4;
+    uint2 txr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) txr[i] = reinterpret_cast<const uint2*>(xt)[min(x4 + i, dw - 1)];
+    // and its vertical taps: loads return in order, so everything the interpolation needs is requested BEFORE the next
+    // tile's window -- a load issued after the prefetch would have to wait for it
+    uint2 tyr[TROWS / 4];
+#pragma unroll
+    for (int k = 0; k < TROWS / 4; k++) tyr[k] = reinterpret_cast<const uint2*>(yt)[min(g.y0 + wv * (TROWS / 4) + k, dh - 1)];
+    if (r0 < rpp) {
+#pragma unroll
+      for (int k = 0; k < NLD; k++) {
+        const int r = r0 + k * rpp;
+        if (r < g.nrows) *reinterpret_cast<uint4*>(tile + r * RS_COLS + 16 * c) = v[k];
+      }
+    }
+    __syncthreads();
+    const ResizeGeom cur = g;
+    const int tn = t + (int)gridDim.x;
+    if (tn < n_tiles) {
+      g = geom(tn);
+      fetch(g, v, r0, c, rpp);
+    }
+    if (x4 < dw) {
+      const int s00 = (int)(int16_t)(txr[0].x & 0xffff);
+      const int base = s00 - cur.sxa;
+      const uint32_t sh = (uint32_t)base & 3u;
+      uint32_t sel[4], cp[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t o = (uint32_t)((int)(int16_t)(txr[i].x & 0xffff) - s00);   // 0 .. 6
+        sel[i] = o | 0x0c000c00u | ((o + 1) << 16);
+        cp[i] = txr[i].y;                                                         // c0 | c1 << 16
+      }
+      const uint32_t* trow = reinterpret_cast<const uint32_t*>(tile + (base & ~3));
+      auto hrow = [&](int r, uint32_t (&hh)[4]) {
+        const uint32_t* p = trow + r * (RS_COLS / 4);
+        const uint32_t* p2 = p + 2;
+        asm("" : "+v"(p2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow)
+        const uint32_t w0 = p[0], w1 = p[1], w2 = *p2;
+        const uint32_t W0 = __builtin_amdgcn_alignbyte(w1, w0, sh), W1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t u = __builtin_amdgcn_perm(W1, W0, sel[i]);
+          hh[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, u), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
+        }
+      };
+      uint8_t* D = dst + (size_t)cur.bz * dimg + x4;
+      uint32_t hp[4] = {0, 0, 0, 0};
+      int prev = -1;
+#pragma unroll
+      for (int k = 0; k < TROWS / 4; k++) {
+        const int y = cur.y0 + wv * (TROWS / 4) + k;
+        if (y >= dh) break;
+        const uint32_t tys = (uint32_t)__builtin_amdgcn_readfirstlane((int)tyr[k].x);
+        const uint32_t tyc = (uint32_t)__builtin_amdgcn_readfirstlane((int)tyr[k].y);
+        const int ra = (int)(int16_t)(tys & 0xffff) - cur.sy_first, rb = (int)(int16_t)(tys >> 16) - cur.sy_first;
+        uint32_t h0[4], h1[4];
+        if (ra == prev) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) h0[i] = hp[i];
+        } else {
+          hrow(ra, h0);
+        }
+        if (rb == ra) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) h1[i] = h0[i];
+        } else {
+          hrow(rb, h1);
+        }
+        const uint32_t B0 = (tyc & 0xffffu) << 12, B1 = (tyc >> 16) << 12;
+        uint32_t sm[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) sm[i] = mulhi_u24(B0, h0[i]) + mulhi_u24(B1, h1[i]) + 2u;
+        const uint32_t P01 = (sm[0] | (sm[1] << 16)) >> 2, P23 = (sm[2] | (sm[3] << 16)) >> 2;   // values <= 255 in bytes 0 and 2
+        *reinterpret_cast<uint32_t*>(D + (size_t)y * dpitch) = __builtin_amdgcn_perm(P23, P01, 0x06040200u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) hp[i] = h1[i];
+        prev = rb;
+      }
+    }
+    if (tn >= n_tiles) break;
+    t = tn;
+    __syncthreads();   // every wave is done reading this tile before the next window is written over it
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ FAST
 // ring offsets of FAST-9/16 (OpenCV makeOffsets, patternSize 16)
 __device__ constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -1590,9 +1749,32 @@ void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* d
 }
 
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
-                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s) {
+                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, int mode, hipStream_t s) {
   dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
-  if (lds_ok)
+  static int variant = -1;
+  if (variant < 0) {
+    const char* ev = getenv("ORBFE_RESIZE_VARIANT");   // experiment knob: 1 = byte gathers from LDS, default 2 = perm + dot2
+    variant = ev ? atoi(ev) : 2;
+  }
+  if (mode == 2 && variant == 2) {
+    static int trows = -1, wgs = -1;
+    if (trows < 0) {
+      const char* ev = getenv("ORBFE_RESIZE_TROWS");   // experiment knobs
+      trows = ev ? atoi(ev) : 32;
+      ev = getenv("ORBFE_RESIZE_WGS");
+      wgs = ev ? atoi(ev) : 6;
+    }
+    const int tiles_x = (dw + 255) / 256, tiles_y = (dh + trows - 1) / trows;
+    const int n_tiles = tiles_x * tiles_y * n_images;
+    const int nb = n_tiles < 256 * wgs ? n_tiles : 256 * wgs;
+    if (trows == 32)
+      hipLaunchKernelGGL((pyr_resize_dot_kernel<32, 42>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg, dst,
+                         dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
+    else
+      hipLaunchKernelGGL((pyr_resize_dot_kernel<16, RS2_ROWS>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg,
+                         dst, dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
+  }
+  else if (mode >= 1)
     hipLaunchKernelGGL(pyr_resize_lds16_kernel, dim3((dw + 255) / 256, (dh + 15) / 16, n_images), block, 0, s, src, spitch,
                        (unsigned long long)simg, dst, dpitch, (unsigned long long)dimg, dw, dh, xt, yt);
   else  // source window of a tile exceeds the staged size (scale factor > 2): direct byte gathers

@@ -94,7 +94,8 @@ struct orbfe_extractor {
   size_t oct_lds = 0;
   // device tables
   DevBuf d_cells, d_groups, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];
-  bool resize_lds_ok[ORBFE_MAX_LEVELS]{};  // every 256x4 destination tile's source window fits the LDS stage
+  int resize_mode[ORBFE_MAX_LEVELS]{};  // 0: direct gathers; 1: every 256x16 destination tile's source window fits the LDS stage;
+                                         // 2: and every aligned group of four destination pixels reads at most 8 adjacent source bytes
   // work space for `cap_images`
   int cap_images = 0;
   DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_off, d_slots, d_gkeys, d_lvl_kp, d_lvl_n, d_err;
@@ -357,7 +358,18 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
       const int yl = std::min<int>(y0 + 15, (int)yt.size() - 1);
       if (yt[yl].s1 - yt[y0].s0 + 1 > 34) ok = false;
     }
-    e->resize_lds_ok[l] = ok;
+    bool win8 = ok;
+    for (int y0 = 0; y0 < (int)yt.size() && win8; y0 += 32) {  // 256 x 32 tiles of pyr_resize_dot_kernel<32, 42>
+      const int yl = std::min<int>(y0 + 31, (int)yt.size() - 1);
+      if (yt[yl].s1 - yt[y0].s0 + 1 > 42) win8 = false;
+    }
+    for (int x4 = 0; x4 < (int)xt.size() && win8; x4 += 4) {
+      const int xe = std::min<int>(x4 + 3, (int)xt.size() - 1);
+      if (xt[xe].s0 + 1 - xt[x4].s0 > 7) win8 = false;
+      for (int i = x4; i <= xe; i++)
+        if (xt[i].c1 != 0 && xt[i].s1 != xt[i].s0 + 1) win8 = false;
+    }
+    e->resize_mode[l] = win8 ? 2 : ok ? 1 : 0;
     if ((rc = upload(e->d_xt[l], xt.data(), xt.size() * sizeof(ResizeTap), e->stream))) return rc;
     if ((rc = upload(e->d_yt[l], yt.data(), yt.size() * sizeof(ResizeTap), e->stream))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));  // xt/yt go out of scope
@@ -464,7 +476,7 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     for (int l = 1; l < nl; l++)
       orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], e->lg[l - 1].plane, const_cast<uint8_t*>(pv.base[l]),
                           pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
-                          (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_lds_ok[l], s);
+                          (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_mode[l], s);
   }
   // fork: the blur depends only on the pyramid, so it runs on the handle's second stream while FAST and the
   // quadtree (VALU / latency bound) occupy the first; join before the descriptors

@@ -102,7 +102,7 @@ struct BlurTile {
 
 // launchers (extract_kernels.hip)
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
-                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, bool lds_ok, hipStream_t s);
+                         int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, int mode, hipStream_t s);   // mode: 0 direct gathers, 1 LDS-staged, 2 LDS-staged + 8-byte windows
 void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
                               int total_cells, int tile_rows, int clist_cap, int cell_rows, int cell_span,
                               int sc_max, int bits_max, int32_t* cell_cnt, uint32_t* slots, unsigned long long slots_per_image,
