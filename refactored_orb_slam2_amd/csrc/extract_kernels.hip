@@ -403,6 +403,17 @@ __device__ __forceinline__ unsigned max16(unsigned a, unsigned b) {
   asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// packed (2 x u16) min / max
+__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ unsigned mini16(unsigned a, unsigned b) {
   unsigned r;
   asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -608,17 +619,38 @@ __global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, co
   }
 }
 
-// max over the sixteen 9-arcs of the arc minimum of d[] (16-bit signed in 32-bit containers)
-__device__ __forceinline__ int arc9_maxmin_h(const unsigned d[16]) {
-  unsigned lo2[16], lo4[16];
+// packed (2 x i16) helpers of the pair-wise corner score below
+__device__ __forceinline__ uint32_t pkmin_i(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pkmax_i(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pksub_i(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max over the sixteen 9-arcs of the arc minimum of t[k] = (v - q_k) ^ m, with the ring held as eight (q_2j, q_2j+1) pairs.
+// m = 0: the dark score + 1 of cornerScore<16>.  m = ~0: t = q - v - 1 (bitwise NOT reverses the order), so the result is the
+// bright score + 1, minus 1.  One network serves either polarity without a divergent branch around it.
+__device__ __forceinline__ int arc9_maxmin_pk(const uint32_t (&P)[8], uint32_t VV, uint32_t m) {
+  uint32_t D[8], L[8];
 #pragma unroll
-  for (int i = 0; i < 16; i++) lo2[i] = mini16(d[i], d[(i + 1) & 15]);
+  for (int j = 0; j < 8; j++) D[j] = pksub_i(VV, P[j]) ^ m;
 #pragma unroll
-  for (int i = 0; i < 16; i++) lo4[i] = mini16(lo2[i], lo2[(i + 2) & 15]);
-  unsigned A = 0x8000u;
+  for (int j = 0; j < 8; j++) L[j] = pkmin_i(D[j], __builtin_amdgcn_alignbit(D[(j + 1) & 7], D[j], 16));   // min d[i .. i+1]
+  uint32_t L4[8];
 #pragma unroll
-  for (int i = 0; i < 16; i++) A = maxi16(A, mini16(mini16(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]));
-  return (int)(short)(A & 0xffffu);
+  for (int j = 0; j < 8; j++) L4[j] = pkmin_i(L[j], L[(j + 1) & 7]);                                       // min d[i .. i+3]
+#pragma unroll
+  for (int j = 0; j < 8; j++) L[j] = pkmin_i(pkmin_i(L4[j], L4[(j + 2) & 7]), D[(j + 4) & 7]);             // min d[i .. i+8]
+  const uint32_t A = pkmax_i(pkmax_i(pkmax_i(L[0], L[1]), pkmax_i(L[2], L[3])), pkmax_i(pkmax_i(L[4], L[5]), pkmax_i(L[6], L[7])));
+  return max((int)(short)(A & 0xffffu), (int)(short)(A >> 16));
 }
 
 // ---- FAST, second formulation (default): one WAVE per cell, no workgroup barriers.
@@ -626,21 +658,24 @@ __device__ __forceinline__ int arc9_maxmin_h(const unsigned d[16]) {
 // The phases of the per-cell pipeline (stage, quick test, exact score, NMS, ordered emission) have very different widths; in a
 // workgroup-wide kernel every phase boundary is a barrier at which most waves idle.  Here every wave owns a run of <= 4
 // horizontally adjacent cells and walks them one at a time entirely inside its own LDS slice (~5.4 KB: 28 waves per CU): all
-// synchronisation is the in-order execution of one wave's LDS operations, a compute unit holds independent waves in different
-// phases, and the global loads of the next cell of the run are in flight while the current one is processed.
+// synchronisation is the in-order execution of one wave's LDS operations and a compute unit holds independent waves in
+// different phases.  72 VGPRs = 7 waves per SIMD, which is also what the LDS slices allow; holding the NEXT cell's tile in
+// registers while the current one is processed (FC_PREFETCH) costs 15 registers = one wave per SIMD and measured slower.
 //   stage   cell ROI (<= 66 x 66) as bytes, shifted one column when that makes the tested region start on an even column (the
 //           shift happens in registers: v_alignbyte over one extra aligned dword; LDS stores stay 16-byte aligned)
-//   A1      SWAR quick test, two pixels per lane in 16-bit fields, add / sub / logic only (see below); the
-//           16-bit pairs are cut out of aligned dwords with v_perm_b32 (selectors per lane: the pair starts at byte 0 or 2),
-//           ten dwords per pair in five ds_read2_b32.  Lanes = (row in a band of RI rows, pixel pair): rows are 64 bytes apart,
-//           so the lanes of a 32-lane LDS group hit distinct banks.  Survivors -> 256-entry list with their polarity, scored (A2)
-//           and emptied whenever it is more than half full
-//   A2      exact cornerScore of one polarity -> score plane (tested region + 1-pixel zero frame) and a bitmap of scored pixels
+//   A1      SWAR quick test, two pixels per lane in 16-bit fields: the 16-bit pairs are cut out of aligned dwords with
+//           v_perm_b32 (selectors per lane: the pair starts at byte 0 or 2), ten dwords per pair in five ds_read2_b32; packed
+//           min / max over the four antipodal pairs, one biased subtract / add per polarity (see below).  Lanes = (row in a
+//           band of RI rows, pixel pair): rows are 64 bytes apart, so the lanes of a 32-lane LDS group hit distinct banks.
+//           Survivors -> 384-entry list with their polarity, scored (A2) and emptied whenever more than 256 are waiting
+//   A2      exact cornerScore of the surviving polarity: ring held as eight packed pairs, one 9-arc max-min network of packed
+//           16-bit min / max for either polarity (arc9_maxmin_pk) -> score plane (tested region + 1-pixel zero frame) and a
+//           bitmap of scored pixels
 //   B + C   each lane takes the bitmap words w = lane, lane + 64: strict 3x3 NMS inside the cell, the two-threshold rule and the
 //           row-major emission run from registers (two packed wave scans give the output offsets)
-#define FC_LIST_CAP 256
+#define FC_LIST_CAP 384
 #ifndef FC_WAVES_PER_EU
-#define FC_WAVES_PER_EU 6
+#define FC_WAVES_PER_EU 7
 #endif
 // LDS bytes of one wave's slice: byte tile, score plane, bitmap of scored pixels (nbw words), survivor list
 __host__ __device__ inline int fc_wave_lds(int rows_max, int pb, int sc_bytes, int nbw) {
@@ -695,7 +730,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
   };
 
 #ifndef FC_PREFETCH
-#define FC_PREFETCH 1
+#define FC_PREFETCH 0
 #endif
   CellDesc cd = cells[g.first_cell];
   if (FC_PREFETCH) load_cell(cd);
@@ -750,17 +785,19 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         const int y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
         const int x = e - y * PB;
         if (x >= c_hi) continue;   // the pair straddling the right edge of the tested region
+        // the centre and the sixteen ring bytes, packed in ring order as eight (q_2j, q_2j+1) pairs (d16 byte loads would
+        // build the pairs for free, but with SRAM ECC they zero the other half of the register)
         const uint8_t* c = tile + e;
-        const int v = c[0];
-        unsigned d[16];
+        const uint32_t v = c[0];
+        uint32_t P[8];
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) d[kk] = (unsigned)(v - (int)c[RDY[kk] * PB + RDX[kk]]);
-        int s = 0;
-        if (en & 0x8000u) s = arc9_maxmin_h(d);   // dark: min over the arc of (v - q)
-        if (en & 0x4000u) {                       // bright: min over the arc of (q - v)
-#pragma unroll
-          for (int kk = 0; kk < 16; kk++) d[kk] = 0u - d[kk];
-          s = max(s, arc9_maxmin_h(d));
+        for (int j = 0; j < 8; j++)
+          P[j] = (uint32_t)c[RDY[2 * j] * PB + RDX[2 * j]] | ((uint32_t)c[RDY[2 * j + 1] * PB + RDX[2 * j + 1]] << 16);
+        const uint32_t VV = v | (v << 16);
+        const bool bright = (en & 0x4000u) != 0;
+        int s = arc9_maxmin_pk(P, VV, bright ? ~0u : 0u) + (bright ? 1 : 0);
+        if (__ballot((en & 0xC000u) == 0xC000u)) {   // both polarities survived the quick test (about once in 10^4): wave-uniform
+          if ((en & 0xC000u) == 0xC000u) s = max(s, arc9_maxmin_pk(P, VV, 0u));
         }
         if (s - 1 >= min_th) {
           const int ty = y - 3, tx = x - c_lo;
@@ -812,8 +849,10 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         const uint32_t Q6 = __builtin_amdgcn_perm(0u, (uint32_t)p62, selX), Q2 = __builtin_amdgcn_perm(0u, (uint32_t)(p62 >> 32), selX);
         const uint32_t Q10 = __builtin_amdgcn_perm(0u, (uint32_t)p1014, selX), Q14 = __builtin_amdgcn_perm(0u, (uint32_t)(p1014 >> 32), selX);
         const uint32_t AD = V + C, AB = C - V;
-        const uint32_t dark = ((AD - Q0) | (AD - Q8)) & ((AD - Q2) | (AD - Q10)) & ((AD - Q4) | (AD - Q12)) & ((AD - Q6) | (AD - Q14));
-        const uint32_t brt = ((Q0 + AB) | (Q8 + AB)) & ((Q2 + AB) | (Q10 + AB)) & ((Q4 + AB) | (Q12 + AB)) & ((Q6 + AB) | (Q14 + AB));
+        // one of every antipodal pair is darker than v - t  <=>  max over the pairs of the pair minimum is; same for brighter
+        const uint32_t lo = pkmax(pkmax(pkmin(Q0, Q8), pkmin(Q2, Q10)), pkmax(pkmin(Q4, Q12), pkmin(Q6, Q14)));
+        const uint32_t hi = pkmin(pkmin(pkmax(Q0, Q8), pkmax(Q2, Q10)), pkmin(pkmax(Q4, Q12), pkmax(Q6, Q14)));
+        const uint32_t dark = AD - lo, brt = hi + AB;
         const uint32_t G = act ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
         const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
         const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
