@@ -693,14 +693,26 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
   uint8_t* sc = tile + rows_max * PB;
   uint32_t* scb = reinterpret_cast<uint32_t*>(sc + sc_bytes);   // bitmap of scored pixels, row-major over the tested region
   uint16_t* list = reinterpret_cast<uint16_t*>(scb + nbw);      // quick-test survivors (tile index | polarity)
-  const int img = blockIdx.y;
+  int img = blockIdx.y;
   const int nblk = (n_runs + 3) >> 2;
   const int q = blockIdx.x >> 3;
   const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
-  const int bid = (xcd_run_shift < 0 || (int)blockIdx.x >= (nblk / unit) * unit)
-                      ? (int)blockIdx.x
-                      : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
-                            (q & ((1 << xcd_run_shift) - 1));
+  int bid = (xcd_run_shift < 0 || (int)blockIdx.x >= (nblk / unit) * unit)
+                ? (int)blockIdx.x
+                : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
+                      (q & ((1 << xcd_run_shift) - 1));
+  if (xcd_run_shift == -2) {
+    // whole images per XCD (workgroups go to the XCDs round-robin in linear order): XCD j walks images j, j + 8, ... one after
+    // the other, so the halo rows / 128-byte lines that neighbouring cells share are fetched into ONE L2 once
+    const unsigned gx = gridDim.x;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned grp = lin / (8u * gx);
+    if (8u * grp + 8u <= gridDim.y) {
+      const unsigned within = lin - grp * 8u * gx;
+      img = (int)(8u * grp + (within & 7u));
+      bid = (int)(within >> 3);
+    }
+  }
   const int rid = bid * 4 + wid;
   if (rid >= n_runs) return;   // no barriers below
   const FastGroup g = runs[rid];
@@ -1828,8 +1840,8 @@ void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const F
   if (n_groups == 0) return;
   static int run_shift = -2, variant = -1;
   if (run_shift == -2) {
-    const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order
-    run_shift = ev ? atoi(ev) : 2;                   // runs of 4 groups (~16 cells) per XCD
+    const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order, k >= 0 = runs of 2^k workgroups per XCD
+    run_shift = ev ? atoi(ev) : -2;                  // -2 (wave-per-cell kernel): whole images per XCD -- same time, 30 % less fabric traffic
     const char* vv = getenv("ORBFE_FAST_VARIANT");   // A/B knob: 1 = workgroup per run of cells (byte tile, min/max quick test),
     variant = vv ? atoi(vv) : 2;                     //          2 = wave per cell (default)
   }
@@ -1843,7 +1855,7 @@ void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const F
       lds_allowed = lds;
     }
     hipLaunchKernelGGL(fast_groups_kernel, grid, block, lds, s, pyr, cells, groups, n_groups, total_cells, tile_rows,
-                       clist_cap, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift);
+                       clist_cap, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift == -2 ? 2 : run_shift);
     return;
   }
   // wave per run of cells: per-wave LDS slice = byte tile + score plane + bitmap + list

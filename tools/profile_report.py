@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>/ (tools/profile_round.sh) -> profiles/<round>_kernel_stats.md, <round>_pmc_counters.md, <round>_pmc_dominant.json
+
+usage: tools/profile_report.py gpurun_out/r02 profiles/r02 [config]
+FETCH_SIZE is reported in KB and, on gfx950, tallies the 128-byte requests of 16-byte-per-lane coalesced loads at 64 bytes
+(MI355X_MICROARCH.md, HBM section): kernels whose bulk reads are such loads are listed in WIDE and get the x2 correction.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+WIDE = ("copy_level0", "pyr_resize", "fast_cells", "fast_groups", "orient_describe")   # 16-byte-per-lane streaming reads
+ALG_KB = {  # algorithmic KB per 256-image launch at KITTI geometry
+    "copy_level0": 2 * 466616 * 256 / 1024,
+    "pyr_resize": ((1444097 - 36330) + (1444097 - 466616)) * 256 / 1024 / 7,
+    "fast_cells": (1444097 + 8 * 4600) * 256 / 1024,
+    "gauss_blur7": 2 * 1444097 * 256 / 1024,
+    "orient_describe": 2000 * (749 + 512 + 60) * 256 / 1024,
+}
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def counters(tag_dir):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in sorted(glob.glob(os.path.join(tag_dir, "**", "pmc*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(path)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v[len(v) // 3:]) / max(len(v[len(v) // 3:]), 1) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def main(tag_dir, out_prefix, config="kitti_stereo"):
+    stats = glob.glob(os.path.join(tag_dir, "**", "stats_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(stats)))
+    bench_line = open(os.path.join(tag_dir, "stats.log")).read().strip().split("\n")[-1]
+    try:
+        b = json.loads(bench_line)
+        head = f"{b['value']:.0f} {b['unit']} under the profiler ({b['ms_per_step']:.3f} ms per step of {b['config']['frames_per_gpu_per_step']} stereo frames)"
+    except Exception:
+        head = "bench line not parsed"
+    with open(out_prefix + "_kernel_stats.md", "w") as f:
+        f.write(f"# {os.path.basename(out_prefix)}: rocprofv3 kernel stats of the bench step\n\n"
+                "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0` "
+                f"(tools/profile_round.sh), times in microseconds per launch of 256 images; {head}.\n\n")
+        f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
+        for r in rows:
+            if float(r["Percentage"]) < 0.05:
+                continue
+            f.write(f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | "
+                    f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+    cs = counters(tag_dir)
+    with open(out_prefix + "_pmc_counters.md", "w") as f:
+        f.write(f"# {os.path.basename(out_prefix)}: PMC counters per kernel launch (256 KITTI images / stereo frames per launch)\n\n"
+                "Separate `rocprofv3 --kernel-trace --pmc <set>` passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0` "
+                "(tools/profile_round.sh: two SQ sets, FETCH_SIZE, WRITE_SIZE, TCC hit/miss, GRBM_GUI_ACTIVE), averaged over the later launches of "
+                "each kernel; durations from the `--stats` pass of the same build.  FETCH / WRITE are KB as rocprofv3 reports them; FETCH is doubled "
+                "(x2) for kernels whose bulk reads are coalesced 16-byte-per-lane loads, which gfx950 tallies at half their bytes "
+                "(MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted, so read them as fabric-side traffic.  SQ_WAVE_CYCLES, "
+                "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles summed over waves.  `VALU busy` = SQ_INSTS_VALU x 2 clocks / (1024 SIMDs x kernel "
+                "clocks), kernel clocks = GRBM_GUI_ACTIVE / 8; `LDS busy` = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel clocks).\n\n")
+        f.write("| kernel | us | FETCH KB | WRITE KB | alg. KB | L2 hit | waves | VALU / wave | SALU / wave | LDS / wave | VMEM / wave | wait | issue stall | VALU busy | LDS busy | LDS conflict |\n")
+        f.write("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for k, c in cs.items():
+            if k.startswith("at::") or "rocclr" in k or k not in avg_us:
+                continue
+            wide = any(k.startswith(w) for w in WIDE)
+            fetch = c.get("FETCH_SIZE", 0) * (2 if wide else 1)
+            alg = next((v for a, v in ALG_KB.items() if k.startswith(a)), None)
+            w = max(c.get("SQ_WAVES", 0), 1)
+            clocks = c.get("GRBM_GUI_ACTIVE", 0) / 8
+            hit = c.get("TCC_HIT_sum", 0) / max(c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0), 1)
+            wc = max(c.get("SQ_WAVE_CYCLES", 0), 1)
+            f.write(f"| {k[:40]} | {avg_us[k]:.1f} | {fetch:.3g}{' (x2)' if wide else ''} | {c.get('WRITE_SIZE', 0):.3g} | "
+                    f"{'' if alg is None else format(alg, '.3g')} | {hit:.2f} | {w:.3g} | {c.get('SQ_INSTS_VALU', 0)/w:.0f} | {c.get('SQ_INSTS_SALU', 0)/w:.0f} | "
+                    f"{c.get('SQ_INSTS_LDS', 0)/w:.0f} | {(c.get('SQ_INSTS_VMEM_RD', 0)+c.get('SQ_INSTS_VMEM_WR', 0))/w:.1f} | "
+                    f"{c.get('SQ_WAIT_ANY', 0)/wc:.2f} | {c.get('SQ_WAIT_INST_ANY', 0)/wc:.2f} | "
+                    f"{(c.get('SQ_INSTS_VALU', 0)*2/(1024*clocks) if clocks else 0):.2f} | {(c.get('SQ_LDS_IDX_ACTIVE', 0)/(256*clocks) if clocks else 0):.2f} | "
+                    f"{c.get('SQ_LDS_BANK_CONFLICT', 0)/max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1):.2f} |\n")
+        f.write("\n(`pyr_resize_dot_kernel`: average of the seven level launches.)\n")
+    dom = max((k for k in cs if k in avg_us and not k.startswith("at::") and "rocclr" not in k), key=lambda k: avg_us[k])
+    stage = {"fast_cells": "fast", "fast_groups": "fast", "orient_describe": "describe", "gauss_blur7": "blur"}
+    st = next((v for a, v in stage.items() if dom.startswith(a)), dom)
+    wide = any(dom.startswith(w) for w in WIDE)
+    json.dump({"stage": st, "config": config, "kernel": dom, "images_per_launch": 256, "fetch_kb": cs[dom].get("FETCH_SIZE", 0),
+               "fetch_correction": 2.0 if wide else 1.0, "write_kb": cs[dom].get("WRITE_SIZE", 0), "avg_us_stats_pass": avg_us[dom],
+               "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
+                         "--warmup 1 --cpu-sample 0 --e2e-steps 0; FETCH_SIZE x 2 for 16-byte-per-lane coalesced loads on gfx950 (MI355X_MICROARCH.md, HBM section)"},
+              open(out_prefix + "_pmc_dominant.json", "w"), indent=1)
+    print("dominant:", dom, avg_us[dom])
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
