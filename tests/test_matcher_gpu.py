@@ -964,3 +964,50 @@ def test_twelve_level_motion_model_and_triangulation():
     onmt, omA = ol.search_for_triangulation(k0, d0, None, has0, ga, k1, d1, None, has1, gb, ep.astype(ol.EPIPOLAR_DTYPE), False, True)
     assert nmt == onmt and nmt > 20
     np.testing.assert_array_equal(mA, omA)
+
+
+def test_mono_sequence_driver_on_kitti_layout(tmp_path):
+    """examples/mono_kitti.py (config C1 in small): image_0 + times.txt, mpIniORBextractor's 2 x nFeatures, the front-end half
+    of Tracking::MonocularInitialization (reference frame, SearchForInitialization with window 100, reset rules) == the oracle
+    frame by frame, including a frame that drops the reference (a blank image: no keypoints)."""
+    import subprocess, sys, os
+    seq = tmp_path / "00"
+    (seq / "image_0").mkdir(parents=True)
+    W, H, NF, N = 1241, 376, 1000, 6
+    frames = [f for f in synth.sequence(W, H, N, seq=31)]
+    frames[3] = np.full((H, W), 90, np.uint8)          # no corners: <= 100 keypoints -> the initializer is deleted (:527-532)
+    with open(seq / "times.txt", "w") as f:
+        for i, im in enumerate(frames):
+            _write_png_gray(seq / "image_0" / f"{i:06d}.png", im)
+            f.write(f"{i * 0.1:e}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "mono.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "mono_kitti.py"), str(seq), "--features", str(NF), "--dump", dump],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "median tracking time" in r.stdout and f"Images in the sequence: {N}" in r.stdout
+    g = np.load(dump)
+    orc = ol.OracleExtractor(2 * NF)
+    sf = orc.scale_factors
+    ini, states = None, []
+    for i, im in enumerate(frames):
+        k, d = orc(im)
+        np.testing.assert_array_equal(g[f"kp_{i}"], k, err_msg=f"keypoints of frame {i}")
+        np.testing.assert_array_equal(g[f"desc_{i}"], d)
+        nm, m12, state = 0, np.zeros(0, np.int32), "idle"
+        if ini is None:
+            if len(k) > 100:
+                ini = (k, d, np.stack([k["x"], k["y"]], 1).astype(np.float32)); state = "reference"
+        elif len(k) <= 100:
+            ini, state = None, "reset"
+        else:
+            nm, m12, prev = ol.search_for_initialization(ini[0], ini[1], ol.OracleFrame(k, d, sf, 0, W, 0, H), ini[2], 100, np.float32(0.9), True)
+            if nm < 100:
+                ini, state = None, "reset"
+            else:
+                ini = (ini[0], ini[1], prev); state = "matched"
+        states.append(state)
+        assert str(g[f"state_{i}"]) == state, (i, str(g[f"state_{i}"]), state)
+        assert int(g[f"nm_{i}"]) == nm, (i, int(g[f"nm_{i}"]), nm)
+        np.testing.assert_array_equal(g[f"m12_{i}"], m12, err_msg=f"vnMatches12 of frame {i}")
+    assert states[:5] == ["reference", "matched", "matched", "reset", "reference"] and states[5] == "matched", states
