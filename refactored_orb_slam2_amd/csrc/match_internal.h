@@ -12,6 +12,7 @@ struct FrameBatch {
   const int32_t* n;          // [n_frames]
   int32_t* cell_start;       // [n_frames][GRID_CELLS + 1]
   int32_t* cell_idx;         // [n_frames][cap]
+  uint32_t* cell_rec;        // [n_frames][cap] x 16 B, CSR order: (index | octave << 24, x, y, mvuRight or -1): what a window walk reads per entry
   int cap;
   float min_x, min_y, gw_inv, gh_inv;
 };

@@ -206,6 +206,17 @@ __global__ __launch_bounds__(256) void grid_build_kernel(FrameBatch F) {
       ci[j + 1] = v;
     }
   }
+  __syncthreads();
+  // everything a window walk tests per entry, in CSR order: one 16-byte record instead of the index -> keypoint -> mvuRight chain
+  const float* ur = F.u_right ? F.u_right + (size_t)f * F.cap : nullptr;
+  uint4* cr = reinterpret_cast<uint4*>(F.cell_rec) + (size_t)f * F.cap;
+  const int total = start[GRID_CELLS];
+  for (int e = tid; e < total; e += 256) {
+    const int i = ci[e];
+    const orbfe_keypoint kp = keys[i];
+    cr[e] = make_uint4((uint32_t)i | ((uint32_t)kp.octave << 24), (uint32_t)__float_as_int(kp.x), (uint32_t)__float_as_int(kp.y),
+                       (uint32_t)__float_as_int(ur ? ur[i] : -1.0f));
+  }
 }
 
 // Enumerates, in the reference's order, the keypoints GetFeaturesInArea returns for query q that also pass the
@@ -227,11 +238,10 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
   const int nMaxCellY = min(ORBFE_GRID_ROWS - 1, (int)ceilf((y - F.min_y + r) * F.gh_inv));
   if (nMaxCellY < 0) return 0;
   const bool bCheckLevels = (q.min_level > 0) || (q.max_level >= 0);
-  const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
   const uint8_t* desc = F.desc + (size_t)f * F.cap * 32;
-  const float* ur = F.u_right ? F.u_right + (size_t)f * F.cap : nullptr;
+  const bool has_ur = F.u_right != nullptr;
   const int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
-  const int32_t* ci = F.cell_idx + (size_t)f * F.cap;
+  const uint4* cr = reinterpret_cast<const uint4*>(F.cell_rec) + (size_t)f * F.cap;
   // The window's cells of one grid column (ix, nMinCellY..nMaxCellY) are adjacent in CSR order.  Lane c fetches
   // column c's range; the ranges are concatenated (prefix sum) into one flat candidate sequence -- column-major, then
   // cell row, then ascending index: the reference's enumeration order -- that the wave consumes 64 entries at a time.
@@ -256,19 +266,20 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
     bool ok = false;
     int idx = 0, oct = 0;
     if (ent >= 0) {
-      idx = ci[ent];
-      const orbfe_keypoint kp = keys[idx];
-      oct = kp.octave;
+      const uint4 rec = cr[ent];
+      idx = (int)(rec.x & 0xFFFFFFu);
+      oct = (int)(rec.x >> 24);
+      const float kx = __int_as_float((int)rec.y), ky = __int_as_float((int)rec.z), kur = __int_as_float((int)rec.w);
       ok = true;
       if (bCheckLevels) {
-        if (kp.octave < q.min_level) ok = false;
-        if (q.max_level >= 0 && kp.octave > q.max_level) ok = false;
+        if (oct < q.min_level) ok = false;
+        if (q.max_level >= 0 && oct > q.max_level) ok = false;
       }
-      const float distx = kp.x - x, disty = kp.y - y;
+      const float distx = kx - x, disty = ky - y;
       if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
       if (GATE == 0) {
-        if (ok && ur) {
-          const float u = ur[idx];
+        if (ok && has_ur) {
+          const float u = kur;
           if (u > 0) {
             const float er = fabsf(q.u_r - u);
             if (er > r) ok = false;
@@ -276,9 +287,9 @@ __device__ __forceinline__ int enumerate_window(const FrameBatch& F, int f, cons
         }
       } else if (GATE == 2) {
         if (ok) {
-          const float kpr = ur ? ur[idx] : -1.0f;
-          const float ex = x - kp.x, ey = y - kp.y;
-          const float invs = inv_sigma2[kp.octave & (ORBFE_MAX_LEVELS - 1)];   // the mask only guards memory
+          const float kpr = kur;   // -1 without mvuRight
+          const float ex = x - kx, ey = y - ky;
+          const float invs = inv_sigma2[oct & (ORBFE_MAX_LEVELS - 1)];   // the mask only guards memory
           if (kpr >= 0) {
             const float er = q.u_r - kpr;
             const float e2 = ex * ex + ey * ey + er * er;
@@ -342,14 +353,17 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, Quer
                                                                int32_t* __restrict__ n_cand, int max_cand) {
   const int f = blockIdx.y;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qi >= Q.n[f]) return;
+  if (qi >= Q.cap) return;
+  // count, query record and query descriptor in ONE round trip (slot qi < cap is always readable)
   const orbfe_query* qp = Q.q + (size_t)f * Q.cap + qi;
+  const int nq = Q.n[f];
   const orbfe_query q = *qp;
+  uint4 q0, q1;
+  load_desc4(qp->desc, q0, q1);
+  if (qi >= nq) return;
   orbfe_cand* out = cand + ((size_t)f * Q.cap + qi) * max_cand;
   int total = 0;
   if (q.valid) {
-    uint4 q0, q1;
-    load_desc4(qp->desc, q0, q1);
     total = enumerate_window(F, f, q, q0, q1, [&](int rank, int idx, int dist, int oct) {
       if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist | (oct << 16); }
     });

@@ -50,7 +50,7 @@ struct orbfe_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
   // scratch
-  MBuf cell_start, cell_idx, cand, n_cand, push_idx, push_bin, sad, bucket_start, bucket_idx;
+  MBuf cell_start, cell_idx, cell_rec, cand, n_cand, push_idx, push_bin, sad, bucket_start, bucket_idx;
   // staging for the host-pointer entry points
   MBuf h_keys, h_desc, h_ur, h_q, h_n, h_nq, h_blocked, h_assigned, h_nm;
   // SearchLocalPoints: generated queries (device) and staging of the host entry point
@@ -85,7 +85,7 @@ extern "C" int orbfe_matcher_destroy(orbfe_matcher* m) {
   if (!m) return ORBFE_OK;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->bucket_start, &m->bucket_idx, &m->h_keys,
+  MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cell_rec, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->bucket_start, &m->bucket_idx, &m->h_keys,
                   &m->h_desc, &m->h_ur, &m->h_q, &m->h_n, &m->h_nq, &m->h_blocked, &m->h_assigned, &m->h_nm,
                   &m->lp_q, &m->lp_pts, &m->lp_fr, &m->lp_track, &m->lp_cnt};
   for (auto b : bufs)
@@ -146,6 +146,7 @@ static int ensure_proj_scratch(orbfe_matcher* m, int n_frames, int cap, int q_ca
   const size_t F = (size_t)n_frames;
   if ((rc = mb_alloc(m->cell_start, F * (GRID_CELLS + 1) * sizeof(int32_t)))) return rc;
   if ((rc = mb_alloc(m->cell_idx, F * cap * sizeof(int32_t)))) return rc;
+  if ((rc = mb_alloc(m->cell_rec, F * cap * 16))) return rc;
   if ((rc = mb_alloc(m->cand, F * q_cap * ORBFE_MAX_CAND * sizeof(orbfe_cand)))) return rc;
   if ((rc = mb_alloc(m->n_cand, F * q_cap * sizeof(int32_t)))) return rc;
   if ((rc = mb_alloc(m->push_idx, F * q_cap * sizeof(int32_t)))) return rc;
@@ -162,6 +163,7 @@ static void fill_frame_batch(orbfe_matcher* m, FrameBatch& fb, const orbfe_keypo
   fb.n = d_n;
   fb.cell_start = (int32_t*)m->cell_start.p;
   fb.cell_idx = (int32_t*)m->cell_idx.p;
+  fb.cell_rec = (uint32_t*)m->cell_rec.p;
   fb.cap = cap;
   fb.min_x = min_x;
   fb.min_y = min_y;
