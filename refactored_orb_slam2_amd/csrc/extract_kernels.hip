@@ -674,6 +674,27 @@ __device__ __forceinline__ int arc9_maxmin_pk(const uint32_t (&P)[8], uint32_t V
 //   B + C   each lane takes the bitmap words w = lane, lane + 64: strict 3x3 NMS inside the cell, the two-threshold rule and the
 //           row-major emission run from registers (two packed wave scans give the output offsets)
 #define FC_LIST_CAP 384
+#ifndef FC_TIMING
+#define FC_TIMING 0
+#endif
+#if FC_TIMING
+// -DFC_TIMING=1 instrumentation (tools/fc_phase_profile.py): wave-cycles per phase (wait for pixels, stage + clear, A1, A2, NMS,
+// scan + emit) by s_memtime, accumulated per wave in scalars and added to one of 4096 slots at the end (one slot would
+// serialise 660 k atomics on one cache line: the kernel took 6 ms)
+__device__ unsigned long long g_fc_prof[4096 * 8];   // 4096 slots (spread the atomics), summed on the host
+#define FC_T(i) do { const uint32_t _t = (uint32_t)__builtin_readcyclecounter(); tacc##i += _t - tprev; tprev = _t; } while (0)
+extern "C" int orbfe_debug_fc_profile(unsigned long long* out, int reset) {
+  static unsigned long long h[4096 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fc_prof), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  for (int sl = 0; sl < 4096; sl++)
+    for (int i = 0; i < 8; i++) out[i] += h[sl * 8 + i];
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_fc_prof), h, sizeof(h)) != hipSuccess) return 1; }
+  return 0;
+}
+#else
+#define FC_T(i)
+#endif
 #ifndef FC_WAVES_PER_EU
 #define FC_WAVES_PER_EU 7
 #endif
@@ -744,6 +765,9 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
 #ifndef FC_PREFETCH
 #define FC_PREFETCH 0
 #endif
+#if FC_TIMING
+  uint32_t tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tacc4 = 0, tacc5 = 0, tprev = (uint32_t)__builtin_readcyclecounter();
+#endif
   CellDesc cd = cells[g.first_cell];
   if (FC_PREFETCH) load_cell(cd);
   for (int k = 0; k < g.n_cells; k++) {
@@ -751,6 +775,10 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       cd = cells[g.first_cell + k];
       load_cell(cd);
     }
+#if FC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FC_T(0);   // waiting for the cell's pixels
+#endif
     const int cols = cd.cols, rows = cd.rows;
     const int xo = cd.x0 & 15, sh = (xo + 3) & 1, xs = xo + sh;
     const int ndq = (xs + cols + 15) >> 4;
@@ -781,12 +809,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       for (int i = lane; i < nsc; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
       for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
     }
-    // the next cell of the run: its loads fly while this one is processed
-    CellDesc cdn = cd;
-    if (FC_PREFETCH && k + 1 < g.n_cells) {
-      cdn = cells[g.first_cell + k + 1];
-      load_cell(cdn);
-    }
+    FC_T(1);   // LDS staging + clears
 
     // ---- A2 (called whenever the list is more than half full, and at the end): exact score of list[0 .. n), the polarity
     //      (or, about once in 10^4, the two polarities) the quick test left possible
@@ -875,11 +898,25 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (uint32_t)(e + 1));
         wcnt += n0 + __popcll(m1);
         if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
+          FC_T(2);
           score_list(wcnt);
+          FC_T(3);
           wcnt = 0;
         }
       }
+      FC_T(2);
       score_list(wcnt);
+      FC_T(3);
+    }
+
+    // FC_PREFETCH: the next cell's pixels requested HERE, after the score network (where the register allocation peaks) and
+    // before NMS and emission.  Measured (tools/fc_phase_profile.py): the wait for the pixels drops from 4.2 k to 2.7 k cycles
+    // per cell and the kernel takes the same time -- the SIMDs' vector ALUs are saturated (SQ_ACTIVE_INST_VALU), waves that do
+    // not wait here queue for issue slots elsewhere.  Off by default.
+    CellDesc cdn = cd;
+    if (FC_PREFETCH && k + 1 < g.n_cells) {
+      cdn = cells[g.first_cell + k + 1];
+      load_cell(cdn);
     }
 
     // ---- B + C: NMS, two-threshold rule, row-major emission.  Lane l owns bitmap words l and l + 64.
@@ -896,15 +933,18 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
           const int p = w * 32 + b;
           const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
           const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
+          // all nine reads in flight together: with `&&` every comparison waited for its own LDS round trip (this loop was a
+          // quarter of the kernel's time, tools/fc_phase_profile.py)
           const int v = s[0];
-          const bool kp = v > s[-SCP - 1] && v > s[-SCP] && v > s[-SCP + 1] && v > s[-1] && v > s[1] && v > s[SCP - 1] && v > s[SCP] &&
-                          v > s[SCP + 1];
+          const int n0 = s[-SCP - 1], n1 = s[-SCP], n2 = s[-SCP + 1], n3 = s[-1], n4 = s[1], n5 = s[SCP - 1], n6 = s[SCP], n7 = s[SCP + 1];
+          const bool kp = (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);
           if (kp) {
             keep[h] |= 1u << b;
             if (v >= ini_th) hi[h] |= 1u << b;
           }
         }
       }
+      FC_T(4);   // NMS
       const int pk0 = (__popc(hi[0]) << 16) | __popc(keep[0]), pk1 = (__popc(hi[1]) << 16) | __popc(keep[1]);
       const int in0 = wave_incl_scan(pk0), in1 = wave_incl_scan(pk1);
       const int tot0 = __builtin_amdgcn_readlane(in0, WAVE - 1), tot1 = __builtin_amdgcn_readlane(in1, WAVE - 1);
@@ -930,9 +970,20 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         }
       }
       if (lane == 0) cell_cnt[(size_t)img * total_cells + g.first_cell + k] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
+      FC_T(5);   // scans + emission
     }
     cd = cdn;
   }
+#if FC_TIMING
+  if (lane == 0) {
+    unsigned long long* pr = g_fc_prof + (size_t)((rid * 2654435761u) >> 20) * 8;   // 4096 slots
+    atomicAdd(&pr[0], (unsigned long long)tacc0); atomicAdd(&pr[1], (unsigned long long)tacc1);
+    atomicAdd(&pr[2], (unsigned long long)tacc2); atomicAdd(&pr[3], (unsigned long long)tacc3);
+    atomicAdd(&pr[4], (unsigned long long)tacc4); atomicAdd(&pr[5], (unsigned long long)tacc5);
+    atomicAdd(&pr[6], 1ull);
+    atomicAdd(&pr[7], (unsigned long long)g.n_cells);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ octree

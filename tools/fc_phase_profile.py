@@ -1,0 +1,27 @@
+"""Per-phase wave-cycle breakdown of fast_cells_kernel.  Needs a library built with -DFC_TIMING=1:
+   make -C refactored_orb_slam2_amd/csrc clean && make -C refactored_orb_slam2_amd/csrc EXTRA=-DFC_TIMING=1   (then rebuild without it)."""
+import ctypes as C, numpy as np, sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from refactored_orb_slam2_amd import ORBextractor, synth, _lib
+L=_lib.lib()
+W,H,NF,B=1241,376,2000,256
+imgs=[synth.sequence(W,H,1,seq=100+i)[0] for i in range(8)]
+d=torch.from_numpy(np.stack([imgs[i%8] for i in range(B)])).cuda()
+ex=ORBextractor(NF,device=0)
+cap=ex.max_keypoints(W,H)
+k=torch.zeros(B,cap,28,dtype=torch.uint8,device='cuda'); de=torch.zeros(B,cap,32,dtype=torch.uint8,device='cuda'); n=torch.zeros(B,dtype=torch.int32,device='cuda')
+for _ in range(2): ex.extract_batch_device(d,k,de,n)
+ex.sync()
+out=(C.c_ulonglong*8)()
+L.orbfe_debug_fc_profile(out,1)
+R=5
+for _ in range(R): ex.extract_batch_device(d,k,de,n)
+ex.sync()
+L.orbfe_debug_fc_profile(out,0)
+v=list(out)
+waves=v[6]; cells=v[7]
+names=["wait pixels","stage+clear","A1 quick test","A2 score","B NMS","C scan+emit"]
+tot=sum(v[:6])
+print("waves",waves/R,"cells",cells/R,"cycles/wave",tot/waves)
+for nme,x in zip(names,v[:6]): print(f"{nme:14s} {x/cells:9.0f} cycles/cell  {100*x/tot:5.1f}%")

@@ -62,8 +62,9 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
                 "each kernel; durations from the `--stats` pass of the same build.  FETCH / WRITE are KB as rocprofv3 reports them; FETCH is doubled "
                 "(x2) for kernels whose bulk reads are coalesced 16-byte-per-lane loads, which gfx950 tallies at half their bytes "
                 "(MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted, so read them as fabric-side traffic.  SQ_WAVE_CYCLES, "
-                "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles summed over waves.  `VALU busy` = SQ_INSTS_VALU x 2 clocks / (1024 SIMDs x kernel "
-                "clocks), kernel clocks = GRBM_GUI_ACTIVE / 8; `LDS busy` = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel clocks).\n\n")
+                "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles summed over waves.  `VALU busy` = SQ_ACTIVE_INST_VALU x 4 clocks / (1024 SIMDs x kernel "
+                "clocks) -- the time the SIMDs' vector ALUs were executing; an average above 2 clocks per instruction means slow-class instructions "
+                "(tools/valu_bench.hip: min/max, shifts, v_perm, packed-16, 3-operand integer at ~4.1 clocks; add/sub/logic/mov/FP32/16-bit VOP2 at ~2.1-2.8) --, kernel clocks = GRBM_GUI_ACTIVE / 8; `LDS busy` = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel clocks).\n\n")
         f.write("| kernel | us | FETCH KB | WRITE KB | alg. KB | L2 hit | waves | VALU / wave | SALU / wave | LDS / wave | VMEM / wave | wait | issue stall | VALU busy | LDS busy | LDS conflict |\n")
         f.write("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
         for k, c in cs.items():
@@ -80,7 +81,7 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
                     f"{'' if alg is None else format(alg, '.3g')} | {hit:.2f} | {w:.3g} | {c.get('SQ_INSTS_VALU', 0)/w:.0f} | {c.get('SQ_INSTS_SALU', 0)/w:.0f} | "
                     f"{c.get('SQ_INSTS_LDS', 0)/w:.0f} | {(c.get('SQ_INSTS_VMEM_RD', 0)+c.get('SQ_INSTS_VMEM_WR', 0))/w:.1f} | "
                     f"{c.get('SQ_WAIT_ANY', 0)/wc:.2f} | {c.get('SQ_WAIT_INST_ANY', 0)/wc:.2f} | "
-                    f"{(c.get('SQ_INSTS_VALU', 0)*2/(1024*clocks) if clocks else 0):.2f} | {(c.get('SQ_LDS_IDX_ACTIVE', 0)/(256*clocks) if clocks else 0):.2f} | "
+                    f"{(c.get('SQ_ACTIVE_INST_VALU', 0)*4/(1024*clocks) if clocks else 0):.2f} | {(c.get('SQ_LDS_IDX_ACTIVE', 0)/(256*clocks) if clocks else 0):.2f} | "
                     f"{c.get('SQ_LDS_BANK_CONFLICT', 0)/max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1):.2f} |\n")
         f.write("\n(`pyr_resize_dot_kernel`: average of the seven level launches.)\n")
     dom = max((k for k in cs if k in avg_us and not k.startswith("at::") and "rocclr" not in k), key=lambda k: avg_us[k])

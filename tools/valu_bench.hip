@@ -85,6 +85,34 @@ __global__ __launch_bounds__(256) void k_sdwa(unsigned* out, int iters) {
        "v_min_u32_sdwa %6, %6, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n"
        "v_min_u32_sdwa %7, %7, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n")
 }
+#define SD(op, sel) op " %0, %0, %1 " sel "\n" op " %1, %1, %2 " sel "\n" op " %2, %2, %3 " sel "\n" op " %3, %3, %4 " sel "\n" op " %4, %4, %5 " sel "\n" op " %5, %5, %6 " sel "\n" op " %6, %6, %7 " sel "\n" op " %7, %7, %0 " sel "\n"
+__global__ __launch_bounds__(256) void k_sdwa16(unsigned* out, int iters) {
+  BODY(SD("v_min_u16_sdwa", "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2"))
+}
+__global__ __launch_bounds__(256) void k_sdwa16w(unsigned* out, int iters) {
+  BODY(SD("v_max_u16_sdwa", "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_3"))
+}
+__global__ __launch_bounds__(256) void k_sdwasub(unsigned* out, int iters) {
+  BODY(SD("v_sub_u16_sdwa", "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_0"))
+}
+__global__ __launch_bounds__(256) void k_cmp16(unsigned* out, int iters) {
+  BODY("v_cmp_lt_u16 vcc, %0, %1\nv_cmp_lt_u16 s[10:11], %1, %2\nv_cmp_lt_u16 vcc, %2, %3\nv_cmp_lt_u16 s[10:11], %3, %4\n"
+       "v_cmp_lt_u16 vcc, %4, %5\nv_cmp_lt_u16 s[10:11], %5, %6\nv_cmp_lt_u16 vcc, %6, %7\nv_cmp_lt_u16 s[10:11], %7, %0\n")
+}
+__global__ __launch_bounds__(256) void k_cmp16sdwa(unsigned* out, int iters) {
+  BODY("v_cmp_lt_u16_sdwa vcc, %0, %1 src0_sel:BYTE_1 src1_sel:WORD_0\nv_cmp_lt_u16_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:WORD_0\n"
+       "v_cmp_lt_u16_sdwa vcc, %2, %3 src0_sel:BYTE_1 src1_sel:WORD_0\nv_cmp_lt_u16_sdwa vcc, %3, %4 src0_sel:BYTE_1 src1_sel:WORD_0\n"
+       "v_cmp_lt_u16_sdwa vcc, %4, %5 src0_sel:BYTE_1 src1_sel:WORD_0\nv_cmp_lt_u16_sdwa vcc, %5, %6 src0_sel:BYTE_1 src1_sel:WORD_0\n"
+       "v_cmp_lt_u16_sdwa vcc, %6, %7 src0_sel:BYTE_1 src1_sel:WORD_0\nv_cmp_lt_u16_sdwa vcc, %7, %0 src0_sel:BYTE_1 src1_sel:WORD_0\n")
+}
+__global__ __launch_bounds__(256) void k_cndmask(unsigned* out, int iters) {
+  BODY("v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %1, %1, %2, vcc\nv_cndmask_b32 %2, %2, %3, vcc\nv_cndmask_b32 %3, %3, %4, vcc\n"
+       "v_cndmask_b32 %4, %4, %5, vcc\nv_cndmask_b32 %5, %5, %6, vcc\nv_cndmask_b32 %6, %6, %7, vcc\nv_cndmask_b32 %7, %7, %0, vcc\n")
+}
+__global__ __launch_bounds__(256) void k_mbcnt(unsigned* out, int iters) {
+  BODY("v_mbcnt_lo_u32_b32 %0, %1, %0\nv_mbcnt_hi_u32_b32 %1, %2, %1\nv_mbcnt_lo_u32_b32 %2, %3, %2\nv_mbcnt_hi_u32_b32 %3, %4, %3\n"
+       "v_mbcnt_lo_u32_b32 %4, %5, %4\nv_mbcnt_hi_u32_b32 %5, %6, %5\nv_mbcnt_lo_u32_b32 %6, %7, %6\nv_mbcnt_hi_u32_b32 %7, %0, %7\n")
+}
 // LDS byte / dword reads: 8 independent loads per statement, addresses from the register chain (kept in range by the mask)
 __global__ __launch_bounds__(256) void k_ldsu8(unsigned* out, int iters) {
   __shared__ unsigned char sm[16384];
@@ -152,6 +180,8 @@ int main() {
   run("pk_min_u16", k_pkmin, d, 8); run("pk_sub_i16", k_pksub, d, 8); run("v_perm_b32", k_perm, d, 8);
   run("min_sdwa", k_sdwa, d, 8); run("mul_lo_u32", k_mul, d, 8); run("mul_u24", k_mul24, d, 8); run("v_sad_u8", k_sad, d, 8);
   run("dot4_u8", k_dot4, d, 8);
+  run("min_u16_sdwa", k_sdwa16, d, 8); run("max_u16_sdwa_w", k_sdwa16w, d, 8); run("sub_u16_sdwa", k_sdwasub, d, 8);
+  run("cmp_lt_u16", k_cmp16, d, 8); run("cmp_u16_sdwa", k_cmp16sdwa, d, 8); run("v_cndmask", k_cndmask, d, 8); run("v_mbcnt", k_mbcnt, d, 8);
   run("ds_read_u8", k_ldsu8, d, 8); run("ds_read_b32", k_ldsb32, d, 8);
   return 0;
 }
