@@ -53,6 +53,9 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
                 continue
             f.write(f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | "
                     f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+        f.write("\n`__amd_rocclr_copyBuffer` / `fillBufferAligned` and the `at::native` kernels belong to bench.py's set-up (uploading the synthetic "
+                "frames, one copy per image, before the first step) and result read-back; the kernel trace of a steady-state step holds none of "
+                "them (two `at::native` fills of the match buffers excepted).  Percentages are of the whole profiled process.\n")
     avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
     cs = counters(tag_dir)
     with open(out_prefix + "_pmc_counters.md", "w") as f:
