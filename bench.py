@@ -207,7 +207,7 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["ORBFE_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: ~1 s of timed region)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: ~1.2 s of timed region)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="kitti_stereo")
