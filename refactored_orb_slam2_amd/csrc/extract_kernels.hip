@@ -1374,14 +1374,17 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     for (int rr = 0; rr < 2; rr++) {
       const uint32_t* p = reinterpret_cast<const uint32_t*>(in + (2 * k + rr) * BT_INP + 4 * g);
       const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-      const uint32_t T1 = 18u | (34u << 8) | (48u << 16) | (56u << 24), T2 = 48u | (34u << 8) | (18u << 16);
-      o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), T2,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), T1, 0u, false), false);
-      o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), T2,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), T1, 0u, false), false);
-      o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), T2,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), T1, 0u, false), false);
-      o[rr][3] = __builtin_amdgcn_udot4(w2, T2, __builtin_amdgcn_udot4(w1, T1, 0u, false), false);
+      // output i = sum_j t_j * byte(i + 1 + j) of the 12-byte window (w0, w1, w2): instead of shifting the window with
+      // v_alignbyte (a 4-clock instruction like v_dot4 itself) the TAPS are shifted -- compile-time constants: 10 v_dot4
+      // and no shifts per four pixels where it was 8 + 6
+#define TAPS(a, b, c, d) ((uint32_t)(a) | ((uint32_t)(b) << 8) | ((uint32_t)(c) << 16) | ((uint32_t)(d) << 24))
+#define DOT4(x, t, acc) __builtin_amdgcn_udot4((x), (t), (acc), false)
+      o[rr][0] = DOT4(w1, TAPS(56, 48, 34, 18), DOT4(w0, TAPS(0, 18, 34, 48), 0u));
+      o[rr][1] = DOT4(w2, TAPS(18, 0, 0, 0), DOT4(w1, TAPS(48, 56, 48, 34), DOT4(w0, TAPS(0, 0, 18, 34), 0u)));
+      o[rr][2] = DOT4(w2, TAPS(34, 18, 0, 0), DOT4(w1, TAPS(34, 48, 56, 48), DOT4(w0, TAPS(0, 0, 0, 18), 0u)));
+      o[rr][3] = DOT4(w2, TAPS(48, 34, 18, 0), DOT4(w1, TAPS(18, 34, 48, 56), 0u));
+#undef DOT4
+#undef TAPS
     }
     uint4 st;
     st.x = o[0][0] | (o[1][0] << 16);
@@ -1401,7 +1404,7 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4*>(hbp + (rp + k) * BT_HP + 4 * g);
     const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;        // even row
     const uint32_t O0 = 18u << 16, O1 = 34u | (48u << 16), O2 = 56u | (48u << 16), O3 = 34u | (18u << 16);  // odd row
-    uint32_t outE = 0, outO = 0;
+    uint32_t aE[4], aO[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint32_t p0 = i == 0 ? P[0].x : i == 1 ? P[0].y : i == 2 ? P[0].z : P[0].w;
@@ -1412,9 +1415,13 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
       const uint32_t accE = UD2(p3, E3, UD2(p2, E2, UD2(p1, E1, UD2(p0, E0, 32768u))));
       const uint32_t accO = UD2(p3, O3, UD2(p2, O2, UD2(p1, O1, UD2(p0, O0, 32768u))));
 #undef UD2
-      outE |= (accE >> 16) << (8 * i);
-      outO |= (accO >> 16) << (8 * i);
+      aE[i] = accE;
+      aO[i] = accO;
     }
+    // every sum is < 2^24 (256 * 65280 + 32768), so the rounded pixel IS byte 2 of its accumulator: two v_perm + one or per
+    // four pixels instead of a shift and a shift-or each (all of them 4-clock instructions)
+    const uint32_t outE = __builtin_amdgcn_perm(aE[1], aE[0], 0x0c0c0602u) | __builtin_amdgcn_perm(aE[3], aE[2], 0x06020c0cu);
+    const uint32_t outO = __builtin_amdgcn_perm(aO[1], aO[0], 0x0c0c0602u) | __builtin_amdgcn_perm(aO[3], aO[2], 0x06020c0cu);
     const int gy = oy + 2 * rp, gx = ox + 4 * g;
     if (gx < w) {
       if (gy < h) *reinterpret_cast<uint32_t*>(D + (size_t)gy * dst.pitch[lvl] + gx) = outE;
