@@ -133,6 +133,29 @@ def _cpu_worker(args):
     return _cpu_frames(CONFIGS[name], frames, seq)
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the smaller of the online count, the affinity mask and the cgroup CPU quota
+    (a GPU box hands a job a share of its host, e.g. 16 of 256 hardware threads)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and period > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(n, 1)
+
+
 def cpu_baseline(name: str, sample_frames: int):
     """The CPU oracle (scalar C restatement of the reference path) on a bounded sample, with the reference's own threading
     (two extractor threads per stereo frame), plus a frame-parallel run on all host cores for context."""
@@ -142,6 +165,7 @@ def cpu_baseline(name: str, sample_frames: int):
     dt = _cpu_frames(cfg, sample_frames, 0)
     threads = 2 if cfg["stereo"] else 1
     nproc = os.cpu_count() or 1
+    usable = usable_cpus()
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -160,10 +184,10 @@ def cpu_baseline(name: str, sample_frames: int):
     out = {"value": round(sample_frames / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
            "sample": f"{sample_frames} synthetic frames of {cfg['label'].split(':')[0]} through oracle/orb_oracle.c "
                      f"({'left || right extraction on two threads as in Frame.cc:87-90, the rest on one' if cfg['stereo'] else 'one thread'}), {dt:.1f} s",
-           "nproc": nproc, "cpu_model": model or platform.processor(), "compiler": "gcc " + flags,
+           "nproc": nproc, "usable_cpus": usable, "cpu_model": model or platform.processor(), "compiler": "gcc " + flags,
            "note": "scalar restatement; OpenCV's SIMD FAST / resize / GaussianBlur would make the real reference faster"}
     # all cores, frame-parallel: every worker process runs whole frames (for stereo with its two extractor threads)
-    workers = max(1, nproc // threads)
+    workers = max(1, usable // threads)
     per = max(2, min(sample_frames, 24))
     try:
         ctx = mp.get_context("fork")
