@@ -1669,6 +1669,18 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
 // weights (u + 15, v + 15 and 1 inside the disc, 0 outside; a host-filled table) stay in registers for all eight keypoints, and
 // m10 = sum (u+15) I - 15 sum I, m01 = sum (v+15) I - 15 sum I -- integer, hence the same moments as the reference's loops.
 #define OD_K 8
+#if FC_TIMING
+__device__ unsigned long long g_od_prof[4096 * 8];
+extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
+  static unsigned long long h[4096 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_od_prof), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  for (int sl = 0; sl < 4096; sl++)
+    for (int i = 0; i < 8; i++) out[i] += h[sl * 8 + i];
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_od_prof), h, sizeof(h)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 __device__ __attribute__((aligned(16))) uint32_t g_ic_w[256 * 3];   // [item][u-weights | v-weights | inside], item = row * 8 + 4-column group
 __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
@@ -1685,14 +1697,18 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       bx = (int)(within >> 3);
     }
   }
+#if FC_TIMING
+  uint32_t tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tacc4 = 0, tacc5 = 0, tprev = (uint32_t)__builtin_readcyclecounter();
+#endif
   const int s0 = (bx * 4 + wv_id) * OD_K;
   const int32_t* ln = P.lvl_n + (size_t)img * ORBFE_MAX_LEVELS;
-  if (s0 == 0 && lane == 0) {
-    int tot = 0;
-    for (int l = 0; l < P.n_levels; l++) tot += ln[l];
-    P.out_n[img] = tot;
-  }
   if (s0 >= P.kp_per_image) return;
+  // Everything the prologue needs is requested before anything is waited for: the level counts (lane l holds ln[l]), the
+  // slot's packed record, the pattern and the moment weights.  (A store in front of these loads, or a load per loop
+  // iteration, serialised four or five memory round trips here: a fifth of the kernel's time, tools/fc_phase_profile.py.)
+  const int ln_lane = lane < P.n_levels ? ln[lane] : 0;
+  const int slot_c = min(s0 + (lane & (OD_K - 1)), P.kp_per_image - 1);
+  const uint32_t e_lane = P.lvl_kp[(size_t)img * P.kp_per_image + slot_c];
   float4 pk[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
@@ -1709,21 +1725,33 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
   int i_out = -1, i_level = 0, i_cx = 0, i_cy = 0, i_score = 0;
   {
     const int slot = s0 + lane;
-    if (lane < OD_K && slot < P.kp_per_image) {
-      int level = 0;
-      for (int l = 1; l < P.n_levels; l++) level += slot >= P.kp_off[l] ? 1 : 0;   // kp_off ascends
-      const int idx = slot - P.kp_off[level];
-      int out = idx;
-      for (int l = 0; l < P.n_levels; l++) out += l < level ? ln[l] : 0;
-      if (idx < ln[level] && out < P.cap) {
-        const uint32_t e = P.lvl_kp[(size_t)img * P.kp_per_image + slot];
-        i_out = out; i_level = level;
-        i_cx = (int)(e & 0xfff) + ORBFE_EDGE; i_cy = (int)((e >> 12) & 0xfff) + ORBFE_EDGE; i_score = (int)(e >> 24);
-      }
+    int level = 0, off_level = 0;
+    for (int l = 1; l < P.n_levels; l++) {   // kp_off ascends; it lives in the kernel arguments (scalar registers)
+      const bool ge = slot >= P.kp_off[l];
+      level += ge ? 1 : 0;
+      off_level = ge ? P.kp_off[l] : off_level;
+    }
+    const int idx = slot - off_level;
+    int out = idx, ln_level = 0;
+    for (int l = 0; l < P.n_levels; l++) {
+      const int lnl = __builtin_amdgcn_readlane(ln_lane, l);
+      out += l < level ? lnl : 0;
+      ln_level = l == level ? lnl : ln_level;
+    }
+    if (lane < OD_K && slot < P.kp_per_image && idx < ln_level && out < P.cap) {
+      const uint32_t e = e_lane;
+      i_out = out; i_level = level;
+      i_cx = (int)(e & 0xfff) + ORBFE_EDGE; i_cy = (int)((e >> 12) & 0xfff) + ORBFE_EDGE; i_score = (int)(e >> 24);
+    }
+    if (s0 == 0 && lane == 0) {   // the image's keypoint count = sum of the level counts
+      int tot = 0;
+      for (int l = 0; l < P.n_levels; l++) tot += __builtin_amdgcn_readlane(ln_lane, l);
+      P.out_n[img] = tot;
     }
   }
   const unsigned valid_mask = (unsigned)(__ballot(i_out >= 0) & 0xffu);
   if (valid_mask == 0) return;
+  FC_T(0);   // tables + slot bookkeeping
 
   // the loads of keypoint k's raw patch (two 16-byte pieces per lane) / blurred patch (three)
   auto issue_ori = [&](int k, uint4 vo[2]) {
@@ -1768,6 +1796,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
         const int r = i / 3, c = i - r * 3;
         if (i < 31 * 3) reinterpret_cast<uint4*>(ori)[r * (ORI_PITCH / 16) + c] = vn[j];
       }
+      FC_T(1);   // wait for the raw patch + LDS store
       const int kn = next_valid(k);
       if (kn < OD_K) issue_ori(kn, vn);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1789,6 +1818,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
                 St = __builtin_amdgcn_readlane(wave_incl_scan((int)S), 63);
       if (lane == k) { m10v = At - 15 * St; m01v = Bt - 15 * St; }
       __builtin_amdgcn_wave_barrier();   // every lane has read the patch before the next keypoint overwrites it
+      FC_T(2);   // moments
     }
   }
   // ---- phase 2: lane k computes keypoint k's angle and rotation; the first blurred patch is already on its way
@@ -1798,6 +1828,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a_v, b_v;
   glibc_sincosf(angle_v * factorPI, &b_v, &a_v);
+  FC_T(3);   // angle, sin / cos
   // ---- phase 3: steered BRIEF on the blurred level
   for (int k = k_first; k < OD_K; k = next_valid(k)) {
     const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
@@ -1810,6 +1841,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       const int i = lane + WAVE * j;
       if (i < 37 * 4) reinterpret_cast<uint4*>(dsc)[i] = wn[j];
     }
+    FC_T(4);   // wait for the blurred patch + LDS store
     const int kn = next_valid(k);
     if (kn < OD_K) issue_dsc(kn, wn);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1846,7 +1878,18 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       reinterpret_cast<uint32_t*>(P.out_kps + (size_t)img * P.cap + out)[lane] = wvv;
     }
     __builtin_amdgcn_wave_barrier();
+    FC_T(5);   // BRIEF + stores
   }
+#if FC_TIMING
+  if (lane == 0) {
+    unsigned long long* pr = g_od_prof + (size_t)((((unsigned)(bx * 4 + wv_id) + 977u * (unsigned)img) * 2654435761u) >> 20) * 8;
+    atomicAdd(&pr[0], (unsigned long long)tacc0); atomicAdd(&pr[1], (unsigned long long)tacc1);
+    atomicAdd(&pr[2], (unsigned long long)tacc2); atomicAdd(&pr[3], (unsigned long long)tacc3);
+    atomicAdd(&pr[4], (unsigned long long)tacc4); atomicAdd(&pr[5], (unsigned long long)tacc5);
+    atomicAdd(&pr[6], 1ull);
+    atomicAdd(&pr[7], (unsigned long long)__popc(valid_mask));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

@@ -25,3 +25,12 @@ names=["wait pixels","stage+clear","A1 quick test","A2 score","B NMS","C scan+em
 tot=sum(v[:6])
 print("waves",waves/R,"cells",cells/R,"cycles/wave",tot/waves)
 for nme,x in zip(names,v[:6]): print(f"{nme:14s} {x/cells:9.0f} cycles/cell  {100*x/tot:5.1f}%")
+
+out=(C.c_ulonglong*8)()
+L.orbfe_debug_od_profile(out,1)
+for _ in range(R): ex.extract_batch_device(d,k,de,n)
+ex.sync()
+L.orbfe_debug_od_profile(out,0)
+v=list(out); waves=v[6]; kps=v[7]; tot=sum(v[:6])
+print("describe8: waves",waves/R,"keypoints",kps/R,"cycles/wave",tot/max(waves,1))
+for nme,x in zip(["tables+bookkeeping","wait raw patch","moments","angle sincos","wait blurred patch","BRIEF+stores"],v[:6]): print(f"{nme:20s} {x/max(kps,1):9.0f} cycles/keypoint  {100*x/max(tot,1):5.1f}%")
