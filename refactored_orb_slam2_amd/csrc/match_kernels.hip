@@ -1107,17 +1107,24 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
     for (int j = 0; j < 5; j++) { acc[2 * j] = pk[j] & 0xffffu; acc[2 * j + 1] = pk[j] >> 16; }
     acc[10] = pk[5];
   }
-  if (lane != 0) return;
-  int sadBest = 2147483647, bestincR = 0;
-  float vDists[11];
+  // The eleven sums are wave-uniform integers (< 2^16, exact as floats): the reference's `dist < bestDist` walk over float
+  // distances is an integer first-minimum, done here on the scalar unit -- a vector instruction costs the same issue slots with
+  // one active lane as with 64, and this epilogue was a fifth of the kernel's vector instructions.
+  int sadBest = 2147483647, bk = 0;
+  int sacc[11];
 #pragma unroll
   for (int k = 0; k < 11; k++) {
-    const float dist = (float)acc[k];
-    if (dist < (float)sadBest) { sadBest = (int)dist; bestincR = k - L; }
-    vDists[k] = dist;
+    sacc[k] = __builtin_amdgcn_readfirstlane((int)acc[k]);
+    if (sacc[k] < sadBest) { sadBest = sacc[k]; bk = k; }
   }
+  const int bestincR = bk - L;
   if (bestincR == -L || bestincR == L) return;
-  const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+  int i1 = 0, i2 = 0, i3 = 0;
+#pragma unroll
+  for (int k = 1; k < 10; k++)
+    if (k == bk) { i1 = sacc[k - 1]; i2 = sacc[k]; i3 = sacc[k + 1]; }
+  if (lane != 0) return;
+  const float dist1 = (float)i1, dist2 = (float)i2, dist3 = (float)i3;
   const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
   if (deltaR < -1 || deltaR > 1) return;
   float bestuR = P.scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
