@@ -1302,6 +1302,13 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 }
 
 // ------------------------------------------------------------------------------------------------ blur
+// The blurred planes are read by nobody but the descriptor gather, which fetches a 37-row x 64-byte window per keypoint: one
+// memory request per window row in a row-major plane (~55 per keypoint).  They are therefore stored TILED: 16 pixels x 8 rows
+// = one 128-byte line, tiles in raster order (pitch / 16 tiles per tile row).  A window then touches ~4 x 6 tiles.
+// Byte offset of pixel (x, y); x, y >= 0:
+__device__ __forceinline__ size_t blur_tiled_offset(int x, int y, int pitch) {
+  return ((size_t)(y >> 3) * (size_t)(pitch >> 4) + (size_t)(x >> 4)) * 128 + (size_t)((y & 7) * 16 + (x & 15));
+}
 // 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps [18,34,48,56,48,34,18], exact 16.16 accumulation,
 // round half up.  One 64x32 output tile per workgroup, separable through LDS.  Interior tiles stage the
 // (64+8)x(32+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
@@ -1423,9 +1430,9 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     const uint32_t outE = __builtin_amdgcn_perm(aE[1], aE[0], 0x0c0c0602u) | __builtin_amdgcn_perm(aE[3], aE[2], 0x06020c0cu);
     const uint32_t outO = __builtin_amdgcn_perm(aO[1], aO[0], 0x0c0c0602u) | __builtin_amdgcn_perm(aO[3], aO[2], 0x06020c0cu);
     const int gy = oy + 2 * rp, gx = ox + 4 * g;
-    if (gx < w) {
-      if (gy < h) *reinterpret_cast<uint32_t*>(D + (size_t)gy * dst.pitch[lvl] + gx) = outE;
-      if (gy + 1 < h) *reinterpret_cast<uint32_t*>(D + (size_t)(gy + 1) * dst.pitch[lvl] + gx) = outO;
+    if (gx < w) {   // gx is a multiple of 4: the four pixels lie in one tile row
+      if (gy < h) *reinterpret_cast<uint32_t*>(D + blur_tiled_offset(gx, gy, dst.pitch[lvl])) = outE;
+      if (gy + 1 < h) *reinterpret_cast<uint32_t*>(D + blur_tiled_offset(gx, gy + 1, dst.pitch[lvl])) = outO;
     }
     }
   }
@@ -1583,7 +1590,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) 
   for (int k = 0; k < 3; k++) {
     const int i = lane + WAVE * k;
     const int r = i >> 2, c = i & 3;
-    vd[k] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 16 * c) : make_uint4(0, 0, 0, 0);
+    vd[k] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + blur_tiled_offset(max(ax_d + 16 * c, 0), max(cy - 18 + r, 0), bpitch)) : make_uint4(0, 0, 0, 0);
   }
 #pragma unroll
   for (int k = 0; k < 2; k++) {
@@ -1775,7 +1782,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     for (int j = 0; j < 3; j++) {
       const int i = lane + WAVE * j;
       const int r = i >> 2, c = i & 3;
-      vd[j] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + (size_t)(cy - 18 + r) * bpitch + ax_d + 16 * c) : make_uint4(0, 0, 0, 0);
+      vd[j] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + blur_tiled_offset(max(ax_d + 16 * c, 0), max(cy - 18 + r, 0), bpitch)) : make_uint4(0, 0, 0, 0);
     }
   };
   // next valid slot after k (OD_K if none)

@@ -199,7 +199,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
       return ORBFE_ERR_INVALID;
     }
     g.pitch = (g.w + 63) & ~63;
-    g.plane = ((size_t)g.pitch * g.h + 255) & ~(size_t)255;
+    g.plane = ((size_t)g.pitch * ((g.h + 7) & ~7) + 255) & ~(size_t)255;   // rows padded to 8: the blurred planes are stored in 16 x 8 tiles
     g.off = off;  // per-image offsets; the buffer is level-major: level block = plane * cap_images
     off += g.plane;
   }
@@ -916,7 +916,13 @@ extern "C" int orbfe_debug_blurred(orbfe_extractor* e, int image, int level, uin
   HIPCHK(hipSetDevice(e->device));
   const LevelGeom& g = e->lg[level];
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy2D(dst, dst_stride, level_ptr(e, e->d_blur, level, image), g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
+  // the blurred planes are stored in 16 x 8 pixel tiles (one 128-byte line each, extract_kernels.hip): untile on the host
+  const int hp = (g.h + 7) & ~7;
+  std::vector<uint8_t> tiled((size_t)g.pitch * hp);
+  HIPCHK(hipMemcpy(tiled.data(), level_ptr(e, e->d_blur, level, image), tiled.size(), hipMemcpyDeviceToHost));
+  for (int y = 0; y < g.h; y++)
+    for (int x = 0; x < g.w; x++)
+      dst[(size_t)y * dst_stride + x] = tiled[((size_t)(y >> 3) * (g.pitch >> 4) + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15)];
   return ORBFE_OK;
 }
 
