@@ -10,6 +10,7 @@
 // stereo_median       median-based outlier cut                                 L/src/Frame.cc:634-645
 //
 // Compiled with -ffp-contract=off: every float expression is evaluated un-fused, as the reference does.
+#include <string.h>
 #include "match_internal.h"
 
 #define WAVE 64
@@ -956,6 +957,30 @@ __device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) 
   asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+#ifndef FC_TIMING
+#define FC_TIMING 0
+#endif
+#if FC_TIMING
+// -DFC_TIMING=1 (tools/fc_phase_profile.py): wave-cycles of stereo_match_kernel per phase, 4096 accumulation slots
+__device__ unsigned long long g_sm_prof[4096 * 8];
+extern "C" int orbfe_debug_sm_profile(unsigned long long* out, int reset) {
+  static unsigned long long h[4096 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sm_prof), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  for (int sl = 0; sl < 4096; sl++)
+    for (int i = 0; i < 8; i++) out[i] += h[sl * 8 + i];
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_sm_prof), h, sizeof(h)) != hipSuccess) return 1; }
+  return 0;
+}
+#define SM_T(i) do { const uint32_t _t = (uint32_t)__builtin_readcyclecounter(); tacc##i += _t - tprev; tprev = _t; } while (0)
+#define SM_END() do { if (lane == 0) { unsigned long long* pr = g_sm_prof + (size_t)((((unsigned)iL + 4099u * (unsigned)pair) * 2654435761u) >> 20) * 8; \
+    atomicAdd(&pr[0], (unsigned long long)tacc0); atomicAdd(&pr[1], (unsigned long long)tacc1); atomicAdd(&pr[2], (unsigned long long)tacc2); \
+    atomicAdd(&pr[3], (unsigned long long)tacc3); atomicAdd(&pr[4], (unsigned long long)tacc4); atomicAdd(&pr[5], (unsigned long long)tacc5); \
+    atomicAdd(&pr[6], 1ull); } } while (0)
+#else
+#define SM_T(i)
+#define SM_END()
+#endif
 #define SAD_LP 20   // LDS pitch of the staged left window (5 dwords)
 #define SAD_RP 24   // LDS pitch of the staged right window (6 dwords)
 __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
@@ -978,6 +1003,9 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const orbfe_keypoint kpL = kl[iL];
   uint4 a0, a1;
   load_desc(dl + (size_t)iL * 32, a0, a1);
+#if FC_TIMING
+  uint32_t tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tacc4 = 0, tacc5 = 0, tprev = (uint32_t)__builtin_readcyclecounter();
+#endif
   if (lane == 0) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
   if (iL >= nL) return;
   // every lane read the same record: tell the compiler, so that the per-level parameters become scalar loads
@@ -994,6 +1022,10 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
   const int4* bent = reinterpret_cast<const int4*>(P.bucket_idx) + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
   const int e0 = bs[row >> 3], e1 = bs[(row >> 3) + 1];
+#if FC_TIMING
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  SM_T(0);   // own record, descriptor, bucket range
   // two 64-entry chunks of the bucket in flight: bucket records (index, x, y, octave), then -- for the survivors of
   // the band / level / disparity tests -- descriptors: two memory round trips for up to 128 candidates
   for (int eb = e0; eb < e1; eb += 2 * WAVE) {
@@ -1027,18 +1059,20 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
         }
       }
   }
+  SM_T(1);   // bucket records + descriptors + Hamming
   // first minimum in index order; the winning lane also holds the right keypoint's x
   float uR0;
   {
     const unsigned k = ((best >> 16) < (unsigned)ORBFE_TH_HIGH) ? best : 0xFFFFFFFFu;
     best = wave_min_u32(k);
-    if (best == 0xFFFFFFFFu) return;
+    if (best == 0xFFFFFFFFu) { SM_END(); return; }
     const unsigned long long wm = __ballot(k == best);
     uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_x), __ffsll((long long)wm) - 1));
   }
   const int bestDist = (int)(best >> 16);
   const int thOrbDist = (ORBFE_TH_HIGH + ORBFE_TH_LOW) / 2;
-  if (!(bestDist < thOrbDist)) return;
+  if (!(bestDist < thOrbDist)) { SM_END(); return; }
+  SM_T(2);   // reduction
 
   // sub-pixel refinement by 11x11 SAD over 11 shifts (L/src/Frame.cc:557-631)
   const float sfac = P.inv_scale[levelL];
@@ -1078,6 +1112,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  SM_T(3);   // SAD windows: global loads -> LDS
   const uint8_t* WL = winL + (xW - axL);
   const uint8_t* WR = winR + (xR0 - axR);
   // |a - b| with a = IL - cL, b = IR - cR[k]: both biased by +255 so that v_sad_u32 (|x - y| + acc) applies
@@ -1110,6 +1145,8 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   // The eleven sums are wave-uniform integers (< 2^16, exact as floats): the reference's `dist < bestDist` walk over float
   // distances is an integer first-minimum, done here on the scalar unit -- a vector instruction costs the same issue slots with
   // one active lane as with 64, and this epilogue was a fifth of the kernel's vector instructions.
+  SM_T(4);   // SAD sums + wave reductions
+  SM_END();
   int sadBest = 2147483647, bk = 0;
   int sacc[11];
 #pragma unroll

@@ -34,3 +34,21 @@ L.orbfe_debug_od_profile(out,0)
 v=list(out); waves=v[6]; kps=v[7]; tot=sum(v[:6])
 print("describe8: waves",waves/R,"keypoints",kps/R,"cycles/wave",tot/max(waves,1))
 for nme,x in zip(["tables+bookkeeping","wait raw patch","moments","angle sincos","wait blurred patch","BRIEF+stores"],v[:6]): print(f"{nme:20s} {x/max(kps,1):9.0f} cycles/keypoint  {100*x/max(tot,1):5.1f}%")
+
+# ---- stereo_match_kernel
+from refactored_orb_slam2_amd.matcher import Matcher
+pairs=synth.sequence(W,H,8,seq=5,stereo=True)
+Lt=torch.from_numpy(np.stack([pairs[i%8][0] for i in range(B)])).cuda(); Rt=torch.from_numpy(np.stack([pairs[i%8][1] for i in range(B)])).cuda()
+exR=ORBextractor(NF,device=0); mt=Matcher(0)
+kr=torch.zeros_like(k); dr=torch.zeros_like(de); nr=torch.zeros_like(n)
+ur=torch.zeros(B,cap,dtype=torch.float32,device='cuda'); dp=torch.zeros_like(ur); ns=torch.zeros_like(n)
+ex.extract_batch_device(Lt,k,de,n); exR.extract_batch_device(Rt,kr,dr,nr); ex.sync(); exR.sync()
+out=(C.c_ulonglong*8)()
+mt.stereo_match(ex,exR,k,de,n,kr,dr,nr,386.1448,386.1448/718.856,ur,dp,ns); torch.cuda.synchronize()
+L.orbfe_debug_sm_profile(out,1)
+for _ in range(R): mt.stereo_match(ex,exR,k,de,n,kr,dr,nr,386.1448,386.1448/718.856,ur,dp,ns)
+torch.cuda.synchronize()
+L.orbfe_debug_sm_profile(out,0)
+v=list(out); waves=v[6]; tot=sum(v[:6])
+print("stereo_match: waves recorded",waves/R,"cycles/wave",tot/max(waves,1))
+for nme,x in zip(["own record+range","bucket+Hamming","min reduction","window loads->LDS","SAD+reductions","-"],v[:6]): print(f"{nme:20s} {x/max(waves,1):9.0f} cycles/wave  {100*x/max(tot,1):5.1f}%")
