@@ -62,3 +62,56 @@ def test_matcher_dropin_all_eleven_methods_on_gpu(tmp_path, geom):
                 "SearchByProjection(KF, Scw) ok", "SearchByBoW ok", "SearchForInitialization ok", "SearchForTriangulation ok",
                 "SearchBySim3 ok", "Fuse ok", "Fuse(Sim3) ok", "matcher dropin ok"):
         assert tag in r.stdout, r.stdout
+
+
+# ---- the C ABI from plain C99 (examples/extract_c.c): what a cgo / JNI / FFI binding would do
+def _build_c_example(tmp_path):
+    from refactored_orb_slam2_amd import _lib
+    _lib.build()
+    exe = str(tmp_path / "extract_c")
+    csrc = os.path.join(ROOT, "refactored_orb_slam2_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "extract_c.c"), "-L" + csrc, "-lorbfe", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True, capture_output=True)
+    return exe
+
+
+def _png(path, img):
+    import struct, zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    h, w = img.shape
+    rows = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rows, 6)) +
+                chunk(b"IEND", b""))
+
+
+def test_c99_example_builds_and_fails_loudly_without_device(tmp_path):
+    """include/orbfe.h is valid C99 (-pedantic -Werror) and the plain-C caller gets ORBFE_ERR_NO_DEVICE, not a CPU result."""
+    import ctypes as C
+    from refactored_orb_slam2_amd import _lib, synth
+    exe = _build_c_example(tmp_path)
+    n = C.c_int(0)
+    if _lib.lib().orbfe_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    _png(tmp_path / "a.png", synth.sequence(320, 240, 1, seq=4)[0])
+    r = subprocess.run([exe, str(tmp_path / "a.png")], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c99_example_matches_the_oracle(tmp_path):
+    from refactored_orb_slam2_amd import synth
+    from tests import oracle_lib as ol
+    exe = _build_c_example(tmp_path)
+    img = synth.sequence(640, 480, 1, seq=4)[0]
+    _png(tmp_path / "a.png", img)
+    r = subprocess.run([exe, str(tmp_path / "a.png"), "1000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    k, d = ol.OracleExtractor(1000)(img)
+    s = 0
+    for b in d.reshape(-1).tolist():
+        s = ((s * 16777619) & 0xffffffff) ^ b
+    assert f"640x480: {len(k)} keypoints, descriptor checksum {s:08x}" in r.stdout, r.stdout
+    assert f"kp 0: ({k['x'][0]:.1f}, {k['y'][0]:.1f}) octave {k['octave'][0]}" in r.stdout
