@@ -93,7 +93,7 @@ struct orbfe_extractor {
   int max_nodes = 0, lds_keys = 0;
   size_t oct_lds = 0;
   // device tables
-  DevBuf d_cells, d_groups, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];
+  DevBuf d_cells, d_groups, d_groups1, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];   // d_groups1: one cell per run (small batches)
   int resize_mode[ORBFE_MAX_LEVELS]{};  // 0: direct gathers; 1: every 256x16 destination tile's source window fits the LDS stage;
                                          // 2: and every aligned group of four destination pixels reads at most 8 adjacent source bytes
   // work space for `cap_images`
@@ -342,6 +342,19 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   int rc;
   if ((rc = upload(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), e->stream))) return rc;
   if ((rc = upload(e->d_groups, e->groups.data(), e->groups.size() * sizeof(FastGroup), e->stream))) return rc;
+  {
+    // one cell per run: with a handful of images the chip has more wave slots than cells, and a wave that walks four cells one
+    // after the other is four times the latency of the stage (single-image FAST 40 -> 12 us)
+    std::vector<FastGroup> g1(e->cells.size());
+    for (size_t i = 0; i < e->cells.size(); i++) {
+      memset(&g1[i], 0, sizeof(FastGroup));
+      g1[i].first_cell = (int32_t)i;
+      g1[i].n_cells = 1;
+      g1[i].level = e->cells[i].level;
+    }
+    if ((rc = upload(e->d_groups1, g1.data(), g1.size() * sizeof(FastGroup), e->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));   // g1 goes out of scope
+  }
   if ((rc = upload(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(BlurTile), e->stream))) return rc;
   for (int l = 1; l < nl; l++) {
     std::vector<ResizeTap> xt, yt;
@@ -493,7 +506,10 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   if (fork) (void)hipEventRecord(e->ev_blur, sb);
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
-    orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)e->d_groups.p, (int)e->groups.size(),
+    static const bool wave_per_cell = !(getenv("ORBFE_FAST_VARIANT") && atoi(getenv("ORBFE_FAST_VARIANT")) == 1);   // the A/B kernel needs real groups
+    const bool few = wave_per_cell && n_images <= 8;   // 8 x 1220 cells = 9.8 k waves: ~1.4 rounds of the chip's resident waves
+    orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)(few ? e->d_groups1.p : e->d_groups.p),
+                             few ? e->total_cells : (int)e->groups.size(),
                              e->total_cells, e->fg_tile_rows, e->fg_clist_cap, e->fc_rows, e->fc_span, e->fc_sc, e->fc_bits,
                              (int32_t*)e->d_cell_cnt.p,
                              (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast,
@@ -627,7 +643,7 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   drain_events(e);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-  DevBuf* bufs[] = {&e->d_cells, &e->d_groups, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
+  DevBuf* bufs[] = {&e->d_cells, &e->d_groups, &e->d_groups1, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
                     &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
   for (auto b : bufs) dev_free(*b);
   dev_free(e->d_in_stage);
@@ -761,21 +777,32 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     if (stride == w) memcpy(dst, imgs[i], img_bytes);
     else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, imgs[i] + (size_t)y * stride, (size_t)w);
   }
-  HIPCHK(hipMemcpyAsync(e->d_in_stage.p, e->h_in, img_bytes * B, hipMemcpyHostToDevice, s));
+  // Latency path (a frame or a stereo pair at a time, what the C++ drop-in does): no copy engine at all.  The level-0 kernel
+  // reads the pinned staging buffer over PCIe itself and the descriptor kernel writes keypoints, descriptors and counts
+  // straight into pinned host memory (hipHostMalloc memory is device-addressable); each memcpy on the stream costs a launch
+  // and a dependency gap (~10 us) that a 120 KB result does not repay.  Larger batches keep the DMA copies.
+  static const bool zero_copy_ok = !(getenv("ORBFE_ZERO_COPY") && atoi(getenv("ORBFE_ZERO_COPY")) == 0);   // A/B knob
+  const bool zc = zero_copy_ok && n_images <= 2;
+  uint8_t* ho = (uint8_t*)e->h_out;
+  if (!zc) HIPCHK(hipMemcpyAsync(e->d_in_stage.p, e->h_in, img_bytes * B, hipMemcpyHostToDevice, s));
   {
     StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
-    orbfe_launch_copy0((const uint8_t*)e->d_in_stage.p, w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch,
+    orbfe_launch_copy0((const uint8_t*)(zc ? e->h_in : e->d_in_stage.p), w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch,
                        e->lg[0].plane, w, h, n_images, s);
   }
   int32_t* d_hdr = (int32_t*)e->d_out_n.p;
-  if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap, d_hdr, s)))
-    return rc;
-  // results: header (counts + device error word) and the full padded records, one sync
-  HIPCHK(hipMemcpyAsync(d_hdr + B, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  uint8_t* ho = (uint8_t*)e->h_out;
-  HIPCHK(hipMemcpyAsync(ho, d_hdr, sizeof(int32_t) * (B + 1), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(ho + hdr_bytes, e->d_out_kps.p, kp_bytes, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(ho + hdr_bytes + kp_bytes, e->d_out_desc.p, desc_bytes, hipMemcpyDeviceToHost, s));
+  if (zc) {
+    if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)(ho + hdr_bytes), ho + hdr_bytes + kp_bytes, cap, (int32_t*)ho, s))) return rc;
+    HIPCHK(hipMemcpyAsync(ho + sizeof(int32_t) * B, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  } else {
+    if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap, d_hdr, s)))
+      return rc;
+    // results: header (counts + device error word) and the full padded records, one sync
+    HIPCHK(hipMemcpyAsync(d_hdr + B, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(ho, d_hdr, sizeof(int32_t) * (B + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ho + hdr_bytes, e->d_out_kps.p, kp_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ho + hdr_bytes + kp_bytes, e->d_out_desc.p, desc_bytes, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(hipStreamSynchronize(s));
   if (e->profile) drain_events(e);
   const int32_t* hn = (const int32_t*)ho;
