@@ -1016,10 +1016,24 @@ size_t orbfe_octree_lds_bytes(int M, int lds_keys) {
   return (size_t)M * (12 + 12 + 16 + 8 + 4 + 4) + (size_t)lds_keys * 8 + 64 * 4 + ORBFE_MAX_INI * 8 + 256;
 }
 
+#if FC_TIMING
+__device__ unsigned long long g_oct_prof[64];   // [level] cycles, [32 + level] iterations of the subdivision loop
+extern "C" int orbfe_debug_oct_profile(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_prof), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[64]; memset(z, 0, sizeof(z)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
-  const int level = blockIdx.x, img = blockIdx.y;
+  // grid = (images, levels): workgroups start level-major, the long ones (level 0: ~120 k cycles, level 7: ~45 k) first, so the
+  // tail of the launch is made of short workgroups (image-major order ran as two rounds of the longest one: 110 -> 80 us)
+  const int level = blockIdx.y, img = blockIdx.x;
+#if FC_TIMING
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  int n_iter = 0;
+#endif
   const OctLevel L = P.lv[level];
   const int M = P.max_nodes;
 
@@ -1112,6 +1126,9 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   bool finish = (size == 0);
   const int N = L.N;
   while (!finish) {
+#if FC_TIMING
+    n_iter++;
+#endif
     const int prev = size;
     for (int i = tid; i < size * 4; i += 256) cnt4[i] = 0;
     __syncthreads();
@@ -1298,6 +1315,10 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   if (tid == 0) {
     if (size > L.kp_cap) atomicOr(P.err, 4);
     P.lvl_n[(size_t)img * ORBFE_MAX_LEVELS + level] = size < L.kp_cap ? size : L.kp_cap;
+#if FC_TIMING
+    atomicAdd(&g_oct_prof[level], __builtin_readcyclecounter() - t_begin);
+    atomicAdd(&g_oct_prof[32 + level], (unsigned long long)n_iter);
+#endif
   }
 }
 
@@ -1987,7 +2008,7 @@ void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const F
 }
 
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s) {
-  dim3 block(ORBFE_OCT_THREADS), grid(p.n_levels, n_images);
+  dim3 block(ORBFE_OCT_THREADS), grid(n_images, p.n_levels);
   hipLaunchKernelGGL(octree_select_kernel, grid, block, lds_bytes, s, p);
 }
 

@@ -35,6 +35,14 @@ v=list(out); waves=v[6]; kps=v[7]; tot=sum(v[:6])
 print("describe8: waves",waves/R,"keypoints",kps/R,"cycles/wave",tot/max(waves,1))
 for nme,x in zip(["tables+bookkeeping","wait raw patch","moments","angle sincos","wait blurred patch","BRIEF+stores"],v[:6]): print(f"{nme:20s} {x/max(kps,1):9.0f} cycles/keypoint  {100*x/max(tot,1):5.1f}%")
 
+# ---- octree_select_kernel: cycles and subdivision iterations per level
+out64=(C.c_ulonglong*64)()
+L.orbfe_debug_oct_profile(out64,1)
+for _ in range(R): ex.extract_batch_device(d,k,de,n)
+ex.sync()
+L.orbfe_debug_oct_profile(out64,0)
+print("octree: level, cycles per workgroup, loop iterations per workgroup")
+for l in range(8): print(f"  level {l}: {out64[l]/(R*B):9.0f} cycles  {out64[32+l]/(R*B):5.1f} iterations")
 # ---- stereo_match_kernel
 from refactored_orb_slam2_amd.matcher import Matcher
 pairs=synth.sequence(W,H,8,seq=5,stereo=True)
