@@ -91,6 +91,14 @@ def test_batch_equals_single_and_is_idempotent():
     batch = ex.extract_batch(imgs)
     for (k1, d1), (k2, d2) in zip(single, batch):
         np.testing.assert_array_equal(k1, k2); np.testing.assert_array_equal(d1, d2)
+    # the three host paths: one or two images (zero-copy through pinned memory, one FAST cell per wave), up to eight (DMA copies,
+    # one cell per wave), more (runs of four cells) -- B = 6 above is the middle one, a pair and a batch of 9 the other two
+    pair = ex.extract_batch(imgs[1:3])
+    for (k1, d1), (k2, d2) in zip(single[1:3], pair):
+        np.testing.assert_array_equal(k1, k2); np.testing.assert_array_equal(d1, d2)
+    nine = ex.extract_batch(imgs + imgs[:3])
+    for (k1, d1), (k2, d2) in zip(single + single[:3], nine):
+        np.testing.assert_array_equal(k1, k2); np.testing.assert_array_equal(d1, d2)
     # device-resident path, non-contiguous source rows (stride > width), twice (idempotence)
     pad = np.zeros((B, h, w + 37), np.uint8)
     pad[:, :, :w] = np.stack(imgs)
