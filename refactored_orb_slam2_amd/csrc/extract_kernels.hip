@@ -740,7 +740,6 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
   const int level = g.level;
   const int pitch = pyr.pitch[level];
   const uint8_t* plane = pyr.base[level] + (size_t)img * pyr.img_stride[level];
-  const uint32_t C = (uint32_t)(0x8000 - min_th - 1) * 0x00010001u;
   const uint32_t tile_a = (uint32_t)(uintptr_t)tile;
 
   uint4 pv[NLD];
@@ -811,9 +810,10 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
     }
     FC_T(1);   // LDS staging + clears
 
-    // ---- A2 (called whenever the list is more than half full, and at the end): exact score of list[0 .. n), the polarity
-    //      (or, about once in 10^4, the two polarities) the quick test left possible
-    auto score_list = [&](int n) {
+    // ---- A2 (called when the list is nearly full -- `mark`: the list is about to be recycled, so scored pixels are also
+    //      recorded in the bitmap -- and at the end): exact score of list[0 .. n), the polarity (or, about once in 10^4, the
+    //      two polarities) the quick test left possible
+    auto score_list = [&](int n, bool mark, int th_cur) {
       for (int i = lane; i < n; i += WAVE) {
         const uint32_t en = list[i];
         const int e = (int)(en & 0x3fffu);
@@ -834,129 +834,181 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         if (__ballot((en & 0xC000u) == 0xC000u)) {   // both polarities survived the quick test (about once in 10^4): wave-uniform
           if ((en & 0xC000u) == 0xC000u) s = max(s, arc9_maxmin_pk(P, VV, 0u));
         }
-        if (s - 1 >= min_th) {
+        if (s - 1 >= th_cur) {
           const int ty = y - 3, tx = x - c_lo;
           sc[(ty + 1) * SCP + tx + 1] = (uint8_t)(s - 1);
-          const int p = ty * tw + tx;
-          atomicOr(&scb[p >> 5], 1u << (p & 31));
+          if (mark) {
+            const int p = ty * tw + tx;
+            atomicOr(&scb[p >> 5], 1u << (p & 31));
+          }
         }
       }
     };
 
-    // ---- A1
-    if (th > 0 && tw > 0) {
-      const int ppr = (tw + 1) >> 1;                 // <= 30
-      const int RI = WAVE / ppr;                     // rows per iteration, >= 2
-      const int rl = (int)((lane + 0.5f) * (1.0f / (float)ppr)), pl = lane - rl * ppr;
-      const bool lane_ok = rl < RI;
-      const int n_it = (th + RI - 1) / RI;
-      const int x = c_lo + 2 * pl;                   // even: the pair (x, x + 1) starts at byte 0 or 2 of its dword
-      const bool odd2 = (x & 2) != 0;
-      const uint32_t selV = odd2 ? 0x0c030c02u : 0x0c010c00u;    // (x, x+1) and (x, x+1) of rows +-3
-      const uint32_t selX = odd2 ? 0x0c010c00u : 0x0c030c02u;    // (x+-2, x+-2+1)
-      const uint32_t selM = odd2 ? 0x0c040c03u : 0x0c020c01u;    // (x-3, x-2) out of dwords {D(x)-1, D(x)}
-      const uint32_t selP = odd2 ? 0x0c020c01u : 0x0c040c03u;    // (x+3, x+4) out of dwords {D(x+2), D(x+2)+1}
-      int e = (3 + rl) * PB + x;                     // byte index of the pair's first pixel
-      // addresses of row (y - 3): the dword of x (minus one dword: the centre row reads {D-1, D}), of x + 2, of x - 2
-      uint32_t a0 = tile_a + rl * PB + ((x >> 2) << 2) - 4;
-      uint32_t ap = tile_a + rl * PB + (((x + 2) >> 2) << 2);
-      uint32_t am = tile_a + rl * PB + (((x - 2) >> 2) << 2);
+    // The reference's own order (L/src/ORBextractor.cc:773-780): cv::FAST(cell, iniThFAST) first, cv::FAST(cell, minThFAST)
+    // only when that returned nothing.  Pass 0 runs quick test, score, NMS at ini_th; a cell whose pass 0 keeps no pixel
+    // (wave-uniform) repeats them at min_th from the tile that is still staged.
+    uint32_t keep[2] = {0u, 0u};
+    int total = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      const int th_cur = pass ? min_th : ini_th;
+      const uint32_t C = (uint32_t)(0x8000 - th_cur - 1) * 0x00010001u;
+      bool flushed = false;
       int wcnt = 0;
-      for (int it = 0; it < n_it; it++, e += RI * PB, a0 += RI * PB, ap += RI * PB, am += RI * PB) {
-        const bool act = lane_ok && (it * RI + rl) < th;   // inactive lanes read in-range garbage: rows < rows_max + RI
-        unsigned long long p08, pc, pp, p62, p1014;
-        asm volatile(
-            "ds_read2_b32 %0, %5 offset0:1 offset1:%8\n\t"
-            "ds_read2_b32 %1, %5 offset0:%9 offset1:%10\n\t"
-            "ds_read2_b32 %2, %6 offset0:%11 offset1:%12\n\t"
-            "ds_read2_b32 %3, %6 offset0:%13 offset1:%14\n\t"
-            "ds_read2_b32 %4, %7 offset0:%13 offset1:%14\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(p08), "=&v"(pc), "=&v"(pp), "=&v"(p62), "=&v"(p1014)
-            : "v"(a0), "v"(ap), "v"(am), "n"(6 * PB / 4 + 1), "n"(3 * PB / 4), "n"(3 * PB / 4 + 1), "n"(3 * PB / 4),
-              "n"(3 * PB / 4 + 1), "n"(PB / 4), "n"(5 * PB / 4)
-            : "memory");
-        const uint32_t D0 = (uint32_t)(pc >> 32), Dm = (uint32_t)pc;
-        const uint32_t V = __builtin_amdgcn_perm(0u, D0, selV);
-        const uint32_t Q8 = __builtin_amdgcn_perm(0u, (uint32_t)p08, selV), Q0 = __builtin_amdgcn_perm(0u, (uint32_t)(p08 >> 32), selV);
-        const uint32_t Q12 = __builtin_amdgcn_perm(D0, Dm, selM);
-        const uint32_t Q4 = __builtin_amdgcn_perm((uint32_t)(pp >> 32), (uint32_t)pp, selP);
-        const uint32_t Q6 = __builtin_amdgcn_perm(0u, (uint32_t)p62, selX), Q2 = __builtin_amdgcn_perm(0u, (uint32_t)(p62 >> 32), selX);
-        const uint32_t Q10 = __builtin_amdgcn_perm(0u, (uint32_t)p1014, selX), Q14 = __builtin_amdgcn_perm(0u, (uint32_t)(p1014 >> 32), selX);
-        const uint32_t AD = V + C, AB = C - V;
-        // one of every antipodal pair is darker than v - t  <=>  max over the pairs of the pair minimum is; same for brighter
-        const uint32_t lo = pkmax(pkmax(pkmin(Q0, Q8), pkmin(Q2, Q10)), pkmax(pkmin(Q4, Q12), pkmin(Q6, Q14)));
-        const uint32_t hi = pkmin(pkmin(pkmax(Q0, Q8), pkmax(Q2, Q10)), pkmin(pkmax(Q4, Q12), pkmax(Q6, Q14)));
-        const uint32_t dark = AD - lo, brt = hi + AB;
-        const uint32_t G = act ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
-        const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
-        const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
-        const int n0 = __popcll(m0);
-        const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
-        const int i1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)(wcnt + n0)));
-        if (has0) list[i0] = (uint16_t)((G & 0xC000u) | (uint32_t)e);
-        if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (uint32_t)(e + 1));
-        wcnt += n0 + __popcll(m1);
-        if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
-          FC_T(2);
-          score_list(wcnt);
-          FC_T(3);
-          wcnt = 0;
+      // ---- A1
+      if (th > 0 && tw > 0) {
+        const int ppr = (tw + 1) >> 1;                 // <= 30
+        const int RI = WAVE / ppr;                     // rows per iteration, >= 2
+        const int rl = (int)((lane + 0.5f) * (1.0f / (float)ppr)), pl = lane - rl * ppr;
+        const bool lane_ok = rl < RI;
+        const int n_it = (th + RI - 1) / RI;
+        const int x = c_lo + 2 * pl;                   // even: the pair (x, x + 1) starts at byte 0 or 2 of its dword
+        const bool odd2 = (x & 2) != 0;
+        const uint32_t selV = odd2 ? 0x0c030c02u : 0x0c010c00u;    // (x, x+1) and (x, x+1) of rows +-3
+        const uint32_t selX = odd2 ? 0x0c010c00u : 0x0c030c02u;    // (x+-2, x+-2+1)
+        const uint32_t selM = odd2 ? 0x0c040c03u : 0x0c020c01u;    // (x-3, x-2) out of dwords {D(x)-1, D(x)}
+        const uint32_t selP = odd2 ? 0x0c020c01u : 0x0c040c03u;    // (x+3, x+4) out of dwords {D(x+2), D(x+2)+1}
+        // addresses of row (y - 3): a0 = the dword of x minus one dword (the centre row reads {D-1, D}); a1 = the dword of
+        // x - 2, which is also the dword of x + 2 minus one dword (x = 4k: D(x) - 1; x = 4k + 2: D(x))
+        uint32_t a0 = tile_a + rl * PB + ((x >> 2) << 2) - 4;
+        uint32_t a1 = a0 + (odd2 ? 4u : 0u);
+        const uint32_t ec = (uint32_t)(3 * PB + 4 + (x & 3)) - tile_a;   // byte index of the pair's first pixel = a0 + ec
+        int rows_left = lane_ok ? th - rl : 0;         // lane active while rows_left > 0
+        for (int it = 0; it < n_it; it++, a0 += RI * PB, a1 += RI * PB, rows_left -= RI) {
+          // inactive lanes read in-range garbage: rows < rows_max + RI
+          const unsigned long long actm = __builtin_amdgcn_sicmp(rows_left, 0, 38 /* ICMP_SGT */);
+          const bool act = rows_left > 0;
+          unsigned long long p08, pc, pp, p62, p1014;
+          // all ten dwords requested at once; the first tier needs the first three pairs only (LDS returns in order)
+          asm volatile(
+              "ds_read2_b32 %0, %5 offset0:1 offset1:%7\n\t"
+              "ds_read2_b32 %1, %5 offset0:%8 offset1:%9\n\t"
+              "ds_read2_b32 %2, %6 offset0:%9 offset1:%10\n\t"
+              "ds_read2_b32 %3, %6 offset0:%11 offset1:%12\n\t"
+              "ds_read2_b32 %4, %6 offset0:%13 offset1:%14\n\t"
+              "s_waitcnt lgkmcnt(2)"
+              : "=&v"(p08), "=&v"(pc), "=&v"(pp), "=&v"(p62), "=&v"(p1014)
+              : "v"(a0), "v"(a1), "n"(6 * PB / 4 + 1), "n"(3 * PB / 4), "n"(3 * PB / 4 + 1), "n"(3 * PB / 4 + 2),
+                "n"(PB / 4 + 1), "n"(5 * PB / 4 + 1), "n"(PB / 4), "n"(5 * PB / 4)
+              : "memory");
+          const uint32_t D0 = (uint32_t)(pc >> 32), Dm = (uint32_t)pc;
+          const uint32_t V = __builtin_amdgcn_perm(0u, D0, selV);
+          const uint32_t Q8 = __builtin_amdgcn_perm(0u, (uint32_t)p08, selV), Q0 = __builtin_amdgcn_perm(0u, (uint32_t)(p08 >> 32), selV);
+          const uint32_t Q12 = __builtin_amdgcn_perm(D0, Dm, selM);
+          const uint32_t Q4 = __builtin_amdgcn_perm((uint32_t)(pp >> 32), (uint32_t)pp, selP);
+          const uint32_t AD = V + C, AB = C - V;
+          // one of every antipodal pair is darker than v - t  <=>  max over the pairs of the pair minimum is; same for brighter.
+          // First tier: the pairs (0, 8) and (4, 12) alone.  No lane of the wave passes it in 43 % of the iterations at
+          // t = 20 on the synthetic KITTI frames (two thirds on the DBoW2 demo images): those skip the other half.
+          uint32_t lo = pkmax(pkmin(Q0, Q8), pkmin(Q4, Q12));
+          uint32_t hi = pkmin(pkmax(Q0, Q8), pkmax(Q4, Q12));
+          const uint32_t t1 = ((AD - lo) | (hi + AB)) & 0x80008000u;
+          const bool any1 = (__builtin_amdgcn_uicmp(t1, 0u, 33 /* ICMP_NE */) & actm) != 0ull;   // v_cmp + s_and: no lane mask round trip
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p62), "+v"(p1014) : : "memory");
+          if (!any1) continue;
+          const uint32_t Q6 = __builtin_amdgcn_perm(0u, (uint32_t)p62, selX), Q2 = __builtin_amdgcn_perm(0u, (uint32_t)(p62 >> 32), selX);
+          const uint32_t Q10 = __builtin_amdgcn_perm(0u, (uint32_t)p1014, selX), Q14 = __builtin_amdgcn_perm(0u, (uint32_t)(p1014 >> 32), selX);
+          lo = pkmax(lo, pkmax(pkmin(Q2, Q10), pkmin(Q6, Q14)));
+          hi = pkmin(hi, pkmin(pkmax(Q2, Q10), pkmax(Q6, Q14)));
+          const uint32_t dark = AD - lo, brt = hi + AB;
+          const uint32_t G = act ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
+          const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
+          const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
+          const int n0 = __popcll(m0);
+          const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
+          const int i1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)(wcnt + n0)));
+          const uint32_t e = a0 + ec;
+          if (has0) list[i0] = (uint16_t)((G & 0xC000u) | e);
+          if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (e + 1));
+          wcnt += n0 + __popcll(m1);
+          if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
+            FC_T(2);
+            flushed = true;
+            score_list(wcnt, true, th_cur);
+            FC_T(3);
+            wcnt = 0;
+          }
+        }
+        FC_T(2);
+        score_list(wcnt, flushed, th_cur);
+        FC_T(3);
+      }
+
+      // ---- B: strict 3x3 NMS inside the cell.
+      if (!flushed) {
+        // lane = survivor: the list still holds every scored pixel of the cell.  Nine reads in flight together; the kept
+        // pixels are collected in the (so far empty) bitmap so that the emission below can walk them in row-major order
+        for (int i = lane; i < wcnt; i += WAVE) {
+          const uint32_t en = list[i];
+          const int e = (int)(en & 0x3fffu);
+          const int y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
+          const int x = e - y * PB;
+          if (x >= c_hi) continue;
+          const int ty = y - 3, tx = x - c_lo;
+          const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
+          const int v = s[0];
+          const int n0 = s[-SCP - 1], n1 = s[-SCP], n2 = s[-SCP + 1], n3 = s[-1], n4 = s[1], n5 = s[SCP - 1], n6 = s[SCP], n7 = s[SCP + 1];
+          const bool kp = (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);   // v = 0: not scored
+          if (kp) {
+            const int p = ty * tw + tx;
+            atomicOr(&scb[p >> 5], 1u << (p & 31));
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) keep[h] = (lane + WAVE * h) < nbw ? scb[lane + WAVE * h] : 0u;
+      } else {
+        // the list was recycled (more than 256 quick-test survivors in one cell): lane l walks the bits of words l and l + 64
+        // of the bitmap of scored pixels
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int w = lane + WAVE * h;
+          uint32_t m = w < nbw ? scb[w] : 0u;
+          keep[h] = 0;
+          while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int p = w * 32 + b;
+            const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
+            const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
+            // all nine reads in flight together: with `&&` every comparison waited for its own LDS round trip
+            const int v = s[0];
+            const int n0 = s[-SCP - 1], n1 = s[-SCP], n2 = s[-SCP + 1], n3 = s[-1], n4 = s[1], n5 = s[SCP - 1], n6 = s[SCP], n7 = s[SCP + 1];
+            const bool kp = (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);
+            if (kp) keep[h] |= 1u << b;
+          }
         }
       }
-      FC_T(2);
-      score_list(wcnt);
-      FC_T(3);
+      FC_T(4);   // NMS
+      total = __popcll(__ballot(keep[0] != 0u || keep[1] != 0u));   // > 0 <=> the cell keeps a pixel
+      if (total != 0 || pass == 1) break;
+      // nothing at ini_th: start over at min_th (score plane and bitmap may hold pass 0's plateau pixels)
+      {
+        const int nsc = ((th + 2) * SCP + 15) >> 4;
+        for (int i = lane; i < nsc; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
+      }
     }
 
     // FC_PREFETCH: the next cell's pixels requested HERE, after the score network (where the register allocation peaks) and
-    // before NMS and emission.  Measured (tools/fc_phase_profile.py): the wait for the pixels drops from 4.2 k to 2.7 k cycles
-    // per cell and the kernel takes the same time -- the SIMDs' vector ALUs are saturated (SQ_ACTIVE_INST_VALU), waves that do
-    // not wait here queue for issue slots elsewhere.  Off by default.
+    // before the emission.  Measured in round 2 (tools/fc_phase_profile.py): the wait for the pixels drops from 4.2 k to 2.7 k
+    // cycles per cell and the kernel takes the same time.  Off by default.
     CellDesc cdn = cd;
     if (FC_PREFETCH && k + 1 < g.n_cells) {
       cdn = cells[g.first_cell + k + 1];
       load_cell(cdn);
     }
 
-    // ---- B + C: NMS, two-threshold rule, row-major emission.  Lane l owns bitmap words l and l + 64.
+    // ---- C: row-major emission from registers (one wave scan per bitmap half gives the output offsets)
     {
-      uint32_t keep[2], hi[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int w = lane + WAVE * h;
-        uint32_t m = w < nbw ? scb[w] : 0u;
-        keep[h] = 0; hi[h] = 0;
-        while (m) {
-          const int b = __ffs((int)m) - 1;
-          m &= m - 1;
-          const int p = w * 32 + b;
-          const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
-          const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
-          // all nine reads in flight together: with `&&` every comparison waited for its own LDS round trip (this loop was a
-          // quarter of the kernel's time, tools/fc_phase_profile.py)
-          const int v = s[0];
-          const int n0 = s[-SCP - 1], n1 = s[-SCP], n2 = s[-SCP + 1], n3 = s[-1], n4 = s[1], n5 = s[SCP - 1], n6 = s[SCP], n7 = s[SCP + 1];
-          const bool kp = (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);
-          if (kp) {
-            keep[h] |= 1u << b;
-            if (v >= ini_th) hi[h] |= 1u << b;
-          }
-        }
-      }
-      FC_T(4);   // NMS
-      const int pk0 = (__popc(hi[0]) << 16) | __popc(keep[0]), pk1 = (__popc(hi[1]) << 16) | __popc(keep[1]);
+      const int pk0 = __popc(keep[0]), pk1 = __popc(keep[1]);
       const int in0 = wave_incl_scan(pk0), in1 = wave_incl_scan(pk1);
       const int tot0 = __builtin_amdgcn_readlane(in0, WAVE - 1), tot1 = __builtin_amdgcn_readlane(in1, WAVE - 1);
-      const int total = tot0 + tot1;
-      const bool use_hi = (total >> 16) != 0;
-      const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
+      const int n_out = tot0 + tot1;
       uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int ex = (h ? tot0 + in1 - pk1 : in0 - pk0);
-        int off = use_hi ? (ex >> 16) : (ex & 0xffff);
-        uint32_t mask = use_hi ? hi[h] : keep[h];
+        int off = (h ? tot0 + in1 - pk1 : in0 - pk0);
+        uint32_t mask = keep[h];
         const int w = lane + WAVE * h;
         while (mask) {
           const int b = __ffs((int)mask) - 1;

@@ -6,6 +6,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from refactored_orb_slam2_amd import _lib
+if os.environ.get("ORBFE_AB_LIB"):   # an experiment build of tools/ab_build.sh
+    _lib.LIB_PATH = os.path.join(_lib.CSRC, "_ab", "liborbfe_%s.so" % os.environ["ORBFE_AB_LIB"])
 from refactored_orb_slam2_amd import ORBextractor, synth
 
 F = int(os.environ.get("F", "256")); W, H = 1241, 376
