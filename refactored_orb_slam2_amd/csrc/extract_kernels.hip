@@ -742,37 +742,40 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
   const uint8_t* plane = pyr.base[level] + (size_t)img * pyr.img_stride[level];
   const uint32_t tile_a = (uint32_t)(uintptr_t)tile;
 
-  uint4 pv[NLD];
-  uint32_t pe[NLD];
-  auto load_cell = [&](const CellDesc& cd) {
-    const int ndq = ((cd.x0 & 15) + (((cd.x0 & 15) + 3) & 1) + cd.cols + 15) >> 4;   // chunks of the SHIFTED row
-    const int items = cd.rows * ndq;
-    const float inv = 1.0f / (float)ndq;
-    const uint8_t* src = plane + (size_t)cd.y0 * pitch + (cd.x0 & ~15);
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = lane + WAVE * k;
-      if (i < items) {
-        const int r = (int)((i + 0.5f) * inv), c = i - r * ndq;
-        const uint8_t* p = src + (size_t)r * pitch + 16 * c;
-        pv[k] = *reinterpret_cast<const uint4*>(p);
-        pe[k] = *reinterpret_cast<const uint32_t*>(p - 4);   // the dword in front (x0 >= 16: never before the row)
-      }
-    }
-  };
-
-#ifndef FC_PREFETCH
-#define FC_PREFETCH 0
-#endif
 #if FC_TIMING
   uint32_t tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tacc4 = 0, tacc5 = 0, tprev = (uint32_t)__builtin_readcyclecounter();
 #endif
-  CellDesc cd = cells[g.first_cell];
-  if (FC_PREFETCH) load_cell(cd);
   for (int k = 0; k < g.n_cells; k++) {
-    if (!FC_PREFETCH) {
-      cd = cells[g.first_cell + k];
-      load_cell(cd);
+    const CellDesc cd = cells[g.first_cell + k];
+    // ---- the cell's pixels: every lane loads in every round (row and chunk clamped into the cell: a duplicate load and,
+    //      below, a duplicate LDS store of the same bytes cost nothing, a divergent branch around them does)
+    uint4 pv[NLD];
+    uint32_t pe[NLD];
+    {
+      const int ndq = ((cd.x0 & 15) + (((cd.x0 & 15) + 3) & 1) + cd.cols + 15) >> 4;   // chunks of the SHIFTED row
+      const uint8_t* src = plane + (size_t)cd.y0 * pitch + (cd.x0 & ~15);
+      if constexpr (PB == 64) {
+        // four 16-byte chunks per staged row: lane -> (row, chunk) by shift and mask, sixteen rows per round
+        const int c = min(lane & 3, ndq - 1);
+#pragma unroll
+        for (int kk = 0; kk < NLD; kk++) {
+          const int r = min((lane >> 2) + 16 * kk, cd.rows - 1);
+          const uint8_t* p = src + (size_t)r * pitch + 16 * c;
+          pv[kk] = *reinterpret_cast<const uint4*>(p);
+          pe[kk] = *reinterpret_cast<const uint32_t*>(p - 4);   // the dword in front (x0 >= 16: never before the row)
+        }
+      } else {
+        const int items = cd.rows * ndq;
+        const float inv = 1.0f / (float)ndq;
+#pragma unroll
+        for (int kk = 0; kk < NLD; kk++) {
+          const int i = min(lane + WAVE * kk, items - 1);
+          const int r = (int)((i + 0.5f) * inv), c = i - r * ndq;
+          const uint8_t* p = src + (size_t)r * pitch + 16 * c;
+          pv[kk] = *reinterpret_cast<const uint4*>(p);
+          pe[kk] = *reinterpret_cast<const uint32_t*>(p - 4);
+        }
+      }
     }
 #if FC_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -784,25 +787,24 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
     const int th = rows - 6, tw = cols - 6;
     const int c_lo = xs + 3, c_hi = xs + cols - 3;
     const int SCP = tw + 2;
-    const float inv_tw = 1.0f / (float)(tw > 0 ? tw : 1);
+    const int bsh = tw > 32 ? 6 : 5;   // bitmaps: one word (two for wide cells) per tested row, so a bit index splits by shift and mask
     // ---- stage (shifted by `sh` columns), clear the score plane and the bitmaps
     {
       const int items = rows * ndq;
       const float inv = 1.0f / (float)ndq;
 #pragma unroll
       for (int kk = 0; kk < NLD; kk++) {
-        const int i = lane + WAVE * kk;
-        if (i < items) {
-          const int r = (int)((i + 0.5f) * inv), c = i - r * ndq;
-          uint4 d = pv[kk];
-          if (sh) {   // pixel j of the chunk moves to column j + 1: the first byte comes from the dword in front
-            d.w = __builtin_amdgcn_alignbyte(d.w, d.z, 3);
-            d.z = __builtin_amdgcn_alignbyte(d.z, d.y, 3);
-            d.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
-            d.x = __builtin_amdgcn_alignbyte(d.x, pe[kk], 3);
-          }
-          *reinterpret_cast<uint4*>(tile + r * PB + 16 * c) = d;
+        int r, c;
+        if constexpr (PB == 64) { r = min((lane >> 2) + 16 * kk, rows - 1); c = min(lane & 3, ndq - 1); }
+        else { const int i = min(lane + WAVE * kk, items - 1); r = (int)((i + 0.5f) * inv); c = i - r * ndq; }
+        uint4 d = pv[kk];
+        if (sh) {   // pixel j of the chunk moves to column j + 1: the first byte comes from the dword in front
+          d.w = __builtin_amdgcn_alignbyte(d.w, d.z, 3);
+          d.z = __builtin_amdgcn_alignbyte(d.z, d.y, 3);
+          d.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
+          d.x = __builtin_amdgcn_alignbyte(d.x, pe[kk], 3);
         }
+        *reinterpret_cast<uint4*>(tile + r * PB + 16 * c) = d;
       }
       const int nsc = ((th + 2) * SCP + 15) >> 4;
       for (int i = lane; i < nsc; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
           const int ty = y - 3, tx = x - c_lo;
           sc[(ty + 1) * SCP + tx + 1] = (uint8_t)(s - 1);
           if (mark) {
-            const int p = ty * tw + tx;
+            const int p = (ty << bsh) + tx;
             atomicOr(&scb[p >> 5], 1u << (p & 31));
           }
         }
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
           const int n0 = s[-SCP - 1], n1 = s[-SCP], n2 = s[-SCP + 1], n3 = s[-1], n4 = s[1], n5 = s[SCP - 1], n6 = s[SCP], n7 = s[SCP + 1];
           const bool kp = (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);   // v = 0: not scored
           if (kp) {
-            const int p = ty * tw + tx;
+            const int p = (ty << bsh) + tx;
             atomicOr(&scb[p >> 5], 1u << (p & 31));
           }
         }
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
             const int p = w * 32 + b;
-            const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
+            const int ty = p >> bsh, tx = p & ((1 << bsh) - 1);
             const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
             // all nine reads in flight together: with `&&` every comparison waited for its own LDS round trip
             const int v = s[0];
@@ -989,32 +991,24 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       }
     }
 
-    // FC_PREFETCH: the next cell's pixels requested HERE, after the score network (where the register allocation peaks) and
-    // before the emission.  Measured in round 2 (tools/fc_phase_profile.py): the wait for the pixels drops from 4.2 k to 2.7 k
-    // cycles per cell and the kernel takes the same time.  Off by default.
-    CellDesc cdn = cd;
-    if (FC_PREFETCH && k + 1 < g.n_cells) {
-      cdn = cells[g.first_cell + k + 1];
-      load_cell(cdn);
-    }
-
     // ---- C: row-major emission from registers (one wave scan per bitmap half gives the output offsets)
     {
-      const int pk0 = __popc(keep[0]), pk1 = __popc(keep[1]);
-      const int in0 = wave_incl_scan(pk0), in1 = wave_incl_scan(pk1);
-      const int tot0 = __builtin_amdgcn_readlane(in0, WAVE - 1), tot1 = __builtin_amdgcn_readlane(in1, WAVE - 1);
-      const int n_out = tot0 + tot1;
+      const int pk = __popc(keep[0]) | (__popc(keep[1]) << 16);   // both halves in one packed wave scan
+      const int in = wave_incl_scan(pk);
+      const int tot = __builtin_amdgcn_readlane(in, WAVE - 1);
+      const int tot0 = tot & 0xffff, n_out = tot0 + (tot >> 16);
+      const int ex = in - pk;
       uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        int off = (h ? tot0 + in1 - pk1 : in0 - pk0);
+        int off = h ? tot0 + (ex >> 16) : (ex & 0xffff);
         uint32_t mask = keep[h];
         const int w = lane + WAVE * h;
         while (mask) {
           const int b = __ffs((int)mask) - 1;
           mask &= mask - 1;
           const int p = w * 32 + b;
-          const int ty = (int)((p + 0.5f) * inv_tw), tx = p - ty * tw;
+          const int ty = p >> bsh, tx = p & ((1 << bsh) - 1);
           const uint32_t sv = sc[(ty + 1) * SCP + tx + 1];
           const uint32_t rx = (uint32_t)(tx + 3 + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(ty + 3 + cd.y0 - ORBFE_EDGE);
           if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
@@ -1024,7 +1018,6 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       if (lane == 0) cell_cnt[(size_t)img * total_cells + g.first_cell + k] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
       FC_T(5);   // scans + emission
     }
-    cd = cdn;
   }
 #if FC_TIMING
   if (lane == 0) {
@@ -2044,7 +2037,7 @@ void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const F
   const int sc_bytes = (sc_max + 15) & ~15;
   const int nbw = bits_max <= 64 * 32 ? 64 : 128;   // bitmap words (lane l owns words l and l + 64)
   const size_t lds = (size_t)4 * fc_wave_lds(cell_rows, pb, sc_bytes, nbw);
-  const bool small = cell_rows * ((cell_span + 15) / 16) <= 3 * WAVE;   // a cell loads in three rounds of 64 lanes
+  const bool small = cell_rows <= 48;   // a cell loads in three rounds of sixteen rows
   dim3 grid4((n_groups + 3) / 4, n_images);
 #define FC_LAUNCH(PBV, NLDV)                                                                                                   \
   hipLaunchKernelGGL((fast_cells_kernel<PBV, NLDV>), grid4, dim3(256), lds, s, pyr, cells, groups, n_groups, total_cells,       \

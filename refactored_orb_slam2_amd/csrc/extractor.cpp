@@ -263,7 +263,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
           e->fc_rows = std::max(e->fc_rows, (int)c.rows);
           e->fc_span = std::max(e->fc_span, (c.x0 & 15) + 1 + (int)c.cols);
           e->fc_sc = std::max(e->fc_sc, (th + 2) * (tw + 2));
-          e->fc_bits = std::max(e->fc_bits, tw * th);
+          e->fc_bits = std::max(e->fc_bits, th * (tw > 32 ? 64 : 32));   // bitmap: one or two words per tested row
           c.slot_off = (uint32_t)slot_off;
           slot_off += cap;
           level_slots += cap;

@@ -3,7 +3,9 @@
 import ctypes as C, numpy as np, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
-from refactored_orb_slam2_amd import ORBextractor, synth, _lib
+from refactored_orb_slam2_amd import _lib
+if os.environ.get("ORBFE_AB_LIB"): _lib.LIB_PATH = os.path.join(_lib.CSRC, "_ab", "liborbfe_%s.so" % os.environ["ORBFE_AB_LIB"])
+from refactored_orb_slam2_amd import ORBextractor, synth
 L=_lib.lib()
 W,H,NF,B=1241,376,2000,256
 imgs=[synth.sequence(W,H,1,seq=100+i)[0] for i in range(8)]
