@@ -202,6 +202,54 @@ def cpu_baseline(name: str, sample_frames: int):
     return out
 
 
+def _write_png_gray(path, img):
+    """8-bit greyscale PNG (filter 0, zlib level 1): input for the per-frame C++ driver."""
+    import struct, zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    h, w = img.shape
+    rows = np.concatenate([np.zeros((h, 1), np.uint8), img], axis=1).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rows, 1)) +
+                chunk(b"IEND", b""))
+
+
+def per_frame_latency(cfg, n_frames: int):
+    """Latency of ONE stereo pair through the calling pattern the reference uses (Frame.cc:91-99, Tracking.cc:857-884): the
+    C++ drop-in classes -- ORBextractor::operator() for the two eyes on two std::threads, Frame::ComputeStereoMatches on the
+    pyramids in HBM, ORBmatcher::SearchByProjection(cur, last) -- driven by examples/stereo_kitti.cc over a synthetic sequence
+    written as PNGs (decoding is outside the driver's per-frame clock, as imread is outside the reference's).  Separate process,
+    outside the timed region of the batched metric."""
+    import re, tempfile
+    from refactored_orb_slam2_amd import synth
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "stereo_kitti")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "_build/stereo_kitti"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": "examples/stereo_kitti.cc not built: " + r.stderr[-300:]}
+    with tempfile.TemporaryDirectory() as tmp:
+        seq = os.path.join(tmp, "00")
+        os.makedirs(os.path.join(seq, "image_0")); os.makedirs(os.path.join(seq, "image_1"))
+        pairs = synth.sequence(cfg["w"], cfg["h"], n_frames, seq=7, stereo=True)
+        with open(os.path.join(seq, "times.txt"), "w") as f:
+            for i, (L, R) in enumerate(pairs):
+                _write_png_gray(os.path.join(seq, "image_0", f"{i:06d}.png"), L)
+                _write_png_gray(os.path.join(seq, "image_1", f"{i:06d}.png"), R)
+                f.write(f"{i * 0.1:e}\n")
+        r = subprocess.run([exe, seq, "--features", str(cfg["nfeat"]), "--bf", str(cfg["bf"]), "--fx", str(cfg["fx"]), "--fy", str(cfg["fy"]),
+                            "--cx", str(cfg["cx"]), "--cy", str(cfg["cy"]), "--th", str(cfg["th"])], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": f"stereo_kitti exited with {r.returncode}: " + (r.stderr or r.stdout)[-300:]}
+    med = re.search(r"median tracking time: ([0-9.eE+-]+)", r.stdout)
+    mean = re.search(r"mean tracking time: ([0-9.eE+-]+)", r.stdout)
+    stats = re.search(r"keypoints/left image: ([0-9.]+), stereo matches/frame: ([0-9.]+), tracked/frame: ([0-9.]+)", r.stdout)
+    return {"median_ms": round(float(med.group(1)) * 1e3, 4), "mean_ms": round(float(mean.group(1)) * 1e3, 4), "frames": n_frames,
+            "keypoints_per_left_image": float(stats.group(1)), "stereo_matches_per_frame": float(stats.group(2)),
+            "tracked_per_frame": float(stats.group(3)),
+            "path": "examples/stereo_kitti.cc: C++ ORBextractor x2 on two threads + orbfe_host::ComputeStereoMatches + "
+                    "ORBmatcher::SearchByProjection(cur,last), host images in, host keypoints / matches out, one pair at a time"}
+
+
 def spawn_ranks(n: int) -> int:
     """Start n ranks of this script (one process per GPU) before anything touched the GPU in this process."""
     import torch
@@ -237,6 +285,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="kitti_stereo")
     ap.add_argument("--cpu-sample", type=int, default=160, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--e2e-steps", type=int, default=12, help="steps of the PCIe-inclusive measurement (0 = skip)")
+    ap.add_argument("--per-frame", type=int, default=24, help="stereo pairs pushed one at a time through the C++ drop-in classes for per_frame_ms (0 = skip)")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
                     help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
     args = ap.parse_args()
@@ -499,6 +548,10 @@ def main():
         if e2e is not None:
             out["e2e_frames_per_s"] = round(e2e, 1)
             out["e2e_note"] = "pinned host images -> H2D -> step -> D2H of keypoints, descriptors, counts, matches (and mvuRight / mvDepth), double-buffered"
+        if world == 1 and args.per_frame > 0 and STEREO:
+            pf = per_frame_latency(cfg, args.per_frame)
+            out["per_frame_ms"] = pf.get("median_ms")
+            out["per_frame"] = pf
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -444,6 +444,17 @@ int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_ext
                               int cap, float mbf, float mb, float* d_u_right, float* d_depth, int32_t* d_n_matched,
                               void* stream);
 
+/* Frame::ComputeStereoMatches (L/src/Frame.cc:477-646) for the ONE stereo pair the two extractors processed last -- the
+ * per-frame calling pattern of Frame::Frame (L/src/Frame.cc:91-99: ExtractORB on two threads, then ComputeStereoMatches).
+ * HOST pointers, synchronous.  kps / desc are what the two orbfe_extract calls returned (mvKeys, mDescriptors, mvKeysRight,
+ * mDescriptorsRight); the row search, the descriptor match, the 11x11 SAD refinement on the pyramids still resident in HBM
+ * (no mvImagePyramid download), the parabola and the median cut run on the device.  u_right / depth: n_l floats (mvuRight,
+ * mvDepth; -1 = no match); *n_matched (optional) = matches kept.  mb = Frame::mb (minZ, :505), must be > 0.
+ * Both extractors must have completed an extraction of the same image size on the calling thread's device. */
+int orbfe_stereo_match(orbfe_extractor* left, orbfe_extractor* right, const orbfe_keypoint* kps_l, const uint8_t* desc_l,
+                       int n_l, const orbfe_keypoint* kps_r, const uint8_t* desc_r, int n_r, float mbf, float mb,
+                       float* u_right, float* depth, int* n_matched);
+
 /* --------------------------------------------------------------------------------------- ORBVocabulary */
 /* Frame::ComputeBoW (L/src/Frame.cc:412-417): ORBVocabulary::transform(descriptors, BowVector&, FeatureVector&, 4)
  * = DBoW2::TemplatedVocabulary::transform (Source/ThirdParty/DBoW2/DBoW2-local/include/DBoW2/

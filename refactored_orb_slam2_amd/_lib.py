@@ -94,7 +94,7 @@ EXPORTS = [
     "orbfe_debug_level_keypoints", "orbfe_profile_enable", "orbfe_stage_times",
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
-    "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device",
+    "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device", "orbfe_stereo_match",
     "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_kf_search", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
     "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
@@ -188,6 +188,7 @@ def lib():
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, cf, ci, vp, pi]
     L.orbfe_search_for_initialization.argtypes = [C.POINTER(FrameView), C.POINTER(FrameView), vp, ci, cf, ci, vp, pi]
     L.orbfe_stereo_match_device.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
+    L.orbfe_stereo_match.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp, pi]
     for name in EXPORTS:
         if name != "orbfe_last_error":
             getattr(L, name).restype = ci

@@ -9,6 +9,7 @@
 //
 // Members used (same names as the reference):
 //   Frame:    N, mvKeysUn, mDescriptors, mvuRight, mvpMapPoints, mvScaleFactors, mnMinX/mnMaxX/mnMinY/mnMaxY
+//             ComputeStereoMatches additionally -- mvKeys, mvKeysRight, mDescriptorsRight, mbf, mb, mvDepth
 //   MapPoint: mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel, mTrackViewCos,
 //             isBad(), Observations(), GetDescriptor()
 //   SearchLocalPoints additionally -- Frame: mnId, mTcw, GetCameraCenter(), fx, fy, cx, cy, mbf, mfLogScaleFactor, mnScaleLevels;
@@ -323,6 +324,37 @@ int ComputeBoW(orbfe_vocabulary* voc, const uint8_t* descriptors, int N, BowVecT
     v.assign(fvIdx.begin() + fvNodes[i].start, fvIdx.begin() + fvNodes[i].start + fvNodes[i].count);
   }
   return ORBFE_OK;
+}
+
+// Frame::ComputeStereoMatches (L/src/Frame.cc:477-646) -- whole body:
+//     void Frame::ComputeStereoMatches() { orbfe_host::ComputeStereoMatches(*this, mpORBextractorLeft, mpORBextractorRight); }
+// Called where the reference calls it (Frame.cc:99), i.e. after the two ExtractORB threads (:91-94) have joined: the pyramids
+// both extractors built for this pair are still in HBM, so mvImagePyramid is not needed on the host
+// (ORBextractor::SetPyramidDownload(false)).  Members used: N, mvKeys, mvKeysRight, mDescriptors, mDescriptorsRight, mbf, mb,
+// mvuRight, mvDepth (and the static fx when mb has not been set yet).
+// mb: the reference reads Frame::mb as minZ (:505) BEFORE the constructor assigns it (:124) -- an indeterminate value in the
+// first frame, the previous frame's mbf / fx afterwards in practice.  A non-positive or non-finite mb is replaced by mbf / fx.
+template <class FrameT, class ExtractorT>
+int ComputeStereoMatches(FrameT& F, ExtractorT* pLeft, ExtractorT* pRight) {
+  const int N = F.N;
+  F.mvuRight.assign((size_t)N, -1.0f);   // :478-479
+  F.mvDepth.assign((size_t)N, -1.0f);
+  const int Nr = (int)F.mvKeysRight.size();
+  if (N <= 0 || Nr <= 0) return 0;
+  static_assert(sizeof(F.mvKeys[0]) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
+  float mb = F.mb;
+  if (!(mb > 0.0f) || !(mb < 3.0e38f)) mb = F.mbf / F.fx;
+  int nMatched = 0;
+  const int rc = orbfe_stereo_match(pLeft->Handle(), pRight->Handle(), reinterpret_cast<const orbfe_keypoint*>(F.mvKeys.data()),
+                                    F.mDescriptors.ptr(0), N, reinterpret_cast<const orbfe_keypoint*>(F.mvKeysRight.data()),
+                                    F.mDescriptorsRight.ptr(0), Nr, F.mbf, mb, F.mvuRight.data(), F.mvDepth.data(), &nMatched);
+  if (rc != ORBFE_OK) {
+    fprintf(stderr, "Frame::ComputeStereoMatches: liborbfe error %d: %s\n", rc, orbfe_last_error());
+    F.mvuRight.assign((size_t)N, -1.0f);
+    F.mvDepth.assign((size_t)N, -1.0f);
+    return 0;
+  }
+  return nMatched;
 }
 
 // SearchByProjection(Frame& cur, const Frame& last, th, bMono)   L/src/ORBmatcher.cc:1247-1383

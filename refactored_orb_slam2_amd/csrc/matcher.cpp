@@ -55,6 +55,8 @@ struct orbfe_matcher {
   MBuf h_keys, h_desc, h_ur, h_q, h_n, h_nq, h_blocked, h_assigned, h_nm;
   // SearchLocalPoints: generated queries (device) and staging of the host entry point
   MBuf lp_q, lp_pts, lp_fr, lp_track, lp_cnt;
+  // orbfe_stereo_match (one pair, host pointers): packed inputs / outputs
+  MBuf st_in, st_out;
   std::mutex mu;
 };
 
@@ -87,7 +89,7 @@ extern "C" int orbfe_matcher_destroy(orbfe_matcher* m) {
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   MBuf* bufs[] = {&m->cell_start, &m->cell_idx, &m->cell_rec, &m->cand, &m->n_cand, &m->push_idx, &m->push_bin, &m->sad, &m->bucket_start, &m->bucket_idx, &m->h_keys,
                   &m->h_desc, &m->h_ur, &m->h_q, &m->h_n, &m->h_nq, &m->h_blocked, &m->h_assigned, &m->h_nm,
-                  &m->lp_q, &m->lp_pts, &m->lp_fr, &m->lp_track, &m->lp_cnt};
+                  &m->lp_q, &m->lp_pts, &m->lp_fr, &m->lp_track, &m->lp_cnt, &m->st_in, &m->st_out};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -846,20 +848,11 @@ extern "C" int orbfe_search_for_initialization(const orbfe_frame_view* f1, const
 }
 
 // ------------------------------------------------------------------------------------------------ stereo
-extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
-                                         const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
-                                         const orbfe_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r,
-                                         int cap, float mbf, float mb, float* d_u_right, float* d_depth,
-                                         int32_t* d_n_matched, void* stream) {
-  if (!m || !left || !right || n_pairs < 1 || !d_kps_l || !d_desc_l || !d_n_l || !d_kps_r || !d_desc_r || !d_n_r ||
-      cap < 1 || cap >= 65536 || !d_u_right || !d_depth || !d_n_matched || !(mb > 0))
-    return ORBFE_ERR_INVALID;
-  if (((uintptr_t)d_desc_l & 15) || ((uintptr_t)d_desc_r & 15)) {
-    orbfe_set_error("descriptor matrices must be 16-byte aligned");
-    return ORBFE_ERR_INVALID;
-  }
-  std::lock_guard<std::mutex> lk(m->mu);
-  HIPCHK(hipSetDevice(m->device));
+// the three stereo kernels for n_pairs pairs; the caller holds m->mu and has selected the device
+static int stereo_enqueue(orbfe_matcher* m, orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
+                          const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                          const orbfe_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r, int cap, float mbf,
+                          float mb, float* d_u_right, float* d_depth, int32_t* d_n_matched, hipStream_t stream) {
   StereoParams p;
   memset(&p, 0, sizeof(p));
   int nl = 0, nr = 0, il = 0, ir = 0, devl = 0, devr = 0;
@@ -901,6 +894,68 @@ extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left
   p.depth = d_depth;
   p.sad = (int32_t*)m->sad.p;
   p.n_matched = d_n_matched;
-  orbfe_launch_stereo(p, n_pairs, stream ? (hipStream_t)stream : m->stream);
+  orbfe_launch_stereo(p, n_pairs, stream);
   return launch_ok();
+}
+
+extern "C" int orbfe_stereo_match_device(orbfe_matcher* m, orbfe_extractor* left, orbfe_extractor* right, int n_pairs,
+                                         const orbfe_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                                         const orbfe_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r,
+                                         int cap, float mbf, float mb, float* d_u_right, float* d_depth,
+                                         int32_t* d_n_matched, void* stream) {
+  if (!m || !left || !right || n_pairs < 1 || !d_kps_l || !d_desc_l || !d_n_l || !d_kps_r || !d_desc_r || !d_n_r ||
+      cap < 1 || cap >= 65536 || !d_u_right || !d_depth || !d_n_matched || !(mb > 0))
+    return ORBFE_ERR_INVALID;
+  if (((uintptr_t)d_desc_l & 15) || ((uintptr_t)d_desc_r & 15)) {
+    orbfe_set_error("descriptor matrices must be 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  return stereo_enqueue(m, left, right, n_pairs, d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mbf, mb, d_u_right,
+                        d_depth, d_n_matched, stream ? (hipStream_t)stream : m->stream);
+}
+
+// Frame::ComputeStereoMatches for the ONE pair the two extractors processed last (L/src/Frame.cc:91-99: the two ExtractORB
+// threads, then ComputeStereoMatches): host keypoints / descriptors in, mvuRight / mvDepth out, the SAD refinement reads the
+// pyramids that are still in HBM.  One packed upload, three kernels, one packed download on the calling thread's matcher.
+extern "C" int orbfe_stereo_match(orbfe_extractor* left, orbfe_extractor* right, const orbfe_keypoint* kps_l,
+                                  const uint8_t* desc_l, int n_l, const orbfe_keypoint* kps_r, const uint8_t* desc_r, int n_r,
+                                  float mbf, float mb, float* u_right, float* depth, int* n_matched) {
+  if (!left || !right || n_l < 0 || n_r < 0 || (n_l > 0 && (!kps_l || !desc_l || !u_right || !depth)) ||
+      (n_r > 0 && (!kps_r || !desc_r)) || n_l >= 65536 || n_r >= 65536 || !(mb > 0))
+    return ORBFE_ERR_INVALID;
+  if (n_matched) *n_matched = 0;
+  for (int i = 0; i < n_l; i++) u_right[i] = depth[i] = -1.0f;   // L/src/Frame.cc:478-479
+  if (n_l == 0 || n_r == 0) return ORBFE_OK;
+  orbfe_matcher* m;
+  int rc;
+  if ((rc = tls_matcher(&m))) return rc;
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const int cap = std::max(n_l, n_r);
+  // device staging: [n_l, n_r | keys_l | keys_r | desc_l | desc_r], every part 256-byte aligned; outputs [u_right | depth | n]
+  const size_t kb = ((sizeof(orbfe_keypoint) * (size_t)cap + 255) / 256) * 256, db = (((size_t)32 * cap + 255) / 256) * 256;
+  const size_t fb = ((sizeof(float) * (size_t)cap + 255) / 256) * 256;
+  if ((rc = mb_alloc(m->st_in, 256 + 2 * kb + 2 * db)) || (rc = mb_alloc(m->st_out, 2 * fb + 256))) return rc;
+  uint8_t* in = (uint8_t*)m->st_in.p;
+  uint8_t* out = (uint8_t*)m->st_out.p;
+  const int32_t hdr[2] = {n_l, n_r};
+  HIPCHK(hipMemcpyAsync(in, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(in + 256, kps_l, sizeof(orbfe_keypoint) * (size_t)n_l, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(in + 256 + kb, kps_r, sizeof(orbfe_keypoint) * (size_t)n_r, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(in + 256 + 2 * kb, desc_l, (size_t)32 * n_l, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(in + 256 + 2 * kb + db, desc_r, (size_t)32 * n_r, hipMemcpyHostToDevice, s));
+  rc = stereo_enqueue(m, left, right, 1, (const orbfe_keypoint*)(in + 256), in + 256 + 2 * kb, (const int32_t*)in,
+                      (const orbfe_keypoint*)(in + 256 + kb), in + 256 + 2 * kb + db, (const int32_t*)in + 1, cap, mbf, mb,
+                      (float*)out, (float*)(out + fb), (int32_t*)(out + 2 * fb), s);
+  if (rc) { (void)hipStreamSynchronize(s); return rc; }   // hdr lives on this stack frame
+  int32_t nm = 0;
+  HIPCHK(hipMemcpyAsync(u_right, out, sizeof(float) * (size_t)n_l, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(depth, out + fb, sizeof(float) * (size_t)n_l, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&nm, out + 2 * fb, sizeof(nm), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (n_matched) *n_matched = nm;
+  return ORBFE_OK;
 }

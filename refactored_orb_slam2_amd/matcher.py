@@ -389,3 +389,17 @@ class Matcher:
             self._h, ex_left._h, ex_right._h, P, _lib.ptr(kps_l), _lib.ptr(desc_l), _lib.ptr(n_l), _lib.ptr(kps_r),
             _lib.ptr(desc_r), _lib.ptr(n_r), cap, mbf, mb, _lib.ptr(u_right), _lib.ptr(depth), _lib.ptr(n_matched), s),
             "orbfe_stereo_match_device")
+
+
+def compute_stereo_matches(ex_left, ex_right, kps_l, desc_l, kps_r, desc_r, mbf, mb):
+    """Frame::ComputeStereoMatches (L/src/Frame.cc:477-646) for the one pair `ex_left` / `ex_right` extracted last: host numpy
+    keypoints / descriptors in, (n_matched, mvuRight, mvDepth) out.  The pyramids of the two extractors are read in HBM."""
+    L = _lib.lib()
+    kps_l = np.ascontiguousarray(kps_l); kps_r = np.ascontiguousarray(kps_r)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8); desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    ur = np.empty(len(kps_l), np.float32); depth = np.empty(len(kps_l), np.float32)
+    nm = C.c_int(0)
+    _lib.check(L.orbfe_stereo_match(ex_left._h, ex_right._h, _lib.ptr(kps_l), _lib.ptr(desc_l), len(kps_l), _lib.ptr(kps_r),
+                                    _lib.ptr(desc_r), len(kps_r), float(np.float32(mbf)), float(np.float32(mb)), _lib.ptr(ur),
+                                    _lib.ptr(depth), C.byref(nm)), "orbfe_stereo_match")
+    return nm.value, ur, depth

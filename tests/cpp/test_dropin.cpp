@@ -167,6 +167,64 @@ int main(int argc, char** argv) {
     oo_extractor_destroy(orcR);
     delete extR;
   }
+  // --- Frame::ComputeStereoMatches through the adapter (L/src/Frame.cc:91-99: two ExtractORB threads, then the stereo
+  //     association on the pyramids that are still in HBM -- no mvImagePyramid download) vs oo_compute_stereo_matches
+  {
+    struct MockStereoFrame {
+      int N = 0;
+      float fx = 0, mbf = 0, mb = 0;
+      std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+      cv::Mat mDescriptors, mDescriptorsRight;
+      std::vector<float> mvuRight, mvDepth;
+    } SF;
+    const int shift = 23;   // right(x, y) = left(x + shift, y): disparity 23 px everywhere
+    std::vector<uint8_t> shifted(raw.size());
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) shifted[(size_t)y * w + x] = raw[(size_t)y * w + (x + shift) % w];
+    cv::Mat imR(h, w, CV_8U, shifted.data());
+    ORB_SLAM2::ORBextractor* extR = new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7);
+    ext->SetPyramidDownload(false);
+    extR->SetPyramidDownload(false);
+    {
+      std::thread tl([&] { (*ext)(im, cv::Mat(), SF.mvKeys, SF.mDescriptors); });
+      std::thread tr([&] { (*extR)(imR, cv::Mat(), SF.mvKeysRight, SF.mDescriptorsRight); });
+      tl.join();
+      tr.join();
+    }
+    SF.N = (int)SF.mvKeys.size();
+    SF.fx = 718.856f; SF.mbf = 386.1448f; SF.mb = 0.f;   // mb not yet assigned, as in the reference's constructor: mbf / fx is used
+    const int nst = ORB_SLAM2::orbfe_host::ComputeStereoMatches(SF, ext, extR);
+    oo_extractor* orcR = oo_extractor_create(nf, 1.2f, 8, 20, 7);
+    std::vector<oo_keypoint> okR(nf + 64);
+    std::vector<uint8_t> odR((size_t)(nf + 64) * 32);
+    int onR = 0;
+    CHECK(oo_extract(orcR, shifted.data(), w, h, w, okR.data(), odR.data(), nf + 64, &onR) == 0);
+    CHECK(oo_extract(orc, raw.data(), w, h, w, okeys.data(), odesc.data(), (int)okeys.size(), &on) == 0);
+    CHECK(SF.N == on && (int)SF.mvKeysRight.size() == onR);
+    oo_pyramid_view pl, prv;
+    pl.n_levels = prv.n_levels = 8;
+    for (int l = 0; l < 8; l++) {
+      oo_level_size(orc, l, &pl.w[l], &pl.h[l]);
+      pl.data[l] = oo_level_pixels(orc, l, &pl.stride[l]);
+      oo_level_size(orcR, l, &prv.w[l], &prv.h[l]);
+      prv.data[l] = oo_level_pixels(orcR, l, &prv.stride[l]);
+    }
+    std::vector<float> our(on), odepth(on);
+    std::vector<float> isf = ext->GetInverseScaleFactors();
+    const int onst = oo_compute_stereo_matches(okeys.data(), odesc.data(), on, okR.data(), odR.data(), onR, &pl, &prv, sf.data(),
+                                               isf.data(), SF.mbf, SF.mbf / SF.fx, our.data(), odepth.data());
+    (void)onst;
+    int kept = 0;
+    for (int i = 0; i < on; i++) {
+      CHECK(SF.mvuRight[i] == our[i] && SF.mvDepth[i] == odepth[i]);
+      kept += our[i] >= 0;
+    }
+    CHECK(kept == nst && kept > on / 4);
+    printf("ComputeStereoMatches ok: %d of %d keypoints with depth\n", kept, on);
+    ext->SetPyramidDownload(true);
+    oo_extractor_destroy(orcR);
+    delete extR;
+  }
   // --- ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) through the adapter vs the oracle
   MockFrame F;
   F.N = on;

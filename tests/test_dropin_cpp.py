@@ -41,6 +41,7 @@ def test_dropin_parity_on_gpu(tmp_path, geom):
     r = subprocess.run([EXE, p, str(w), str(h), str(nf)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "dropin ok" in r.stdout and "SearchLocalPoints ok" in r.stdout and "SearchByBoW ok" in r.stdout and "SearchForTriangulation ok" in r.stdout and "ComputeBoW ok" in r.stdout
+    assert "ComputeStereoMatches ok" in r.stdout
 
 
 @pytest.mark.gpu
@@ -115,3 +116,65 @@ def test_c99_example_matches_the_oracle(tmp_path):
         s = ((s * 16777619) & 0xffffffff) ^ b
     assert f"640x480: {len(k)} keypoints, descriptor checksum {s:08x}" in r.stdout, r.stdout
     assert f"kp 0: ({k['x'][0]:.1f}, {k['y'][0]:.1f}) octave {k['octave'][0]}" in r.stdout
+
+
+# ---- the C++ sequence driver on the drop-in classes (examples/stereo_kitti.cc): Frame.cc:91-99 + Tracking.cc:857-884 per pair
+@pytest.mark.gpu
+def test_cpp_sequence_driver_on_kitti_layout(tmp_path):
+    """examples/stereo_kitti.cc -- ORBextractor::operator() on two threads, orbfe_host::ComputeStereoMatches on the pyramids in
+    HBM, ORBmatcher::SearchByProjection(cur, last) -- over a synthetic sequence in the KITTI directory layout: every frame's
+    keypoints, descriptors, mvuRight / mvDepth and tracked assignment == the oracle's (oo_compute_stereo_matches etc.)."""
+    from refactored_orb_slam2_amd import synth
+    from refactored_orb_slam2_amd._lib import KP_DTYPE, TRACK_POSE_DTYPE, UNPROJECT_CAM_DTYPE
+    from tests import oracle_lib as ol
+    from tests.test_matcher_gpu import _write_png_gray
+    _build()
+    seq = tmp_path / "00"
+    (seq / "image_0").mkdir(parents=True); (seq / "image_1").mkdir()
+    W, H, NF, N = 1241, 376, 2000, 4
+    pairs = synth.sequence(W, H, N, seq=21, stereo=True)
+    with open(seq / "times.txt", "w") as f:
+        for i, (L, R) in enumerate(pairs):
+            _write_png_gray(seq / "image_0" / f"{i:06d}.png", L)
+            _write_png_gray(seq / "image_1" / f"{i:06d}.png", R)
+            f.write(f"{i * 0.1:e}\n")
+    oL, oR = ol.OracleExtractor(NF), ol.OracleExtractor(NF)
+    sf, isf = oL.scale_factors, oL.inv_scale_factors
+    bf, fx, fy, cx, cy = np.float32(386.1448), np.float32(718.856), np.float32(718.856), np.float32(607.1928), np.float32(185.2157)
+    cam = np.zeros(1, UNPROJECT_CAM_DTYPE); pose = np.zeros(1, TRACK_POSE_DTYPE)
+    eye = np.eye(3, dtype=np.float32).reshape(9)
+    cam["Rwc"] = eye; cam["cx"] = cx; cam["cy"] = cy; cam["invfx"] = np.float32(1) / fx; cam["invfy"] = np.float32(1) / fy
+    pose["Rcw"] = eye; pose["fx"] = fx; pose["fy"] = fy; pose["cx"] = cx; pose["cy"] = cy; pose["mbf"] = bf
+    pose["max_x"] = W; pose["max_y"] = H; pose["th"] = 7.0; pose["scale_factors"][0, :8] = sf
+    exp, prev = [], None
+    for (L, R) in pairs:
+        kL, dL = oL(L); kR, dR = oR(R)
+        _, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, [oL.level_pixels(l) for l in range(8)], [oR.level_pixels(l) for l in range(8)],
+                                                 sf, isf, float(bf), float(bf / fx))
+        nm, assigned = 0, np.full(len(kL), -1, np.int32)
+        if prev is not None:
+            nm, assigned, _ = ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(ol.track_queries(pose, prev), True)
+        exp.append((kL, dL, ur, depth, nm, assigned))
+        prev = ol.unproject_stereo(cam, kL, dL, depth)
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "stereo_kitti")
+    dump = str(tmp_path / "dump.bin")
+    r = subprocess.run([exe, str(seq), "--dump", dump], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "median tracking time" in r.stdout and f"Images in the sequence: {N}" in r.stdout
+    raw = open(dump, "rb").read()
+    off = 0
+    for i, (kL, dL, ur, depth, nm, assigned) in enumerate(exp):
+        n, nmatches = np.frombuffer(raw, np.int32, 2, off); off += 8
+        assert n == len(kL), (i, n, len(kL))
+        k = np.frombuffer(raw, KP_DTYPE, n, off); off += 28 * n
+        d = np.frombuffer(raw, np.uint8, 32 * n, off).reshape(n, 32); off += 32 * n
+        u = np.frombuffer(raw, np.float32, n, off); off += 4 * n
+        z = np.frombuffer(raw, np.float32, n, off); off += 4 * n
+        a = np.frombuffer(raw, np.int32, n, off); off += 4 * n
+        np.testing.assert_array_equal(k, kL, err_msg=f"keypoints of frame {i}")
+        np.testing.assert_array_equal(d, dL)
+        np.testing.assert_array_equal(u, ur, err_msg=f"mvuRight of frame {i}"); np.testing.assert_array_equal(z, depth)
+        assert nmatches == nm, (i, nmatches, nm)
+        np.testing.assert_array_equal(a, assigned, err_msg=f"tracked assignment of frame {i}")
+    assert off == len(raw)
+    assert exp[2][4] > 500 and (exp[1][3] > 0).sum() > 800
