@@ -319,3 +319,293 @@ def orb_descriptor(blurred, x, y, angle_deg, pattern):
 
 def hamming(a, b):
     return int(np.unpackbits(np.bitwise_xor(np.asarray(a, np.uint8), np.asarray(b, np.uint8))).sum())
+
+
+# ============================================================================================ matchers (second reading)
+# An INDEPENDENT restatement of the order-dependent matcher loops, written from the reference sources alone
+# (L/src/ORBmatcher.cc:45-128, 161-273, 388-492, 1247-1383, 1506-1556 and L/src/Frame.cc:250-263, 341-410) as plain Python
+# loops over lists -- structurally unlike oracle/orb_oracle.c (per-cell Python lists instead of a CSR grid, dict FeatureVectors,
+# no query records inside the loops).  tests/test_oracle_cpu.py asserts that the C oracle agrees with it on real-image pairs and
+# on a ties-heavy synthetic case; a misread quirk would have to be made twice, in two languages, to go unnoticed.
+import math
+
+FRAME_GRID_ROWS, FRAME_GRID_COLS = 48, 64      # L/include/Frame.h:36-37
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30    # L/src/ORBmatcher.cc:36-38
+_f32 = np.float32
+_POPCOUNT = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+
+def c_round(x):
+    """C round(): halves away from zero."""
+    x = float(x)
+    return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+def descriptor_distance(a, b):
+    """ORBmatcher::DescriptorDistance (:1542-1556): bit count of the XOR of 8 x 32 bits."""
+    return int(_POPCOUNT[np.bitwise_xor(a, b)].sum())
+
+
+class RefFrame:
+    """The members of Frame the matcher reads, with AssignFeaturesToGrid (Frame.cc:250-263), PosInGrid (:399-410) and
+    GetFeaturesInArea (:341-397)."""
+
+    def __init__(self, keys, desc, min_x, max_x, min_y, max_y, u_right=None):
+        self.N = len(keys)
+        self.x = [_f32(v) for v in keys["x"]]; self.y = [_f32(v) for v in keys["y"]]
+        self.octave = [int(v) for v in keys["octave"]]; self.angle = [_f32(v) for v in keys["angle"]]
+        self.desc = np.asarray(desc, np.uint8)
+        self.u_right = None if u_right is None else [_f32(v) for v in u_right]
+        self.mnMinX, self.mnMaxX, self.mnMinY, self.mnMaxY = _f32(min_x), _f32(max_x), _f32(min_y), _f32(max_y)
+        self.mfGridElementWidthInv = _f32(FRAME_GRID_COLS) / (self.mnMaxX - self.mnMinX)     # Frame.cc:107-110
+        self.mfGridElementHeightInv = _f32(FRAME_GRID_ROWS) / (self.mnMaxY - self.mnMinY)
+        self.mGrid = [[[] for _ in range(FRAME_GRID_ROWS)] for _ in range(FRAME_GRID_COLS)]
+        for i in range(self.N):
+            posX = c_round((self.x[i] - self.mnMinX) * self.mfGridElementWidthInv)
+            posY = c_round((self.y[i] - self.mnMinY) * self.mfGridElementHeightInv)
+            if posX < 0 or posX >= FRAME_GRID_COLS or posY < 0 or posY >= FRAME_GRID_ROWS:
+                continue
+            self.mGrid[posX][posY].append(i)
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
+        x, y, r = _f32(x), _f32(y), _f32(r)
+        vIndices = []
+        nMinCellX = max(0, int(math.floor((x - self.mnMinX - r) * self.mfGridElementWidthInv)))
+        if nMinCellX >= FRAME_GRID_COLS:
+            return vIndices
+        nMaxCellX = min(FRAME_GRID_COLS - 1, int(math.ceil((x - self.mnMinX + r) * self.mfGridElementWidthInv)))
+        if nMaxCellX < 0:
+            return vIndices
+        nMinCellY = max(0, int(math.floor((y - self.mnMinY - r) * self.mfGridElementHeightInv)))
+        if nMinCellY >= FRAME_GRID_ROWS:
+            return vIndices
+        nMaxCellY = min(FRAME_GRID_ROWS - 1, int(math.ceil((y - self.mnMinY + r) * self.mfGridElementHeightInv)))
+        if nMaxCellY < 0:
+            return vIndices
+        bCheckLevels = (minLevel > 0) or (maxLevel >= 0)
+        for ix in range(nMinCellX, nMaxCellX + 1):
+            for iy in range(nMinCellY, nMaxCellY + 1):
+                for j in self.mGrid[ix][iy]:
+                    if bCheckLevels:
+                        if self.octave[j] < minLevel:
+                            continue
+                        if maxLevel >= 0 and self.octave[j] > maxLevel:
+                            continue
+                    distx = self.x[j] - x
+                    disty = self.y[j] - y
+                    if abs(distx) < r and abs(disty) < r:
+                        vIndices.append(j)
+        return vIndices
+
+
+def compute_three_maxima(sizes):
+    """ORBmatcher::ComputeThreeMaxima (:1506-1538) on the bin sizes."""
+    max1 = max2 = max3 = 0
+    ind1 = ind2 = ind3 = -1
+    for i, s in enumerate(sizes):
+        if s > max1:
+            max3, max2, max1 = max2, max1, s
+            ind3, ind2, ind1 = ind2, ind1, i
+        elif s > max2:
+            max3, max2 = max2, s
+            ind3, ind2 = ind2, i
+        elif s > max3:
+            max3 = s
+            ind3 = i
+    if _f32(max2) < _f32(0.1) * _f32(max1):
+        ind2 = ind3 = -1
+    elif _f32(max3) < _f32(0.1) * _f32(max1):
+        ind3 = -1
+    return ind1, ind2, ind3
+
+
+def _rot_bin(angle_a, angle_b):
+    rot = _f32(angle_a) - _f32(angle_b)
+    if rot < 0.0:
+        rot = rot + _f32(360.0)
+    b = c_round(rot * (_f32(1.0) / _f32(HISTO_LENGTH)))
+    return 0 if b == HISTO_LENGTH else b
+
+
+def ref_search_by_projection_points(F, points, nnratio, has_observed_point):
+    """SearchByProjection(Frame&, vector<MapPoint*>&, th) (:45-128).  points: list of dicts with the MapPoint fields the loop
+    reads after the caller's part -- skip (= !mbTrackInView || isBad()), proj_x, proj_y, proj_xr, level, radius
+    (= r * mvScaleFactors[level]), observed (Observations() > 0), desc.  has_observed_point[idx]: F.mvpMapPoints[idx] exists
+    with Observations() > 0 before the call.  Returns (nmatches, point index per keypoint or -1)."""
+    mvpMapPoints = [None] * F.N                      # index of the point written by this call
+    pre = list(has_observed_point)
+    nmatches = 0
+    for iMP, p in enumerate(points):
+        if p["skip"]:
+            continue
+        lvl = p["level"]
+        vIndices = F.GetFeaturesInArea(p["proj_x"], p["proj_y"], p["radius"], lvl - 1, lvl)
+        if not vIndices:
+            continue
+        bestDist, bestLevel, bestDist2, bestLevel2, bestIdx = 256, -1, 256, -1, -1
+        for idx in vIndices:
+            cur = mvpMapPoints[idx]
+            if (cur is not None and points[cur]["observed"]) or (cur is None and pre[idx]):
+                continue
+            if F.u_right is not None and F.u_right[idx] > 0:
+                er = abs(_f32(p["proj_xr"]) - F.u_right[idx])
+                if er > _f32(p["radius"]):
+                    continue
+            dist = descriptor_distance(p["desc"], F.desc[idx])
+            if dist < bestDist:
+                bestDist2, bestDist = bestDist, dist
+                bestLevel2, bestLevel = bestLevel, F.octave[idx]
+                bestIdx = idx
+            elif dist < bestDist2:
+                bestLevel2 = F.octave[idx]
+                bestDist2 = dist
+        if bestDist <= TH_HIGH:
+            if bestLevel == bestLevel2 and _f32(bestDist) > _f32(nnratio) * _f32(bestDist2):
+                continue
+            mvpMapPoints[bestIdx] = iMP
+            pre[bestIdx] = False
+            nmatches += 1
+    return nmatches, [(-1 if v is None else v) for v in mvpMapPoints]
+
+
+def ref_search_by_projection_frame(F, last, check_orientation, has_observed_point):
+    """SearchByProjection(Frame& cur, const Frame& last, th, bMono) from the window search on (:1289-1383).  last: list of
+    dicts per LastFrame keypoint -- skip (no point / outlier / behind the camera / outside the image), u, v, ur
+    (= u - mbf * invzc), radius, min_level, max_level (the bForward / bBackward / default choice made by the caller),
+    observed, angle (LastFrame.mvKeysUn[i].angle), desc."""
+    mvpMapPoints = [None] * F.N
+    pre = list(has_observed_point)
+    rotHist = [[] for _ in range(HISTO_LENGTH)]
+    nmatches = 0
+    for i, p in enumerate(last):
+        if p["skip"]:
+            continue
+        vIndices2 = F.GetFeaturesInArea(p["u"], p["v"], p["radius"], p["min_level"], p["max_level"])
+        if not vIndices2:
+            continue
+        bestDist, bestIdx2 = 256, -1
+        for i2 in vIndices2:
+            cur = mvpMapPoints[i2]
+            if (cur is not None and cur >= 0 and last[cur]["observed"]) or (cur is None and pre[i2]):
+                continue
+            if F.u_right is not None and F.u_right[i2] > 0:
+                er = abs(_f32(p["ur"]) - F.u_right[i2])
+                if er > _f32(p["radius"]):
+                    continue
+            dist = descriptor_distance(p["desc"], F.desc[i2])
+            if dist < bestDist:
+                bestDist, bestIdx2 = dist, i2
+        if bestDist <= TH_HIGH:
+            mvpMapPoints[bestIdx2] = i
+            pre[bestIdx2] = False
+            nmatches += 1
+            if check_orientation:
+                rotHist[_rot_bin(p["angle"], F.angle[bestIdx2])].append(bestIdx2)
+    if check_orientation:
+        ind = compute_three_maxima([len(h) for h in rotHist])
+        for b in range(HISTO_LENGTH):
+            if b in ind:
+                continue
+            for idx in rotHist[b]:
+                mvpMapPoints[idx] = -1          # static_cast<MapPoint*>(NULL)
+                nmatches -= 1
+    return nmatches, [(-1 if v is None else v) for v in mvpMapPoints]
+
+
+def ref_search_by_bow(descKF, angleKF, validKF, featvecKF, descF, angleF, featvecF, nnratio, check_orientation):
+    """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:161-273).  featvec*: {node id: [feature indices]} (DBoW2::FeatureVector
+    is a std::map: ascending ids); validKF[i]: the keyframe's map point i exists and is not bad.  Returns (nmatches,
+    keyframe feature index per frame feature or -1)."""
+    matches = [-1] * len(descF)
+    rotHist = [[] for _ in range(HISTO_LENGTH)]
+    nmatches = 0
+    idsKF, idsF = sorted(featvecKF), sorted(featvecF)
+    a = b = 0
+    while a < len(idsKF) and b < len(idsF):
+        if idsKF[a] == idsF[b]:
+            for realIdxKF in featvecKF[idsKF[a]]:
+                if not validKF[realIdxKF]:
+                    continue
+                bestDist1, bestIdxF, bestDist2 = 256, -1, 256
+                for realIdxF in featvecF[idsF[b]]:
+                    if matches[realIdxF] >= 0:
+                        continue
+                    dist = descriptor_distance(descKF[realIdxKF], descF[realIdxF])
+                    if dist < bestDist1:
+                        bestDist2, bestDist1, bestIdxF = bestDist1, dist, realIdxF
+                    elif dist < bestDist2:
+                        bestDist2 = dist
+                if bestDist1 <= TH_LOW and _f32(bestDist1) < _f32(nnratio) * _f32(bestDist2):
+                    matches[bestIdxF] = realIdxKF
+                    if check_orientation:
+                        rotHist[_rot_bin(angleKF[realIdxKF], angleF[bestIdxF])].append(bestIdxF)
+                    nmatches += 1
+            a += 1
+            b += 1
+        elif idsKF[a] < idsF[b]:
+            while a < len(idsKF) and idsKF[a] < idsF[b]:      # lower_bound
+                a += 1
+        else:
+            while b < len(idsF) and idsF[b] < idsKF[a]:
+                b += 1
+    if check_orientation:
+        ind = compute_three_maxima([len(h) for h in rotHist])
+        for i in range(HISTO_LENGTH):
+            if i in ind:
+                continue
+            for j in rotHist[i]:
+                matches[j] = -1
+                nmatches -= 1
+    return nmatches, matches
+
+
+def ref_search_for_initialization(keys1, desc1, F2, prev_matched, window, nnratio, check_orientation):
+    """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:388-492).  Returns (nmatches, vnMatches12,
+    updated vbPrevMatched)."""
+    INT_MAX = 2 ** 31 - 1
+    n1 = len(keys1)
+    prev = [(_f32(p[0]), _f32(p[1])) for p in prev_matched]
+    vnMatches12 = [-1] * n1
+    rotHist = [[] for _ in range(HISTO_LENGTH)]
+    vMatchedDistance = [INT_MAX] * F2.N
+    vnMatches21 = [-1] * F2.N
+    nmatches = 0
+    for i1 in range(n1):
+        level1 = int(keys1["octave"][i1])
+        if level1 > 0:
+            continue
+        vIndices2 = F2.GetFeaturesInArea(prev[i1][0], prev[i1][1], window, level1, level1)
+        if not vIndices2:
+            continue
+        bestDist, bestDist2, bestIdx2 = INT_MAX, INT_MAX, -1
+        for i2 in vIndices2:
+            dist = descriptor_distance(desc1[i1], F2.desc[i2])
+            if vMatchedDistance[i2] <= dist:
+                continue
+            if dist < bestDist:
+                bestDist2, bestDist, bestIdx2 = bestDist, dist, i2
+            elif dist < bestDist2:
+                bestDist2 = dist
+        if bestDist <= TH_LOW and _f32(bestDist) < _f32(bestDist2) * _f32(nnratio):
+            if vnMatches21[bestIdx2] >= 0:
+                vnMatches12[vnMatches21[bestIdx2]] = -1
+                nmatches -= 1
+            vnMatches12[i1] = bestIdx2
+            vnMatches21[bestIdx2] = i1
+            vMatchedDistance[bestIdx2] = bestDist
+            nmatches += 1
+            if check_orientation:
+                rotHist[_rot_bin(keys1["angle"][i1], F2.angle[bestIdx2])].append(i1)
+    if check_orientation:
+        ind = compute_three_maxima([len(h) for h in rotHist])
+        for i in range(HISTO_LENGTH):
+            if i in ind:
+                continue
+            for idx1 in rotHist[i]:
+                if vnMatches12[idx1] >= 0:
+                    vnMatches12[idx1] = -1
+                    nmatches -= 1
+    for i1 in range(n1):
+        if vnMatches12[i1] >= 0:
+            prev[i1] = (F2.x[vnMatches12[i1]], F2.y[vnMatches12[i1]])
+    return nmatches, vnMatches12, prev

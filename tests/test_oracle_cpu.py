@@ -381,3 +381,123 @@ def test_vocabulary_transform_hand_example(tmp_path):
     half = np.zeros((1, 32), np.uint8); half[0, :22] = 255   # n2 (80 < 112), then n6 (48 < 80): the stopped word -> dropped
     bow1, fv1, (w1, _, wt1) = v.transform(np.concatenate([feats, half]), 1)
     assert w1[-1] == 3 and wt1[-1] == 0 and fv1 == fv and bow1 == bow
+
+
+# ------------------------------------------------------------------ the matcher loops: C oracle vs a second, independent reading
+def _queries_from(keys, desc, sf, rng, dx, dy, mode):
+    """Query records (as the C oracle takes them) for every keypoint of one frame searched in another: window centre = the
+    keypoint moved by (dx, dy) plus jitter, mixed flags."""
+    n = len(keys)
+    q = np.zeros(n, ol.QUERY_DTYPE)
+    q["u"] = keys["x"] + np.float32(dx) + rng.uniform(-1.5, 1.5, n).astype(np.float32)
+    q["v"] = keys["y"] + np.float32(dy) + rng.uniform(-1.5, 1.5, n).astype(np.float32)
+    q["u_r"] = q["u"] - rng.uniform(0, 30, n).astype(np.float32)
+    lvl = keys["octave"].astype(np.int32)
+    if mode == "points":
+        r = np.where(rng.random(n) < 0.5, np.float32(2.5), np.float32(4.0)) * np.float32(3.0)
+        q["radius"] = r.astype(np.float32) * sf[lvl]
+        q["min_level"], q["max_level"] = lvl - 1, lvl
+    else:
+        q["radius"] = np.float32(7.0) * sf[lvl]
+        kind = rng.integers(0, 3, n)                      # default / forward / backward level ranges
+        q["min_level"] = np.where(kind == 0, lvl - 1, np.where(kind == 1, lvl, 0))
+        q["max_level"] = np.where(kind == 0, lvl + 1, np.where(kind == 1, -1, lvl))
+    q["valid"] = rng.random(n) < 0.9
+    q["blocks"] = rng.random(n) < 0.7
+    q["angle"] = keys["angle"]
+    d = desc.copy()
+    flip = rng.random(n) < 0.5
+    d[flip, rng.integers(0, 32)] ^= 0x3c
+    q["desc"] = d
+    return q
+
+
+def _as_points(q):
+    return [dict(skip=not bool(e["valid"]), proj_x=e["u"], proj_y=e["v"], proj_xr=e["u_r"], level=int(e["max_level"]),
+                 radius=e["radius"], observed=bool(e["blocks"]), desc=e["desc"]) for e in q]
+
+
+def _as_last(q):
+    return [dict(skip=not bool(e["valid"]), u=e["u"], v=e["v"], ur=e["u_r"], radius=e["radius"], min_level=int(e["min_level"]),
+                 max_level=int(e["max_level"]), observed=bool(e["blocks"]), angle=e["angle"], desc=e["desc"]) for e in q]
+
+
+def _check_matchers(kA, dA, kB, dB, sf, w, h, u_right, seed, dx=0.0, dy=0.0):
+    rng = np.random.default_rng(seed)
+    oB = ol.OracleFrame(kB, dB, sf, 0, w, 0, h, u_right)
+    rB = nr.RefFrame(kB, dB, 0, w, 0, h, u_right)
+    # Frame::GetFeaturesInArea, query by query, enumeration order included
+    for i in range(0, len(kA), 7):
+        for (lo, hi) in ((-1, -1), (int(kA["octave"][i]) - 1, int(kA["octave"][i]) + 1), (2, -1), (0, 0)):
+            a = oB.features_in_area(float(kA["x"][i]) + dx, float(kA["y"][i]) + dy, 11.5, lo, hi)
+            b = rB.GetFeaturesInArea(np.float32(kA["x"][i]) + np.float32(dx), np.float32(kA["y"][i]) + np.float32(dy), 11.5, lo, hi)
+            assert list(a) == b, (i, lo, hi)
+    blocked = (rng.random(len(kB)) < 0.1).astype(np.uint8)
+    # SearchByProjection(Frame&, MapPoints)  :45-128
+    q = _queries_from(kA, dA, sf, rng, dx, dy, "points")
+    nm, assigned, _ = oB.search_by_projection_points(q, 0.8, blocked)
+    rnm, rassigned = nr.ref_search_by_projection_points(rB, _as_points(q), 0.8, blocked.astype(bool))
+    assert nm == rnm and list(assigned) == rassigned
+    # SearchByProjection(cur, last)  :1247-1383, with and without the rotation check
+    q = _queries_from(kA, dA, sf, rng, dx, dy, "frame")
+    for ori in (True, False):
+        nm, assigned, _ = oB.search_by_projection_frame(q, ori, blocked)
+        rnm, rassigned = nr.ref_search_by_projection_frame(rB, _as_last(q), ori, blocked.astype(bool))
+        assert nm == rnm and list(assigned) == rassigned, ori
+    # SearchByBoW(KF, F)  :161-273
+    gA, gB = _bow_groups(dA), _bow_groups(dB)
+    valid = (rng.random(len(kA)) < 0.85).astype(np.uint8)
+    for ori in (True, False):
+        nm, mB = ol.search_by_bow(dA, kA["angle"], valid, gA, dB, kB["angle"], gB, 0.7, ori)
+        rnm, rmB = nr.ref_search_by_bow(dA, kA["angle"], valid, gA, dB, kB["angle"], gB, 0.7, ori)
+        assert nm == rnm and list(mB) == rmB, ori
+    # SearchForInitialization  :388-492 (match stealing through vMatchedDistance / vnMatches21)
+    prev = np.stack([kA["x"] + np.float32(dx), kA["y"] + np.float32(dy)], 1).astype(np.float32)
+    for win, ori in ((100, True), (20, False)):
+        nm, m12, p2 = ol.search_for_initialization(kA, dA, oB, prev, win, 0.9, ori)
+        rnm, rm12, rp2 = nr.ref_search_for_initialization(kA, dA, rB, prev, win, 0.9, ori)
+        assert nm == rnm and list(m12) == rm12
+        np.testing.assert_array_equal(p2, np.asarray(rp2, np.float32))
+    return nm
+
+
+def test_matcher_loops_agree_with_second_reading_on_real_images():
+    """C oracle == tests/np_restatement.py's independent Python reading of GetFeaturesInArea, SearchByProjection x2,
+    SearchByBoW and SearchForInitialization on the DBoW2 demo images (pairs 0-1 and 0-shifted)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_demo.npz"))
+    imgs = g["images"]
+    ex = ol.OracleExtractor(int(g["nfeatures"]))
+    sf = ex.scale_factors
+    ext = [ex(im) for im in (imgs[0], imgs[1], imgs[4])]
+    h, w = imgs[0].shape
+    rng = np.random.default_rng(5)
+    ur = np.where(rng.random(len(ext[1][0])) < 0.6, ext[1][0]["x"] - rng.uniform(0, 40, len(ext[1][0])).astype(np.float32), np.float32(-1)).astype(np.float32)
+    assert _check_matchers(ext[0][0], ext[0][1], ext[1][0], ext[1][1], sf, w, h, ur, 11) >= 0
+    assert _check_matchers(ext[0][0], ext[0][1], ext[2][0], ext[2][1], sf, w, h, None, 12, dx=4.0, dy=2.0) > 50
+
+
+def test_matcher_loops_agree_with_second_reading_on_ties():
+    """A case built to tie: keypoints on a coarse lattice (many per grid cell, several exactly on window borders), descriptors
+    drawn from five patterns (duplicate descriptors, equal best and second-best distances inside and across grid cells),
+    mvuRight at exactly 0, below and above; every strict / non-strict comparison of the loops decides somewhere."""
+    rng = np.random.default_rng(99)
+    w, h = 320, 240
+    sf = np.array([np.float32(1.2) ** i for i in range(8)], np.float32)
+    pats = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    pats[1] = pats[0]; pats[1][3] ^= 1          # distance 1 apart
+    pats[2] = pats[0]; pats[2][7] ^= 2          # also distance 1 from pattern 0
+    def frame(n, seed):
+        r = np.random.default_rng(seed)
+        k = np.zeros(n, ol.KP_DTYPE)
+        k["x"] = (r.integers(4, 76, n) * 4).astype(np.float32) + np.where(r.random(n) < 0.3, np.float32(0.5), np.float32(0))
+        k["y"] = (r.integers(4, 56, n) * 4).astype(np.float32)
+        k["octave"] = r.integers(0, 3, n)
+        k["angle"] = (r.integers(0, 24, n) * 15).astype(np.float32)      # rot * factor lands on .0 and .5 exactly
+        k["size"] = 31; k["response"] = 20; k["class_id"] = -1
+        d = pats[r.integers(0, 5, n)]
+        return k, d
+    kA, dA = frame(400, 1)
+    kB, dB = frame(500, 2)
+    ur = np.array([0.0, -1.0, 5.0, 0.0, 120.25], np.float32)[rng.integers(0, 5, len(kB))]
+    assert _check_matchers(kA, dA, kB, dB, sf, w, h, ur, 7) >= 0
+    assert _check_matchers(kA, dA, kA.copy(), dA.copy(), sf, w, h, None, 8) >= 0
