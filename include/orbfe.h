@@ -66,6 +66,18 @@ typedef struct orbfe_extractor orbfe_extractor;
 const char* orbfe_last_error(void);   /* thread-local text of the last failure on this thread */
 int orbfe_device_count(int* count);   /* number of visible HIP devices */
 
+/* Hard limits (checked, ORBFE_ERR_INVALID beyond them):
+ *   images              at most 4095 x 4095 pixels (keypoint coordinates travel between kernels as 12-bit fields) and at least
+ *                       one FAST cell per level the caller wants keypoints from (a level narrower or lower than 2 x 16 + 30
+ *                       pixels yields none, where the reference divides by zero, L/src/ORBextractor.cc:753-754)
+ *   pyramid             n_levels <= ORBFE_MAX_LEVELS (16); FAST cells <= 66 x 66 pixels
+ *   descriptor sets     fewer than 65 536 descriptors per frame / per set (orbfe_hamming_bf_device, orbfe_stereo_match*,
+ *                       the projection searches: indices travel as 16-bit fields next to the distance)
+ *   inv_level_sigma2    orbfe_proj_best / orbfe_kf_search read n_levels floats (the caller states n_levels)
+ * Threads: a handle serialises its own calls (internal mutex); different handles may be used from different threads at the same
+ * time (Frame.cc:91-94 runs the two extractors on two threads).  The library holds no other mutable global state and reads no
+ * environment variables. */
+
 /* ------------------------------------------------------------------------------------- ORBextractor */
 /* ORBextractor::ORBextractor (L/src/ORBextractor.cc:407-464).  device < 0 selects the current device. */
 int orbfe_extractor_create(const orbfe_params* params, int device, orbfe_extractor** out);

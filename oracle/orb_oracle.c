@@ -6,7 +6,7 @@
  * OpenCV 4.5.x generic algorithms.  Scalar, single-threaded, written for clarity, not speed.
  *
  * L/ = Source/Libraries/ORB_SLAM2/ in the reference checkout.
- * Build: see oracle/Makefile (-O2 -ffp-contract=off: the reference x86-64 build has no FMA contraction).
+ * Build: see oracle/Makefile (-O3 -ffp-contract=off: the reference x86-64 build has no FMA contraction).
  */
 #include "orb_oracle.h"
 

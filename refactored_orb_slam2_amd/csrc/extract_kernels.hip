@@ -3,7 +3,7 @@
 // Kernel            replaces (reference file:line, L/ = Source/Libraries/ORB_SLAM2/)
 // copy_level0       copyMakeBorder of the input into mvImagePyramid[0]  L/src/ORBextractor.cc:1061
 // pyr_resize        cv::resize(INTER_LINEAR) chained level to level      L/src/ORBextractor.cc:1054
-// fast_groups       per-cell cv::FAST(th=ini, else th=min) + NMS         L/src/ORBextractor.cc:756-791
+// fast_cells        per-cell cv::FAST(th=ini, else th=min) + NMS         L/src/ORBextractor.cc:756-791
 // octree_select     DistributeOctTree + DivideNode                       L/src/ORBextractor.cc:475-731
 // gauss_blur7       GaussianBlur(7x7, sigma 2, REFLECT_101)              L/src/ORBextractor.cc:1017-1019
 // orient_describe   IC_Angle + computeOrbDescriptor + pt*=scale          L/src/ORBextractor.cc:76-146,1028-1035
@@ -356,53 +356,6 @@ __global__ __launch_bounds__(256) void pyr_resize_dot_kernel(const uint8_t* __re
 __device__ constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 __device__ constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
-// true iff the 16-bit circular mask holds >= 9 contiguous ones
-__device__ __forceinline__ bool ring_has9(uint32_t m) {
-  m |= m << 16;
-  uint32_t a = m & (m >> 1);
-  uint32_t b = a & (a >> 2);
-  uint32_t c = b & (b >> 4);
-  uint32_t d = c & (m >> 8);
-  return (d & 0xffffu) != 0;
-}
-
-// cornerScore<16>: (largest t at which the pixel is still a corner) = max over the sixteen 9-arcs of the arc
-// minimum of (v-p), and of (p-v), larger of the two, minus 1.
-__device__ __forceinline__ int corner_score16(const int d[16]) {
-  int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo2[i] = min(d[i], d[(i + 1) & 15]);
-    hi2[i] = max(d[i], d[(i + 1) & 15]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
-    hi4[i] = max(hi2[i], hi2[(i + 2) & 15]);
-  }
-  int A = -1000, B = 1000;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-    int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-    A = max(A, lo9);   // dark arc:   all (v - p) >= lo9
-    B = min(B, hi9);   // bright arc: all (p - v) >= -hi9
-  }
-  return max(A, -B) - 1;
-}
-
-// 16-bit VOP2 min / max issue at twice the rate of their 32-bit forms on gfx950 (tools/valu_bench.hip).  Operands are
-// 32-bit containers whose low halves hold the value (gfx9 16-bit ops zero the high half of the destination).
-__device__ __forceinline__ unsigned min16(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ unsigned max16(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 // packed (2 x u16) min / max
 __device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
   uint32_t r;
@@ -413,210 +366,6 @@ __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
   uint32_t r;
   asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
-}
-__device__ __forceinline__ unsigned mini16(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ unsigned maxi16(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// cornerScore<16> with 16-bit signed min / max: d[k] holds (v - q_k) in its low 16 bits (|d| <= 255)
-__device__ __forceinline__ int corner_score16_h(const unsigned d[16]) {
-  unsigned lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo2[i] = mini16(d[i], d[(i + 1) & 15]);
-    hi2[i] = maxi16(d[i], d[(i + 1) & 15]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo4[i] = mini16(lo2[i], lo2[(i + 2) & 15]);
-    hi4[i] = maxi16(hi2[i], hi2[(i + 2) & 15]);
-  }
-  unsigned A = 0x8000u, B = 0x7fffu;  // INT16_MIN, INT16_MAX
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const unsigned lo9 = mini16(mini16(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-    const unsigned hi9 = maxi16(maxi16(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-    A = maxi16(A, lo9);   // dark arc:   all (v - p) >= lo9
-    B = mini16(B, hi9);   // bright arc: all (p - v) >= -hi9
-  }
-  const int a = (int)(short)(A & 0xffffu), bneg = -(int)(short)(B & 0xffffu);
-  return max(a, bneg) - 1;
-}
-#define FG_THREADS 512
-__global__ __launch_bounds__(FG_THREADS) void fast_groups_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
-                                                            const FastGroup* __restrict__ groups, int n_groups,
-                                                            int total_cells, int tile_rows, int clist_cap,
-                                                            int32_t* __restrict__ cell_cnt, uint32_t* __restrict__ slots,
-                                                            unsigned long long slots_per_image, int ini_th, int min_th,
-                                                            int xcd_run_shift) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t fg_smem[];
-  __shared__ int nlist;
-  uint8_t* tile = fg_smem;
-  uint8_t* sc = tile + tile_rows * ORBFE_FG_PITCH;
-  uint32_t* bits = reinterpret_cast<uint32_t*>(sc + tile_rows * ORBFE_FG_PITCH);  // [cell][all 128 | hi 128]
-  uint16_t* clist = reinterpret_cast<uint16_t*>(bits + ORBFE_FG_MAX * 256);
-
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int img = blockIdx.y;
-  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so consecutive groups --
-  // which share 6-pixel halo lines -- would be fetched by different L2s.  Hand every XCD runs of 2^shift consecutive
-  // groups instead (runs interleave over the XCDs, so all levels stay balanced); the last partial set of 8 runs keeps the
-  // identity order, so the grid needs no padding blocks.
-  const int q = blockIdx.x >> 3;
-  const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
-  const int gid = (xcd_run_shift < 0 || (int)blockIdx.x >= (n_groups / unit) * unit)
-                      ? (int)blockIdx.x
-                      : ((q >> xcd_run_shift) << (xcd_run_shift + 3)) + ((blockIdx.x & 7) << xcd_run_shift) +
-                            (q & ((1 << xcd_run_shift) - 1));
-  const FastGroup g = groups[gid];
-  const int pitch = pyr.pitch[g.level];
-  const uint8_t* plane = pyr.base[g.level] + (size_t)img * pyr.img_stride[g.level];
-  const int width = g.width, rows = g.rows, wcell = g.wcell, ncell = g.n_cells;
-  const int ax = g.x0 & ~15, xo = g.x0 & 15;
-  const int ndq = (xo + width + 15) >> 4;  // 16-byte columns, <= 12 (plane base, pitch and ax are 16-byte aligned)
-
-  if (tid == 0) nlist = 0;
-  for (int i = tid; i < ORBFE_FG_MAX * 256; i += FG_THREADS) bits[i] = 0;
-  {
-    // clear the score plane, then stage the ROI with 16-byte loads: thread -> (row r0 + k*rpp, column c), one division
-    uint4* s128 = reinterpret_cast<uint4*>(sc);
-    for (int i = tid; i < rows * (ORBFE_FG_PITCH / 16); i += FG_THREADS) s128[i] = make_uint4(0, 0, 0, 0);
-    const int rpp = FG_THREADS / ndq;  // rows per pass (>= 42)
-    const int r0 = (int)((tid + 0.5f) * (1.0f / (float)ndq));
-    const int c = tid - r0 * ndq;
-    if (r0 < rpp) {
-      const uint8_t* src = plane + (size_t)g.y0 * pitch + ax + 16 * c;
-      uint4* dst = reinterpret_cast<uint4*>(tile) + c;
-      uint4 v[2];
-#pragma unroll
-      for (int k = 0; k < 2; k++) {   // rows <= 66 < 2 * rpp
-        const int rr = r0 + k * rpp;
-        v[k] = rr < rows ? *reinterpret_cast<const uint4*>(src + (size_t)rr * pitch) : make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int rr = r0 + k * rpp;
-        if (rr < rows) dst[rr * (ORBFE_FG_PITCH / 16)] = v[k];
-      }
-    }
-  }
-  __syncthreads();
-
-  const int tw = width - 6, th = rows - 6;  // tested region of the group: [3, width-3) x [3, rows-3)
-  const int npix = (tw > 0 && th > 0) ? tw * th : 0;
-
-  // ---- A1 (flattened over the tested region; the index advances without divisions).  Scalar bytes on purpose: on
-  // gfx950 v_pk_*16 / v_perm_b32 / min / max all issue at 16 lanes per clock, the same as their scalar forms, so a packed
-  // two-pixels-per-lane variant (tried: 78 VALU per 4 pixels) was slower than this one (tools/valu_bench.hip).
-  {
-    const int ty0 = (int)((tid + 0.5f) * (1.0f / (float)(tw > 0 ? tw : 1)));
-    int tx = tid - ty0 * tw;
-    const int sa = FG_THREADS / (tw > 0 ? tw : 1), sb = FG_THREADS - sa * tw;   // FG_THREADS = sa * tw + sb, sb < tw
-    const int delta = sa * ORBFE_FG_PITCH + sb;
-    // the pixel's byte offset in the staged tile is carried along (one multiply per thread, not per pixel) and doubles as the
-    // survivor-list entry: sc uses the same offsets, so A2 / B address both planes with it directly
-    int off = (ty0 + 3) * ORBFE_FG_PITCH + tx + 3 + xo;
-    typedef unsigned u16;  // 32-bit container, value in the low half
-    // (processing two pixels per iteration with all 18 LDS reads up front was measured slower: the phase is bound by
-    // VALU / SALU issue, not by LDS latency)
-    for (int p = tid; p < npix; p += FG_THREADS) {
-      const uint8_t* c = tile + off;
-      const u16 v = c[0];
-      const u16 q0 = c[3 * ORBFE_FG_PITCH], q8 = c[-3 * ORBFE_FG_PITCH];
-      const u16 q2 = c[2 * ORBFE_FG_PITCH + 2], q10 = c[-2 * ORBFE_FG_PITCH - 2];
-      const u16 q4 = c[3], q12 = c[-3];
-      const u16 q6 = c[-2 * ORBFE_FG_PITCH + 2], q14 = c[2 * ORBFE_FG_PITCH - 2];
-      const u16 d01 = max16(min16(q0, q8), min16(q2, q10)), d23 = max16(min16(q4, q12), min16(q6, q14));
-      const u16 b01 = min16(max16(q0, q8), max16(q2, q10)), b23 = min16(max16(q4, q12), max16(q6, q14));
-      const int dm = (int)max16(d01, d23), bm = (int)min16(b01, b23);
-      if (dm < (int)v - min_th || bm > (int)v + min_th) {
-        const int idx = atomicAdd(&nlist, 1);
-        if (idx < clist_cap) clist[idx] = (uint16_t)off;
-      }
-      tx += sb; off += delta;
-      if (tx >= tw) { tx -= tw; off += ORBFE_FG_PITCH - tw; }
-    }
-  }
-  __syncthreads();
-
-  // ---- A2: exact score of the survivors
-  const int nl = min(nlist, clist_cap);
-  for (int i = tid; i < nl; i += FG_THREADS) {
-    const int e = clist[i];   // byte offset of the pixel in the tile (and in sc)
-    const uint8_t* c = tile + e;
-    const int v = c[0];
-    unsigned d[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = (unsigned)(v - (int)c[RDY[k] * ORBFE_FG_PITCH + RDX[k]]);
-    const int sc16 = corner_score16_h(d);
-    if (sc16 >= min_th) sc[e] = (uint8_t)sc16;
-  }
-  __syncthreads();
-
-  // ---- B: strict 3x3 NMS inside the survivor's own cell
-  for (int i = tid; i < nl; i += FG_THREADS) {
-    const int e = clist[i];
-    const uint8_t* s = sc + e;
-    const int v = s[0];
-    if (v > 0) {
-      const int y = (int)((e + 0.5f) * (1.0f / ORBFE_FG_PITCH));   // exact: e < 66 * 192
-      const int x = e - y * ORBFE_FG_PITCH - xo;
-      const int xr = x - 3;
-      const int c = (xr >= wcell) + (xr >= 2 * wcell) + (xr >= 3 * wcell);
-      const int lo = c * wcell + 3, hi = (c == ncell - 1) ? width - 3 : lo + wcell;
-      const bool hasl = x > lo, hasr = x + 1 < hi;
-      const int l0 = hasl ? s[-ORBFE_FG_PITCH - 1] : 0, l1 = hasl ? s[-1] : 0, l2 = hasl ? s[ORBFE_FG_PITCH - 1] : 0;
-      const int r0 = hasr ? s[-ORBFE_FG_PITCH + 1] : 0, r1 = hasr ? s[1] : 0, r2 = hasr ? s[ORBFE_FG_PITCH + 1] : 0;
-      const bool keep = v > l0 && v > l1 && v > l2 && v > r0 && v > r1 && v > r2 && v > s[-ORBFE_FG_PITCH] && v > s[ORBFE_FG_PITCH];
-      if (keep) {
-        const int p = (y - 3) * (hi - lo) + (x - lo);
-        atomicOr(&bits[c * 256 + (p >> 5)], 1u << (p & 31));
-        if (v >= ini_th) atomicOr(&bits[c * 256 + 128 + (p >> 5)], 1u << (p & 31));
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- C: wave w emits cell w: two consecutive 32-pixel words per lane, one wave scan
-  if (wid < ncell) {
-    const int c = wid;
-    const CellDesc cd = cells[g.first_cell + c];
-    const int lo = c * wcell + 3, hi = (c == ncell - 1) ? width - 3 : lo + wcell;
-    const int twc = hi - lo;
-    const float inv_twc = 1.0f / (float)twc;
-    const uint32_t* ba = bits + c * 256;
-    const uint32_t a0 = ba[2 * lane], a1 = ba[2 * lane + 1], h0 = ba[128 + 2 * lane], h1 = ba[128 + 2 * lane + 1];
-    const int packed = ((__popc(h0) + __popc(h1)) << 16) | (__popc(a0) + __popc(a1));
-    const int incl = wave_incl_scan(packed);
-    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
-    const int excl = incl - packed;
-    const bool use_hi = (total >> 16) != 0;
-    int off = use_hi ? (excl >> 16) : (excl & 0xffff);
-    const int n_out = use_hi ? (total >> 16) : (total & 0xffff);
-    uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
-#pragma unroll
-    for (int w = 0; w < 2; w++) {
-      uint32_t mask = use_hi ? (w ? h1 : h0) : (w ? a1 : a0);
-      while (mask) {
-        const int b = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        const int p = (2 * lane + w) * 32 + b;
-        const int ty = (int)((p + 0.5f) * inv_twc);
-        const int x = p - ty * twc + lo, y = ty + 3;
-        const uint32_t sv = sc[y * ORBFE_FG_PITCH + x + xo];
-        const uint32_t rx = (uint32_t)(x + g.x0 - ORBFE_EDGE), ry = (uint32_t)(y + g.y0 - ORBFE_EDGE);
-        if (off < cd.slot_cap) slot[off] = rx | (ry << 12) | (sv << 24);
-        off++;
-      }
-    }
-    if (lane == 0) cell_cnt[(size_t)img * total_cells + g.first_cell + c] = n_out < cd.slot_cap ? n_out : cd.slot_cap;
-  }
 }
 
 // packed (2 x i16) helpers of the pair-wise corner score below
@@ -1387,7 +1136,7 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
   __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
   const int tid = threadIdx.x;
-  // XCD-aware mapping (see fast_groups): runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
+  // XCD-aware mapping: runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
   const int q = blockIdx.x >> 3;
   const int tile_id = (int)blockIdx.x >= (n_tiles / 64) * 64 ? (int)blockIdx.x : (q >> 3) * 64 + (blockIdx.x & 7) * 8 + (q & 7);
   const BlurTile t = tiles[tile_id];
@@ -1508,7 +1257,6 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
 // the same pattern as floats, one (x0, y0, x1, y1) record per test pair (filled at start-up by the host)
 __device__ __attribute__((aligned(16))) float g_pattern_f[1024];
 // umax of ORBextractor's constructor for HALF_PATCH_SIZE 15 (L/src/ORBextractor.cc:449-463)
-__device__ constexpr int UMAX[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 // cv::fastAtan2 (degrees), scalar OpenCV path, float, un-fused
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -1580,162 +1328,16 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
   *cs = sc_poly(xs, x2, n ^ 1, flip);
 }
 
-// One wave per keypoint slot.  IC_Angle on the un-blurred level, steered BRIEF on the blurred level,
-// 4 x __ballot -> 256 bits; writes the cv::KeyPoint record (pt scaled to level-0 pixels) and 32 bytes.
+// LDS staging of a keypoint's two patches: the raw 31 x 31 window of IC_Angle and the blurred 37 x 37 window of the pattern
 #define ORI_PITCH 48   // 3 x 16 B: (cx - 15) & 15 <= 15, 15 + 31 <= 48
 #define DSC_PITCH 64   // 4 x 16 B: 15 + 37 <= 64
 #define ORI_BYTES (31 * ORI_PITCH)                        // 1116
 #define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 2608
-__global__ __launch_bounds__(256) void orient_describe_kernel(DescribeParams P) {
-  __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
-  const int lane = threadIdx.x & (WAVE - 1);
-  // everything that identifies the wave's keypoint is wave-uniform: readfirstlane keeps it (and all the address
-  // arithmetic that follows) in SGPRs / on the scalar unit instead of 64 redundant VALU lanes
-  const int wv_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest).  The patch gather
-  // is bound by L2 misses (every patch byte used to come over the fabric: the planes of the ~4 images in flight do not
-  // fit one XCD's 4 MB L2 when each XCD sees all of them), so XCD k takes whole images k, k+8, ...: the planes of the one
-  // image an XCD is working on (2.9 MB) stay in its L2 and neighbouring patches share their lines.
-  int bx = blockIdx.x, img = blockIdx.y;
-  if (P.xcd_images) {
-    const unsigned gx = gridDim.x;
-    const unsigned lin = blockIdx.y * gx + blockIdx.x;
-    const unsigned grp = lin / (8u * gx);
-    if (8u * grp + 8u <= gridDim.y) {
-      const unsigned within = lin - grp * 8u * gx;
-      img = (int)(8u * grp + (within & 7u));
-      bx = (int)(within >> 3);
-    }
-  }
-  const int slot = bx * 4 + wv_id;
-  // the four pattern entries of this lane (rounds 0..3): issued early, consumed after the orientation
-  float4 pk[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
-  // per-level keypoint counts of this image (scalar loads)
-  const int32_t* ln = P.lvl_n + (size_t)img * ORBFE_MAX_LEVELS;
-  if (slot == 0 && lane == 0) {
-    int tot = 0;
-    for (int l = 0; l < P.n_levels; l++) tot += ln[l];
-    P.out_n[img] = tot;
-  }
-  if (slot >= P.kp_per_image) return;
-  int level = 0;
-  while (level + 1 < P.n_levels && slot >= P.kp_off[level + 1]) level++;
-  const int idx = slot - P.kp_off[level];
-  if (idx >= ln[level]) return;
-  int out = idx;
-  for (int l = 0; l < level; l++) out += ln[l];
-  if (out >= P.cap) return;
-
-  const uint32_t e = P.lvl_kp[(size_t)img * P.kp_per_image + slot];
-  const int cx = (int)(e & 0xfff) + ORBFE_EDGE, cy = (int)((e >> 12) & 0xfff) + ORBFE_EDGE;
-  const int score = (int)(e >> 24);
-
-  // --- stage both patches of this keypoint in the wave's LDS slice with aligned dword loads:
-  //     un-blurred 31x31 (orientation) and blurred 37x37 (rotated pattern offsets reach +-18).
-  //     All 11 loads of a lane are issued before the first LDS store (one memory round trip, not eleven).
-  uint8_t* ori = &patch[wv_id][0];
-  uint8_t* dsc = ori + ORI_BYTES;
-  const int pitch = P.pyr.pitch[level];
-  const int bpitch = P.blur.pitch[level];
-  const uint8_t* plane = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level];
-  const uint8_t* bplane = P.blur.base[level] + (size_t)img * P.blur.img_stride[level];
-  // 16-byte loads: 31 x 3 + 37 x 4 = 241 per keypoint, four per lane (the gather is bound by address processing / L2
-  // requests, not bytes: 4-byte loads needed eleven per lane).  A row's last 16 bytes may lie beyond the image width
-  // (inside the pitch, or the plane buffers' slack for the last row); those bytes are never used.
-  const int ax_o = (cx - 15) & ~15, ax_d = (cx - 18) & ~15;
-  uint4 vo[2], vd[3];
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int i = lane + WAVE * k;
-    const int r = i / 3, c = i - r * 3;
-    vo[k] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 16 * c) : make_uint4(0, 0, 0, 0);
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int i = lane + WAVE * k;
-    const int r = i >> 2, c = i & 3;
-    vd[k] = i < 37 * 4 ? *reinterpret_cast<const uint4*>(bplane + blur_tiled_offset(max(ax_d + 16 * c, 0), max(cy - 18 + r, 0), bpitch)) : make_uint4(0, 0, 0, 0);
-  }
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int i = lane + WAVE * k;
-    const int r = i / 3, c = i - r * 3;
-    if (i < 31 * 3) reinterpret_cast<uint4*>(ori)[r * (ORI_PITCH / 16) + c] = vo[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int i = lane + WAVE * k;
-    if (i < 37 * 4) reinterpret_cast<uint4*>(dsc)[i] = vd[k];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // --- IC_Angle (L/src/ORBextractor.cc:76-100): two rows per step, lanes 0-31 / 32-63
-  const uint8_t* center = ori + 15 * ORI_PITCH + (cx - ax_o);
-  int m10 = 0, m01 = 0;
-  const int u = (lane & 31) - 15;
-  // the circular patch is symmetric (|u| <= umax[|v|]  <=>  |v| <= umax[|u|]): one table look-up per lane
-  const int vlim = (lane & 31) < 31 ? UMAX[u < 0 ? -u : u] : -1;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    // branch-free: lanes outside the disc read a (valid) LDS byte and discard it.  Row 16 (lanes 32-63, i = 15) and
-    // column 16 (lane & 31 == 31) fall inside the wave's own LDS slice.
-    const int v = -15 + 2 * i + (lane >> 5);
-    const int av = v < 0 ? -v : v;
-    const int val = av <= vlim ? (int)center[v * ORI_PITCH + u] : 0;
-    m10 += u * val;
-    m01 += v * val;
-  }
-  m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);  // DPP reduction, total in lane 63
-  m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-  // --- computeOrbDescriptor (L/src/ORBextractor.cc:103-146)
-  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-  const float arad = angle * factorPI;
-  float a, b;
-  glibc_sincosf(arad, &b, &a);
-  const uint8_t* bc = dsc + 18 * DSC_PITCH + (cx - ax_d);
-  uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
-    const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
-    const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
-    const int t0 = bc[ry0 * DSC_PITCH + rx0];
-    const int t1 = bc[ry1 * DSC_PITCH + rx1];
-    const unsigned long long bits = __ballot(t0 < t1);
-    if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = bits;
-  }
-
-  // --- keypoint record
-  if (lane < 7) {
-    float fx = (float)cx, fy = (float)cy;
-    if (level != 0) {
-      fx *= P.scale[level];
-      fy *= P.scale[level];
-    }
-    uint32_t wv;
-    switch (lane) {
-      case 0: wv = __float_as_uint(fx); break;
-      case 1: wv = __float_as_uint(fy); break;
-      case 2: wv = __float_as_uint(P.kp_size[level]); break;
-      case 3: wv = __float_as_uint(angle); break;
-      case 4: wv = __float_as_uint((float)score); break;
-      case 5: wv = (uint32_t)level; break;
-      default: wv = 0xFFFFFFFFu; break;
-    }
-    reinterpret_cast<uint32_t*>(P.out_kps + (size_t)img * P.cap + out)[lane] = wv;
-  }
-}
 
 // ---- orientation + description, eight keypoints per wave ------------------------------------------------------------------
 // The per-keypoint work has two kinds of instructions: cooperative ones (patch staging, the 749-pixel moment sums, the 256
 // rotated comparisons) and wave-uniform ones (level bookkeeping, fastAtan2, the double-precision sin / cos: ~130 of the ~380
-// instructions of orient_describe_kernel, each of them computing ONE value on 64 lanes).  Here a wave takes eight consecutive
+// instructions of a wave-per-keypoint kernel, each of them computing ONE value on 64 lanes).  Here a wave takes eight consecutive
 // keypoint slots: phase 1 stages each raw 31 x 31 patch and leaves the keypoint's moments in lane k; phase 2 evaluates
 // fastAtan2 / sinf / cosf once, lane k for keypoint k; phase 3 stages each blurred 37 x 37 patch and samples the pattern with
 // (a, b) read from lane k.  The moments use v_dot4_u32_u8: a lane owns four (row, 4-column) items of the disc, the per-item
@@ -1760,7 +1362,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int bx = blockIdx.x, img = blockIdx.y;
-  if (P.xcd_images) {   // whole images per XCD, see orient_describe_kernel
+  if (P.xcd_images) {   // whole images per XCD (XCD k takes images k, k + 8, ...): the planes one image's patches are gathered from stay in one L2
     const unsigned gx = gridDim.x;
     const unsigned lin = blockIdx.y * gx + blockIdx.x;
     const unsigned grp = lin / (8u * gx);
@@ -1976,28 +1578,13 @@ void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* d
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, int mode, hipStream_t s) {
   dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
-  static int variant = -1;
-  if (variant < 0) {
-    const char* ev = getenv("ORBFE_RESIZE_VARIANT");   // experiment knob: 1 = byte gathers from LDS, default 2 = perm + dot2
-    variant = ev ? atoi(ev) : 2;
-  }
-  if (mode == 2 && variant == 2) {
-    static int trows = -1, wgs = -1;
-    if (trows < 0) {
-      const char* ev = getenv("ORBFE_RESIZE_TROWS");   // experiment knobs
-      trows = ev ? atoi(ev) : 32;
-      ev = getenv("ORBFE_RESIZE_WGS");
-      wgs = ev ? atoi(ev) : 6;
-    }
-    const int tiles_x = (dw + 255) / 256, tiles_y = (dh + trows - 1) / trows;
+  if (mode == 2) {   // scale <= 2 and taps within 8 source bytes: persistent workgroups, perm + dot2 interpolation
+    const int wgs = 6;   // workgroups per CU
+    const int tiles_x = (dw + 255) / 256, tiles_y = (dh + 31) / 32;
     const int n_tiles = tiles_x * tiles_y * n_images;
     const int nb = n_tiles < 256 * wgs ? n_tiles : 256 * wgs;
-    if (trows == 32)
-      hipLaunchKernelGGL((pyr_resize_dot_kernel<32, 42>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg, dst,
-                         dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
-    else
-      hipLaunchKernelGGL((pyr_resize_dot_kernel<16, RS2_ROWS>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg,
-                         dst, dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
+    hipLaunchKernelGGL((pyr_resize_dot_kernel<32, 42>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg, dst,
+                       dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
   }
   else if (mode >= 1)
     hipLaunchKernelGGL(pyr_resize_lds16_kernel, dim3((dw + 255) / 256, (dh + 15) / 16, n_images), block, 0, s, src, spitch,
@@ -2007,31 +1594,11 @@ void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* d
                        (unsigned long long)dimg, dw, dh, xt, yt);
 }
 
-void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
-                              int total_cells, int tile_rows, int clist_cap, int cell_rows, int cell_span, int sc_max,
-                              int bits_max, int32_t* cell_cnt, uint32_t* slots, unsigned long long slots_per_image,
-                              int ini_th, int min_th, int n_images, hipStream_t s) {
+void orbfe_launch_fast_cells(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups, int total_cells,
+                             int cell_rows, int cell_span, int sc_max, int bits_max, int32_t* cell_cnt, uint32_t* slots,
+                             unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s) {
   if (n_groups == 0) return;
-  static int run_shift = -2, variant = -1;
-  if (run_shift == -2) {
-    const char* ev = getenv("ORBFE_XCD_RUN_SHIFT");  // experiment knob: -1 = plain blockIdx order, k >= 0 = runs of 2^k workgroups per XCD
-    run_shift = ev ? atoi(ev) : -2;                  // -2 (wave-per-cell kernel): whole images per XCD -- same time, 30 % less fabric traffic
-    const char* vv = getenv("ORBFE_FAST_VARIANT");   // A/B knob: 1 = workgroup per run of cells (byte tile, min/max quick test),
-    variant = vv ? atoi(vv) : 2;                     //          2 = wave per cell (default)
-  }
-  if (variant == 1) {
-    dim3 block(FG_THREADS), grid(n_groups, n_images);
-    const size_t lds = (size_t)2 * tile_rows * ORBFE_FG_PITCH + (size_t)ORBFE_FG_MAX * 256 * 4 + (size_t)clist_cap * 2;
-    static size_t lds_allowed = 48 * 1024;
-    if (lds > lds_allowed) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(fast_groups_kernel, grid, block, lds, s, pyr, cells, groups, n_groups, total_cells, tile_rows,
-                       clist_cap, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift == -2 ? 2 : run_shift);
-    return;
-  }
+  const int run_shift = -2;   // whole images per XCD (-1: plain blockIdx order, k >= 0: runs of 2^k workgroups per XCD)
   // wave per run of cells: per-wave LDS slice = byte tile + score plane + bitmap + list
   const int pb = cell_span <= 64 ? 64 : 96;
   const int sc_bytes = (sc_max + 15) & ~15;
@@ -2064,21 +1631,11 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
 }
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
-  static int xcd = -1, variant = -1;
-  if (xcd < 0) {
-    const char* ev = getenv("ORBFE_DESC_XCD"); xcd = ev ? atoi(ev) : 1;               // A/B knob
-    const char* vv = getenv("ORBFE_DESC_VARIANT"); variant = vv ? atoi(vv) : 2;       // 1: wave per keypoint, 2: eight keypoints per wave
-  }
   DescribeParams pp = p;
-  pp.xcd_images = xcd;
-  if (variant == 1) {
-    dim3 block(256), grid((p.kp_per_image + 3) / 4 > 0 ? (p.kp_per_image + 3) / 4 : 1, n_images);
-    hipLaunchKernelGGL(orient_describe_kernel, grid, block, 0, s, pp);
-  } else {
-    const int per_block = 4 * OD_K;
-    dim3 block(256), grid((p.kp_per_image + per_block - 1) / per_block > 0 ? (p.kp_per_image + per_block - 1) / per_block : 1, n_images);
-    hipLaunchKernelGGL(orient_describe8_kernel, grid, block, 0, s, pp);
-  }
+  pp.xcd_images = 1;
+  const int per_block = 4 * OD_K;
+  dim3 block(256), grid((p.kp_per_image + per_block - 1) / per_block > 0 ? (p.kp_per_image + per_block - 1) / per_block : 1, n_images);
+  hipLaunchKernelGGL(orient_describe8_kernel, grid, block, 0, s, pp);
 }
 
 int orbfe_upload_pattern_floats() {

@@ -73,8 +73,6 @@ struct orbfe_extractor {
   orbfe_params prm{};
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // the blur runs here, concurrently with FAST + quadtree (it only needs the pyramid)
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
   // constructor tables
   float scale[ORBFE_MAX_LEVELS]{}, inv_scale[ORBFE_MAX_LEVELS]{}, sigma2[ORBFE_MAX_LEVELS]{}, inv_sigma2[ORBFE_MAX_LEVELS]{};
   int feat_per_level[ORBFE_MAX_LEVELS]{};
@@ -83,7 +81,6 @@ struct orbfe_extractor {
   LevelGeom lg[ORBFE_MAX_LEVELS]{};
   std::vector<CellDesc> cells;
   std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
-  int fg_tile_rows = 0, fg_clist_cap = 0;
   int fc_rows = 0, fc_span = 0, fc_sc = 0, fc_bits = 0;   // wave-per-cell FAST: largest cell ROI rows, (x0 & 15) + 1 + cols, score plane bytes
   std::vector<BlurTile> tiles;
   OctLevel oct[ORBFE_MAX_LEVELS]{};
@@ -106,7 +103,6 @@ struct orbfe_extractor {
   int out_cap = 0;
   int last_images = 0;
   // profiling
-  bool overlap_blur = false;  // measured: FAST and the blur are both issue-bound, running them concurrently is 2 % slower
   bool profile = false;
   unsigned profile_mask = ~0u;  // bit s: stage s is timed
   float stage_ms[ORBFE_STAGE_COUNT]{};
@@ -206,15 +202,8 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   // FAST cells and octree levels
   e->cells.clear();
   e->groups.clear();
-  e->fg_tile_rows = 0;
-  e->fg_clist_cap = 0;
   e->fc_rows = e->fc_span = e->fc_sc = e->fc_bits = 0;
   e->tiles.clear();
-  static int fg_max = -1;
-  if (fg_max < 0) {
-    const char* ev = getenv("ORBFE_FAST_GROUP");  // experiment knob: cells per workgroup (1..4)
-    fg_max = ev ? std::min(std::max(atoi(ev), 1), ORBFE_FG_MAX) : ORBFE_FG_MAX;
-  }
   size_t slot_off = 0, key_off = 0;
   int kp_off = 0, maxM = 0;
   for (int l = 0; l < nl; l++) {
@@ -272,7 +261,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
         // split this cell row into runs of <= G cells of near-equal length (cells of a row are contiguous: only
         // trailing ones are ever skipped)
         const int n_row = (int)(e->cells.size() - row_first);
-        const int G = std::max(1, std::min(fg_max, (ORBFE_FG_MAX_WIDTH - 6) / wCell));
+        const int G = std::max(1, std::min(ORBFE_FG_MAX, (ORBFE_FG_MAX_WIDTH - 6) / wCell));
         const int n_grp = (n_row + G - 1) / G;
         int done = 0;
         for (int k = 0; k < n_grp; k++) {
@@ -285,8 +274,6 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
           fg.x0 = a.x0; fg.y0 = a.y0; fg.width = (int16_t)(b.x0 + b.cols - a.x0); fg.rows = a.rows;
           fg.wcell = (int16_t)wCell; fg.pad = 0;
           e->groups.push_back(fg);
-          e->fg_tile_rows = std::max(e->fg_tile_rows, (int)fg.rows);
-          e->fg_clist_cap = std::max(e->fg_clist_cap, std::max(fg.width - 6, 0) * std::max(fg.rows - 6, 0));
           done += cnt;
         }
       }
@@ -491,29 +478,13 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
                           pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
                           (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_mode[l], s);
   }
-  // fork: the blur depends only on the pyramid, so it runs on the handle's second stream while FAST and the
-  // quadtree (VALU / latency bound) occupy the first; join before the descriptors
-  const bool fork = e->overlap_blur;
-  hipStream_t sb = fork ? e->stream2 : s;
-  if (fork) {
-    (void)hipEventRecord(e->ev_pyr, s);
-    (void)hipStreamWaitEvent(sb, e->ev_pyr, 0);
-  }
-  {
-    StageTimer t(e, sb, ORBFE_STAGE_BLUR);
-    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), n_images, sb);
-  }
-  if (fork) (void)hipEventRecord(e->ev_blur, sb);
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
-    static const bool wave_per_cell = !(getenv("ORBFE_FAST_VARIANT") && atoi(getenv("ORBFE_FAST_VARIANT")) == 1);   // the A/B kernel needs real groups
-    const bool few = wave_per_cell && n_images <= 8;   // 8 x 1220 cells = 9.8 k waves: ~1.4 rounds of the chip's resident waves
-    orbfe_launch_fast_groups(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)(few ? e->d_groups1.p : e->d_groups.p),
-                             few ? e->total_cells : (int)e->groups.size(),
-                             e->total_cells, e->fg_tile_rows, e->fg_clist_cap, e->fc_rows, e->fc_span, e->fc_sc, e->fc_bits,
-                             (int32_t*)e->d_cell_cnt.p,
-                             (uint32_t*)e->d_slots.p, e->slots_per_image, e->prm.ini_th_fast, e->prm.min_th_fast,
-                             n_images, s);
+    const bool few = n_images <= 8;   // one cell per wave: 8 x 1220 cells = 9.8 k waves, ~1.4 rounds of the chip's resident waves
+    orbfe_launch_fast_cells(pv, (const CellDesc*)e->d_cells.p, (const FastGroup*)(few ? e->d_groups1.p : e->d_groups.p),
+                            few ? e->total_cells : (int)e->groups.size(), e->total_cells, e->fc_rows, e->fc_span, e->fc_sc,
+                            e->fc_bits, (int32_t*)e->d_cell_cnt.p, (uint32_t*)e->d_slots.p, e->slots_per_image,
+                            e->prm.ini_th_fast, e->prm.min_th_fast, n_images, s);
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_OCTREE);
@@ -537,7 +508,10 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     op.lds_keys = e->lds_keys;
     orbfe_launch_octree(op, n_images, e->oct_lds, s);
   }
-  if (fork) (void)hipStreamWaitEvent(s, e->ev_blur, 0);
+  {
+    StageTimer t(e, s, ORBFE_STAGE_BLUR);
+    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), n_images, s);
+  }
   {
     StageTimer t(e, s, ORBFE_STAGE_DESCRIBE);
     DescribeParams dp;
@@ -616,15 +590,11 @@ extern "C" int orbfe_extractor_create(const orbfe_params* p, int device, orbfe_e
   }
   e->feat_per_level[p->n_levels - 1] = std::max(p->n_features - sum, 0);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming);
-  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming);
   if (he != hipSuccess) {
     orbfe_set_error("hipStreamCreate: %s", hipGetErrorString(he));
     delete e;
     return ORBFE_ERR_HIP;
   }
-  if (const char* ev = getenv("ORBFE_OVERLAP_BLUR")) e->overlap_blur = atoi(ev) != 0;  // experiment knob
   {  // per-device constant: the sampling pattern as floats (the device symbol lives once per device / code object)
     const int prc = orbfe_upload_pattern_floats();
     if (prc != 0) {
@@ -651,9 +621,6 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   if (e->h_out) (void)hipHostFree(e->h_out);
   for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { dev_free(e->d_xt[l]); dev_free(e->d_yt[l]); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
-  if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
-  if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
-  if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
   delete e;
   return ORBFE_OK;
 }
@@ -781,8 +748,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
   // reads the pinned staging buffer over PCIe itself and the descriptor kernel writes keypoints, descriptors and counts
   // straight into pinned host memory (hipHostMalloc memory is device-addressable); each memcpy on the stream costs a launch
   // and a dependency gap (~10 us) that a 120 KB result does not repay.  Larger batches keep the DMA copies.
-  static const bool zero_copy_ok = !(getenv("ORBFE_ZERO_COPY") && atoi(getenv("ORBFE_ZERO_COPY")) == 0);   // A/B knob
-  const bool zc = zero_copy_ok && n_images <= 2;
+  const bool zc = n_images <= 2;
   uint8_t* ho = (uint8_t*)e->h_out;
   if (!zc) HIPCHK(hipMemcpyAsync(e->d_in_stage.p, e->h_in, img_bytes * B, hipMemcpyHostToDevice, s));
   {

@@ -67,11 +67,13 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
   }
   int cap = 0;
   orbfe_extractor_max_keypoints(mpImpl, image.cols, image.rows, &cap);
-  std::vector<orbfe_keypoint> kps((size_t)cap);
-  std::vector<uint8_t> desc((size_t)cap * 32);
+  // staging owned by the object and reused across calls (one caller thread per extractor, as in the reference)
+  if (mvStageKeys.size() < (size_t)cap * sizeof(orbfe_keypoint)) mvStageKeys.resize((size_t)cap * sizeof(orbfe_keypoint));
+  if (mvStageDesc.size() < (size_t)cap * 32) mvStageDesc.resize((size_t)cap * 32);
+  orbfe_keypoint* kps = reinterpret_cast<orbfe_keypoint*>(mvStageKeys.data());
+  uint8_t* desc = mvStageDesc.data();
   int n = 0;
-  const int rc = orbfe_extract(mpImpl, image.ptr(0), image.cols, image.rows, (int)image.step, kps.data(), desc.data(),
-                               cap, &n);
+  const int rc = orbfe_extract(mpImpl, image.ptr(0), image.cols, image.rows, (int)image.step, kps, desc, cap, &n);
   if (rc != ORBFE_OK) {
     fprintf(stderr, "ORBextractor: orbfe_extract failed (%d): %s\n", rc, orbfe_last_error());
     n = 0;
@@ -82,10 +84,11 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
   } else {
     _descriptors.create(n, 32, CV_8U);
     cv::Mat d = _descriptors.getMat();
-    for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+    if (d.isContinuous()) memcpy(d.ptr(0), desc, (size_t)n * 32);
+    else for (int i = 0; i < n; i++) memcpy(d.ptr(i), desc + (size_t)i * 32, 32);
     _keypoints.resize((size_t)n);
     static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
-    memcpy((void*)_keypoints.data(), kps.data(), sizeof(orbfe_keypoint) * (size_t)n);
+    memcpy((void*)_keypoints.data(), kps, sizeof(orbfe_keypoint) * (size_t)n);
   }
   if (mbDownloadPyramid && rc == ORBFE_OK) {
     std::vector<uint8_t*> dst((size_t)nlevels, nullptr);

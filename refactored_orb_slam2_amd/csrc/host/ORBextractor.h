@@ -76,6 +76,7 @@ class ORBextractor {
   orbfe_extractor* mpImpl;
   bool mbDownloadPyramid;
   std::vector<cv::Mat> mvPadded;  // owners of the bordered level buffers
+  std::vector<unsigned char> mvStageKeys, mvStageDesc;  // results of the last call before they are cut to size
 };
 
 }  // namespace ORB_SLAM2

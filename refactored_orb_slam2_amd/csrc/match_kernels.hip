@@ -11,6 +11,8 @@
 //
 // Compiled with -ffp-contract=off: every float expression is evaluated un-fused, as the reference does.
 #include <string.h>
+#include <mutex>
+
 #include "match_internal.h"
 
 #define WAVE 64
@@ -1264,12 +1266,12 @@ void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const o
                                int32_t* assigned, int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames,
                                hipStream_t s) {
   const size_t dyn = (size_t)(((f.cap + 15) & ~15) + 8 * (size_t)f.cap);
-  static size_t dyn_allowed = 0;  // this kernel's static LDS alone is ~69 KiB: always raise the limit
-  if (dyn > dyn_allowed) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_resolve_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024);
-    dyn_allowed = 88 * 1024;
-  }
+  // this kernel's static LDS alone is ~69 KiB: the limit is raised once per process, whichever thread launches first
+  static std::once_flag raised;
+  std::call_once(raised, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              88 * 1024);
+  });
   hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, th_high,
                      nnratio, check_ori, blocked, assigned, n_matches, push_idx, push_bin);
 }

@@ -36,11 +36,9 @@ struct CellDesc {
   uint32_t slot_off;   // offset (entries) of this cell's slot inside one image's slot block
 };
 
-// A run of horizontally adjacent FAST cells of one cell row, processed by one workgroup (shared ROI staging, one pass of
-// the per-pixel work; NMS, the two-threshold rule and the emission stay per cell)
-#define ORBFE_FG_MAX 4           // cells per group
-#define ORBFE_FG_PITCH 192       // LDS row pitch of a group's ROI (12 x 16 B): (x0 & 15) + width <= 192
-#define ORBFE_FG_MAX_WIDTH 176   // 192 - 15 - 1
+// A run of horizontally adjacent FAST cells of one cell row: one wave of fast_cells_kernel walks them one after the other
+#define ORBFE_FG_MAX 4           // cells per run
+#define ORBFE_FG_MAX_WIDTH 176   // pixels a run may span
 struct FastGroup {
   int32_t first_cell;            // index into the cell table; the group's cells are consecutive there
   int16_t n_cells, level;
@@ -92,7 +90,7 @@ struct DescribeParams {
   uint8_t* out_desc;
   int32_t* out_n;
   int cap;
-  int xcd_images;   // 1: XCD k works on images k, k+8, ... (see orient_describe_kernel)
+  int xcd_images;   // 1: XCD k works on images k, k+8, ...
 };
 
 struct BlurTile {
@@ -103,10 +101,9 @@ struct BlurTile {
 // launchers (extract_kernels.hip)
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, int mode, hipStream_t s);   // mode: 0 direct gathers, 1 LDS-staged, 2 LDS-staged + 8-byte windows
-void orbfe_launch_fast_groups(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups,
-                              int total_cells, int tile_rows, int clist_cap, int cell_rows, int cell_span,
-                              int sc_max, int bits_max, int32_t* cell_cnt, uint32_t* slots, unsigned long long slots_per_image,
-                              int ini_th, int min_th, int n_images, hipStream_t s);
+void orbfe_launch_fast_cells(const PyrView& pyr, const CellDesc* cells, const FastGroup* groups, int n_groups, int total_cells,
+                             int cell_rows, int cell_span, int sc_max, int bits_max, int32_t* cell_cnt, uint32_t* slots,
+                             unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
 void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
                        hipStream_t s);
