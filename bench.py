@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--e2e-steps", type=int, default=12, help="steps of the PCIe-inclusive measurement (0 = skip)")
     ap.add_argument("--per-frame", type=int, default=24, help="stereo pairs pushed one at a time through the C++ drop-in classes for per_frame_ms (0 = skip)")
+    ap.add_argument("--gather", choices=("all", "root"), default="all",
+                    help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
                     help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
     args = ap.parse_args()
@@ -298,7 +300,7 @@ def main():
     import torch.distributed as dist
     from refactored_orb_slam2_amd import ORBextractor, synth
     from refactored_orb_slam2_amd.matcher import Matcher, track_queries_batch, unproject_stereo_batch
-    from refactored_orb_slam2_amd.sharding import AsyncGather
+    from refactored_orb_slam2_amd.sharding import AsyncGather, gather_traffic
 
     cfg = CONFIGS[args.config]
     W, H, NFEAT, STEREO = cfg["w"], cfg["h"], cfg["nfeat"], cfg["stereo"]
@@ -407,7 +409,7 @@ def main():
         with torch.cuda.stream(sM):
             _step(sM, B0)
 
-    gatherer = AsyncGather(B0.nl, B0.kl, B0.dl) if world > 1 else None
+    gatherer = AsyncGather(B0.nl, B0.kl, B0.dl, mode=args.gather) if world > 1 else None
 
     def barrier():
         if gatherer is not None:
@@ -455,10 +457,25 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    rank_rates, coll_ms = None, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own clock (the straggler shows), the MAX over ranks is the job's time
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_rates = [round(F * args.steps / float(x.item()), 1) for x in every]
+        dt = max(float(x.item()) for x in every)
+        # the collective on its own (not overlapped with a step): HIP events around three blocking gathers
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(sM):
+            gatherer.launch(B0.nl, B0.kl, B0.dl); gatherer.wait()
+            torch.cuda.synchronize(); dist.barrier()
+            ev0.record(sM)
+            for _ in range(3):
+                gatherer.launch(B0.nl, B0.kl, B0.dl); gatherer.wait()
+            ev1.record(sM)
+        torch.cuda.synchronize()
+        coll_ms = ev0.elapsed_time(ev1) / 3
     st_dom = stage_sums()[dom]
     for e in extractors:
         e.profile(False)
@@ -537,7 +554,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": cfg["label"], "name": args.config, "frames_per_gpu_per_step": F,
                        "images_per_step": n_img * world, "parallelism": f"frame-shard x{world}",
-                       "collective": (f"{backend} all_gather of padded per-frame records, world size {dist.get_world_size()}" if world > 1 else "none"),
+                       "collective": (f"{backend} {'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {dist.get_world_size()}" if world > 1 else "none"),
                        "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
                        "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -545,6 +562,10 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
+        if world > 1:
+            out["config"]["gather"] = dict(gather_traffic(B0.nl, B0.kl, B0.dl, world, args.gather), standalone_ms_rank0=round(coll_ms, 4),
+                                           note="per step, overlapped with the next step's kernels; standalone_ms = the same collective alone, HIP events on rank 0")
+            out["config"]["frames_per_s_by_rank"] = rank_rates
         if e2e is not None:
             out["e2e_frames_per_s"] = round(e2e, 1)
             out["e2e_note"] = "pinned host images -> H2D -> step -> D2H of keypoints, descriptors, counts, matches (and mvuRight / mvDepth), double-buffered"
@@ -557,11 +578,13 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         # the gathered records of the last step == every rank's own records at its slot (the collective moved the right bytes)
-        n_all, k_all, d_all = gatherer.result()
-        mine = slice(rank * F, (rank + 1) * F)
-        ok = bool((n_all[mine].to(B0.nl.device) == B0.nl).all()) and bool((d_all[mine].to(B0.dl.device) == B0.dl).all())
-        if not ok:
-            raise SystemExit(f"rank {rank}: gathered records differ from the local ones")
+        res = gatherer.result()
+        if res is not None:   # mode "root": rank 0 alone holds the records; it checks its own slot
+            n_all, k_all, d_all = res
+            mine = slice(rank * F, (rank + 1) * F)
+            ok = bool((n_all[mine].to(B0.nl.device) == B0.nl).all()) and bool((d_all[mine].to(B0.dl.device) == B0.dl).all())
+            if not ok:
+                raise SystemExit(f"rank {rank}: gathered records differ from the local ones")
         dist.barrier()
         dist.destroy_process_group()
 

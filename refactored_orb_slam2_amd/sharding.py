@@ -1,5 +1,7 @@
 """Batched-sequence mode: independent frames are sharded over ranks (one process per GPU) and the per-frame
-keypoint records are gathered with one collective (RCCL all_gather on GPUs, gloo in the CPU tests).
+keypoint records are gathered with one collective per tensor (RCCL on GPUs, gloo in the CPU tests): `mode="all"` is an
+all_gather (every rank ends up with every frame's records), `mode="root"` a gather to rank 0 (the consumer of
+the records is one process; N - 1 sends of one rank's records instead of N x (N - 1)).
 
 The reference processes frames strictly sequentially in one process (Source/Examples/Stereo/stereo_kitti.cc:
 36-150); extraction carries no state between frames, so contiguous chunks of the frame range are independent
@@ -22,23 +24,43 @@ def padded_chunk(n_frames: int, world: int) -> int:
     return (n_frames + world - 1) // world
 
 
+def record_bytes(n, kps, desc) -> int:
+    """Bytes of one rank's padded records {n[F]; kps[F, cap, 28]; desc[F, cap, 32]}."""
+    return sum(int(t.numel()) * t.element_size() for t in (n, kps, desc))
+
+
+def gather_traffic(n, kps, desc, world: int, mode: str = "all") -> dict:
+    """Bytes a rank sends / receives per gather (payload, not the ring's forwarding): the figures bench.py prints."""
+    b = record_bytes(n, kps, desc)
+    if mode == "root":
+        return {"mode": "root", "record_bytes_per_rank": b, "sent_per_rank": b, "received_rank0": (world - 1) * b, "received_other_ranks": 0}
+    return {"mode": "all", "record_bytes_per_rank": b, "sent_per_rank": b, "received_per_rank": (world - 1) * b}
+
+
 class AsyncGather:
     """Overlaps the record gather of step k with the compute of step k+1: the step's outputs are snapshotted
     (device-to-device copy on the compute stream), the collectives run asynchronously on the process group's
-    stream, and the previous gather is waited for only when its buffers are about to be reused."""
+    stream, and the previous gather is waited for only when its buffers are about to be reused.
+    mode "all": all_gather_into_tensor; mode "root": gather to rank 0 (the other ranks hold no output)."""
 
-    def __init__(self, n, kps, desc, group=None):
+    def __init__(self, n, kps, desc, group=None, mode: str = "all"):
         import torch
         import torch.distributed as dist
+        if mode not in ("all", "root"):
+            raise ValueError("mode must be 'all' or 'root'")
         self.group = group
+        self.mode = mode
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         # RCCL moves device tensors; the gloo rehearsal path (CPU tests, several ranks on one GPU -- RCCL refuses two ranks
         # per device) stages the records through host memory
         self.on_host = dist.get_backend(group) != "nccl" and n.is_cuda
         dev = "cpu" if self.on_host else n.device
         self.snap = [torch.empty_like(t, device=dev) for t in (n, kps, desc)]
-        self.out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-                    for t in (n, kps, desc)]
+        self.out = None
+        if mode == "all" or self.rank == 0:
+            self.out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                        for t in (n, kps, desc)]
         self.pending = []
 
     def wait(self):
@@ -54,35 +76,49 @@ class AsyncGather:
             s.copy_(t, non_blocking=not self.on_host)
         if self.on_host:
             torch.cuda.current_stream().synchronize()
-        self.pending = [dist.all_gather_into_tensor(o, s, group=self.group, async_op=True)
-                        for o, s in zip(self.out, self.snap)]
+        if self.mode == "all":
+            self.pending = [dist.all_gather_into_tensor(o, s, group=self.group, async_op=True)
+                            for o, s in zip(self.out, self.snap)]
+        else:
+            dst = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            self.pending = [dist.gather(s, list(o.chunk(self.world)) if self.rank == 0 else None, dst=dst, group=self.group, async_op=True)
+                            for o, s in zip(self.out or [None] * 3, self.snap)]
 
     def result(self):
+        """(n_all, kps_all, desc_all) in rank order; None on the ranks that hold no output (mode "root", rank > 0)."""
         self.wait()
-        return tuple(self.out)
+        return tuple(self.out) if self.out is not None else None
 
 
-def gather_records(n, kps, desc, group=None):
-    """all_gather of fixed-size padded per-frame records {n[f]; kps[f, cap, 28]; desc[f, cap, 32]}.
+def gather_records(n, kps, desc, group=None, mode: str = "all"):
+    """Gather of fixed-size padded per-frame records {n[f]; kps[f, cap, 28]; desc[f, cap, 32]}.
 
     n: int32 (F,), kps: uint8 (F, cap, 28), desc: uint8 (F, cap, 32) -- F identical on every rank.
     Returns (n_all (world*F,), kps_all (world*F, cap, 28), desc_all (world*F, cap, 32)) in rank order, i.e.
-    in global frame order for contiguous shards.  With world size 1 (or no process group) it is the identity.
+    in global frame order for contiguous shards; with mode "root" only rank 0 gets them, the others None.
+    With world size 1 (or no process group) it is the identity.
     """
     import torch
     import torch.distributed as dist
 
+    if mode not in ("all", "root"):
+        raise ValueError("mode must be 'all' or 'root'")
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return n, kps, desc
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     on_host = dist.get_backend(group) != "nccl" and n.is_cuda   # gloo rehearsal: records go through host memory
     out = []
     for t in (n, kps, desc):
         t = t.contiguous().cpu() if on_host else t.contiguous()
-        g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(g, t, group=group)  # concatenation along dim 0, rank order
+        if mode == "all":
+            g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(g, t, group=group)  # concatenation along dim 0, rank order
+        else:
+            g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) if rank == 0 else None
+            dst = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.gather(t, list(g.chunk(world)) if rank == 0 else None, dst=dst, group=group)
         out.append(g)
-    return tuple(out)
+    return tuple(out) if (mode == "all" or rank == 0) else None
 
 
 def unpack_records(n_all, kps_all, desc_all, n_frames: int):

@@ -243,15 +243,16 @@ def test_rccl_gather_self_check_world1():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        ag = sharding.AsyncGather(n, kps, desc)       # the overlapped variant bench.py uses: really runs the collective
-        ag.launch(n, kps, desc)
-        n_all, k_all, d_all = ag.result()
-        torch.cuda.synchronize()
-        frames = sharding.unpack_records(n_all, k_all, d_all, F)
-        assert len(frames) == F
-        for (k, d), (k0, d0) in zip(frames, single):
-            np.testing.assert_array_equal(k, k0)
-            np.testing.assert_array_equal(d, d0)
+        for mode in ("all", "root"):                        # all_gather_into_tensor, and gather to rank 0 (ncclSend / Recv group)
+            ag = sharding.AsyncGather(n, kps, desc, mode=mode)   # the overlapped variant bench.py uses: really runs the collective
+            ag.launch(n, kps, desc)
+            n_all, k_all, d_all = ag.result()
+            torch.cuda.synchronize()
+            frames = sharding.unpack_records(n_all, k_all, d_all, F)
+            assert len(frames) == F
+            for (k, d), (k0, d0) in zip(frames, single):
+                np.testing.assert_array_equal(k, k0)
+                np.testing.assert_array_equal(d, d0)
     finally:
         dist.destroy_process_group()
     ex.close()
@@ -268,10 +269,14 @@ def test_bench_spawns_its_ranks_and_checks_the_gather():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ORBFE_BENCH_SHARE_DEVICE="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--frames", "8", "--cpu-sample", "0",
-                        "--e2e-steps", "0"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "frame-shard x2" and out["value"] > 0
-    assert "all_gather" in out["config"]["collective"]
+    for mode, name in (("all", "all_gather"), ("root", "gather to rank 0")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--frames", "8", "--cpu-sample", "0",
+                            "--e2e-steps", "0", "--gather", mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "frame-shard x2" and out["value"] > 0
+        assert name in out["config"]["collective"]
+        g = out["config"]["gather"]
+        assert g["mode"] == mode and g["record_bytes_per_rank"] > 8 * 2000 * 60 and g["standalone_ms_rank0"] > 0
+        assert len(out["config"]["frames_per_s_by_rank"]) == 2 and min(out["config"]["frames_per_s_by_rank"]) > 0

@@ -120,6 +120,20 @@ def _gather_worker(rank, world, port, n_frames, cap, tmp):
                 assert bool((k_all[g, :c] == f % 251).all()) and bool((d_all[g, :c] == (f * 3) % 253).all())
             for i in range(re_ - rb, chunk):
                 assert int(n_all[r * chunk + i]) == 0
+        # gather to the root (ncclSend / Recv to rank 0): rank 0 holds the same records, the others nothing
+        root = sharding.gather_records(n, kps, desc, mode="root")
+        ag = sharding.AsyncGather(n, kps, desc, mode="root")
+        for _ in range(2):
+            ag.launch(n, kps, desc)
+        a_root = ag.result()
+        if rank == 0:
+            for got in (root, a_root):
+                assert torch.equal(got[0], n_all) and torch.equal(got[1], k_all) and torch.equal(got[2], d_all)
+        else:
+            assert root is None and a_root is None
+        tr_all, tr_root = sharding.gather_traffic(n, kps, desc, world, "all"), sharding.gather_traffic(n, kps, desc, world, "root")
+        assert tr_all["received_per_rank"] == (world - 1) * tr_all["record_bytes_per_rank"] == tr_root["received_rank0"]
+        assert tr_all["record_bytes_per_rank"] == chunk * (4 + cap * 60)
         dist.barrier()
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
