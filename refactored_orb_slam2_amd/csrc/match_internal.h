@@ -52,11 +52,13 @@ struct StereoParams {
   int32_t* sad;        // scratch [n_pairs][cap]
   int32_t* n_matched;  // [n_pairs]
   // row buckets of the right keypoints (bucket b = image rows [8b, 8b+8)): CSR per pair
-  int32_t* bucket_start;  // [n_pairs][STEREO_MAX_BUCKETS + 1]
+  int32_t* bucket_start;  // [n_pairs][n_keys + 1], key = (row / 8) * n_levels + octave
   int32_t* bucket_idx;    // [n_pairs][cap * STEREO_BUCKET_SPAN]
-  int n_buckets;
+  int n_buckets;          // row buckets
+  int n_levels, n_keys;   // n_keys = n_buckets * n_levels
 };
 #define STEREO_MAX_BUCKETS 512      // rows / 8, rows <= 4095
+#define STEREO_MAX_KEYS 8192        // (row bucket, octave) keys: 512 x 16; the bucket kernel's LDS holds two ints per key
 #define STEREO_BUCKET_SPAN 8        // a band [y-r, y+r], r = 2*scale <= ~25 rows, overlaps at most this many buckets
 
 struct BowPair { int32_t startA, countA, startB, countB; };

@@ -917,38 +917,55 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameBatch F, QueryBat
 // (L/src/Frame.cc:493-502,536-553): the (distance, index) lexicographic minimum reproduces that first-wins
 // rule whatever order the candidates are visited in.
 __global__ __launch_bounds__(256) void stereo_bucket_kernel(StereoParams P) {
-  __shared__ int cnt[STEREO_MAX_BUCKETS];
-  __shared__ int start[STEREO_MAX_BUCKETS + 1];
+  // keys = (row bucket, octave), row-bucket major: the entries a left keypoint of level l may match -- octaves l - 1 .. l + 1
+  // of its row bucket -- are ONE contiguous run of the CSR array, a third as long as the whole row bucket (39 entries on
+  // average at KITTI geometry instead of 104: one 64-lane chunk for 97 % of the left keypoints instead of two to four)
+  extern __shared__ int sb_lds[];
+  int* cnt = sb_lds;                 // [n_keys]
+  int* start = sb_lds + P.n_keys;    // [n_keys + 1]
+  __shared__ int part[256];
   const int pair = blockIdx.x, tid = threadIdx.x;
   const int nR = P.nR[pair];
-  const int nb = P.n_buckets;
+  const int nb = P.n_buckets, nl = P.n_levels, nk = P.n_keys;
   const orbfe_keypoint* kr = P.kpsR + (size_t)pair * P.cap;
-  int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
+  int32_t* bs = P.bucket_start + (size_t)pair * (nk + 1);
   int4* bi = reinterpret_cast<int4*>(P.bucket_idx) + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
-  for (int b = tid; b < nb; b += 256) cnt[b] = 0;
+  for (int b = tid; b < nk; b += 256) cnt[b] = 0;
   __syncthreads();
   for (int pass = 0; pass < 2; pass++) {
     for (int iR = tid; iR < nR; iR += 256) {
       const orbfe_keypoint kp = kr[iR];
-      const float r = 2.0f * P.scale[kp.octave];
+      const int oct = min(max(kp.octave, 0), nl - 1);
+      const float r = 2.0f * P.scale[oct];
       const int maxr = (int)ceilf(kp.y + r), minr = (int)floorf(kp.y - r);
       int b0 = max(minr, 0) >> 3, b1 = min(maxr >> 3, nb - 1);
       if (b1 - b0 >= STEREO_BUCKET_SPAN) b1 = b0 + STEREO_BUCKET_SPAN - 1;  // cannot happen for scale <= 12
       for (int b = b0; b <= b1; b++) {
-        const int pos = atomicAdd(&cnt[b], 1);
-        if (pass == 1) bi[start[b] + pos] = make_int4(iR, __float_as_int(kp.x), __float_as_int(kp.y), kp.octave);
+        const int key = b * nl + oct;
+        const int pos = atomicAdd(&cnt[key], 1);
+        if (pass == 1) bi[start[key] + pos] = make_int4(iR, __float_as_int(kp.x), __float_as_int(kp.y), kp.octave);
       }
     }
     __syncthreads();
     if (pass == 0) {
+      // exclusive prefix sum over the keys: every thread sums a contiguous slice, the 256 slice totals are scanned serially
+      const int per = (nk + 255) / 256;
+      const int k0 = min(tid * per, nk), k1 = min(k0 + per, nk);
+      int sum = 0;
+      for (int k = k0; k < k1; k++) sum += cnt[k];
+      part[tid] = sum;
+      __syncthreads();
       if (tid == 0) {
         int run = 0;
-        for (int b = 0; b < nb; b++) { start[b] = run; run += cnt[b]; }
-        start[nb] = run;
+        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = run; run += v; }
+        start[nk] = run;
       }
       __syncthreads();
-      for (int b = tid; b <= nb; b += 256) bs[b] = start[b];
-      for (int b = tid; b < nb; b += 256) cnt[b] = 0;
+      int run = part[tid];
+      for (int k = k0; k < k1; k++) { start[k] = run; run += cnt[k]; }
+      __syncthreads();
+      for (int b = tid; b <= nk; b += 256) bs[b] = start[b];
+      for (int b = tid; b < nk; b += 256) cnt[b] = 0;
       __syncthreads();
     }
   }
@@ -1021,45 +1038,33 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   if (maxU < 0) return;
   unsigned best = ((unsigned)ORBFE_TH_HIGH << 16) | 0xffffu;  // bestDist starts at TH_HIGH; strict <
   float best_x = 0.f;                                         // x of this lane's best candidate
-  const int32_t* bs = P.bucket_start + (size_t)pair * (STEREO_MAX_BUCKETS + 1);
+  const int32_t* bs = P.bucket_start + (size_t)pair * (P.n_keys + 1);
   const int4* bent = reinterpret_cast<const int4*>(P.bucket_idx) + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
-  const int e0 = bs[row >> 3], e1 = bs[(row >> 3) + 1];
+  // the run of this row bucket's entries with octave levelL - 1 .. levelL + 1 (L/src/Frame.cc:538-539 keeps nothing else)
+  const int kb = (row >> 3) * P.n_levels;
+  const int e0 = bs[kb + max(levelL - 1, 0)], e1 = bs[kb + min(levelL + 1, P.n_levels - 1) + 1];
 #if FC_TIMING
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
   SM_T(0);   // own record, descriptor, bucket range
-  // two 64-entry chunks of the bucket in flight: bucket records (index, x, y, octave), then -- for the survivors of
-  // the band / level / disparity tests -- descriptors: two memory round trips for up to 128 candidates
-  for (int eb = e0; eb < e1; eb += 2 * WAVE) {
-    int4 rec[2];
-    bool ok[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int e = eb + u * WAVE + lane;
-      rec[u] = e < e1 ? bent[e] : make_int4(-1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float rx = __int_as_float(rec[u].y), ry = __int_as_float(rec[u].z);
-      const int roct = rec[u].w;
-      const float r = s_r[roct & (ORBFE_MAX_LEVELS - 1)];
-      const int maxr = (int)ceilf(ry + r), minr = (int)floorf(ry - r);
-      ok[u] = rec[u].x >= 0 && !(row < minr || row > maxr) && !(roct < levelL - 1 || roct > levelL + 1) &&
-              (rx >= minU && rx <= maxU);
-    }
-    uint4 b0[2], b1[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++)
-      if (ok[u]) load_desc(dr + (size_t)rec[u].x * 32, b0[u], b1[u]);
-#pragma unroll
-    for (int u = 0; u < 2; u++)
-      if (ok[u]) {
-        const unsigned key = ((unsigned)hamming256(a0, a1, b0[u], b1[u]) << 16) | (unsigned)rec[u].x;
-        if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) {  // (dist, index) minimum among dist < TH_HIGH
-          best = key;
-          best_x = __int_as_float(rec[u].y);
-        }
+  // 64 entries per round: bucket records (index, x, y, octave), then -- for the survivors of the band / disparity tests --
+  // their descriptors: two memory round trips, and one round for all but a few left keypoints
+  for (int eb = e0; eb < e1; eb += WAVE) {
+    const int e = eb + lane;
+    const int4 rec = e < e1 ? bent[e] : make_int4(-1, 0, 0, 0);
+    const float rx = __int_as_float(rec.y), ry = __int_as_float(rec.z);
+    const float r = s_r[rec.w & (ORBFE_MAX_LEVELS - 1)];
+    const int maxr = (int)ceilf(ry + r), minr = (int)floorf(ry - r);
+    const bool ok = rec.x >= 0 && !(row < minr || row > maxr) && (rx >= minU && rx <= maxU);
+    if (ok) {
+      uint4 b0, b1;
+      load_desc(dr + (size_t)rec.x * 32, b0, b1);
+      const unsigned key = ((unsigned)hamming256(a0, a1, b0, b1) << 16) | (unsigned)rec.x;
+      if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) {  // (dist, index) minimum among dist < TH_HIGH
+        best = key;
+        best_x = rx;
       }
+    }
   }
   SM_T(1);   // bucket records + descriptors + Hamming
   // first minimum in index order; the winning lane also holds the right keypoint's x
@@ -1299,7 +1304,15 @@ void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const o
                      check_ori, matches12, prev_xy, n_matches, push_idx, push_bin);
 }
 void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {
-  hipLaunchKernelGGL(stereo_bucket_kernel, dim3(n_pairs), dim3(256), 0, s, p);
+  const size_t bucket_lds = sizeof(int) * (size_t)(2 * p.n_keys + 1);
+  if (bucket_lds > 48 * 1024) {   // tall images with many levels only (KITTI: 3 KB)
+    static std::once_flag raised;
+    std::call_once(raised, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(int) * (2 * STEREO_MAX_KEYS + 1)));
+    });
+  }
+  hipLaunchKernelGGL(stereo_bucket_kernel, dim3(n_pairs), dim3(256), bucket_lds, s, p);
   dim3 grid((p.cap + 3) / 4, n_pairs);
   hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, p);
   hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, p);

@@ -874,12 +874,14 @@ static int stereo_enqueue(orbfe_matcher* m, orbfe_extractor* left, orbfe_extract
       return ORBFE_ERR_INVALID;
     }
   if ((rc = mb_alloc(m->sad, sizeof(int32_t) * (size_t)n_pairs * cap))) return rc;
-  if ((rc = mb_alloc(m->bucket_start, sizeof(int32_t) * (size_t)n_pairs * (STEREO_MAX_BUCKETS + 1)))) return rc;
+  p.n_buckets = (p.pyrL.h[0] + 7) / 8;
+  p.n_levels = nl;
+  p.n_keys = p.n_buckets * nl;
+  if (p.n_buckets > STEREO_MAX_BUCKETS || p.n_keys > STEREO_MAX_KEYS) return ORBFE_ERR_INVALID;
+  if ((rc = mb_alloc(m->bucket_start, sizeof(int32_t) * (size_t)n_pairs * (p.n_keys + 1)))) return rc;
   if ((rc = mb_alloc(m->bucket_idx, 16 * (size_t)n_pairs * cap * STEREO_BUCKET_SPAN))) return rc;  // int4 records
   p.bucket_start = (int32_t*)m->bucket_start.p;
   p.bucket_idx = (int32_t*)m->bucket_idx.p;
-  p.n_buckets = (p.pyrL.h[0] + 7) / 8;
-  if (p.n_buckets > STEREO_MAX_BUCKETS) return ORBFE_ERR_INVALID;
   for (int l = 0; l < nl; l++)
     if (2.0f * p.scale[l] + 2.0f > 8.0f * (STEREO_BUCKET_SPAN - 1) / 2.0f) {
       orbfe_set_error("stereo match: pyramid scale %.2f too large for the row buckets", p.scale[l]);
