@@ -75,72 +75,110 @@ __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------ brute force
-// Block = 32 A rows x 8 partitions of B.  B is staged through LDS in tiles of 256 descriptors.  Every
-// thread keeps (best dist, best j, second dist) over its partition in index order; partitions are merged with
-// the (dist, j) lexicographic minimum == the reference's strict-< first-wins scan over vIndicesF.
+// Thread = one A row, block = 256 rows of one set; every thread keeps (best (dist, j) key, second dist) of its own row, so there
+// is no cross-lane reduction and no merge: the lexicographic (dist, j) minimum IS the reference's strict-< first-wins scan over
+// vIndicesF (L/src/ORBmatcher.cc:205-222), the second-smallest distance its bestDist2, whatever order the j arrive in.
+//   plain     B streams through LDS in tiles of 256 descriptors; a wave reads one descriptor per step (same address on all lanes:
+//             an LDS broadcast) -- 8 v_xor + 8 v_bcnt (popcount with accumulate) per 64 pairs
+//   grouped   (vocabulary node ids, the SearchByBoW use): comparing a row with every j and discarding 99 % of them by the group
+//             test costs a full scan per row.  Instead the block buckets the B indices by a 10-bit hash of their group id in LDS
+//             (counting sort: histogram, scan, scatter -- 4 KB of ids per 1000 descriptors) and every row walks only the bucket
+//             of its own group (a dozen candidates at 1000 descriptors in 100 groups), testing the exact id.  B sets beyond
+//             HBF_MAX_SORT fall back to the plain scan with the group test.
+#define HBF_HASH_BITS 10
+#define HBF_BUCKETS (1 << HBF_HASH_BITS)
+#define HBF_MAX_SORT 8192
+__device__ __forceinline__ unsigned hbf_hash(int g) { return ((unsigned)g * 2654435761u) >> (32 - HBF_HASH_BITS); }
+__device__ __forceinline__ void hbf_update(unsigned& best, int& second, int d, int j) {
+  const unsigned key = ((unsigned)d << 16) | (unsigned)j;
+  if (key < best) { second = min(second, (int)(best >> 16)); best = key; }
+  else second = min(second, d);
+}
 __global__ __launch_bounds__(256) void hamming_bf_kernel(HammingBfParams P) {
-  __shared__ uint4 sb[256 * 2];
+  __shared__ __attribute__((aligned(16))) uint4 sb[256 * 2 + 1];   // plain: a tile of B; grouped: start[HBF_BUCKETS + 1] + cur[HBF_BUCKETS] (8196 bytes)
   __shared__ int sg[256];
   __shared__ uint8_t sm[256];
-  __shared__ unsigned mkey[8][32];
-  __shared__ int msec[8][32];
+  __shared__ uint16_t order[HBF_MAX_SORT];
   const int set = blockIdx.y;
   const int nA = P.nA[set], nB = P.nB[set];
-  const int a = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int part = threadIdx.x >> 5;
-  if (blockIdx.x * 32 >= nA) return;
+  if ((int)blockIdx.x * 256 >= nA) return;
+  const int a = blockIdx.x * 256 + threadIdx.x;
   const uint8_t* A = P.A + (size_t)set * P.strideA * 32;
   const uint8_t* B = P.B + (size_t)set * P.strideB * 32;
+  const int32_t* gB = P.groupB ? P.groupB + (size_t)set * P.strideB : nullptr;
+  const uint8_t* mB = P.maskB ? P.maskB + (size_t)set * P.strideB : nullptr;
   uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
   int ga = 0;
   if (a < nA) {
     load_desc(A + (size_t)a * 32, a0, a1);
     if (P.groupA) ga = P.groupA[(size_t)set * P.strideA + a];
   }
-  int bestd = 256, bestj = -1, second = 256;  // sequential best / second-best of this thread's j subsequence
-  for (int t0 = 0; t0 < nB; t0 += 256) {
+  unsigned best = 0xFFFFFFFFu;   // (256 << 16) would do; all ones also marks "none"
+  int second = 256;
+  if (gB && nB <= HBF_MAX_SORT) {
+    int* start = reinterpret_cast<int*>(sb);          // [HBF_BUCKETS + 1]
+    int* cur = start + HBF_BUCKETS + 1;               // [HBF_BUCKETS]
+    for (int i = threadIdx.x; i < HBF_BUCKETS; i += 256) cur[i] = 0;
     __syncthreads();
-    {
-      const int j = t0 + threadIdx.x;
-      if (j < nB) {
-        const uint4* q = reinterpret_cast<const uint4*>(B + (size_t)j * 32);
-        sb[2 * threadIdx.x] = q[0];
-        sb[2 * threadIdx.x + 1] = q[1];
-        sg[threadIdx.x] = P.groupB ? P.groupB[(size_t)set * P.strideB + j] : 0;
-        sm[threadIdx.x] = P.maskB ? P.maskB[(size_t)set * P.strideB + j] : 0;
+    for (int j = threadIdx.x; j < nB; j += 256)
+      if (!(mB && mB[j])) atomicAdd(&cur[hbf_hash(gB[j])], 1);
+    __syncthreads();
+    {   // exclusive scan of 1024 counts: four per thread, wave scan, wave totals through LDS
+      const int t = threadIdx.x;
+      const int c0 = cur[4 * t], c1 = cur[4 * t + 1], c2 = cur[4 * t + 2], c3 = cur[4 * t + 3];
+      const int incl = wave_incl_scan_i(c0 + c1 + c2 + c3);
+      if ((t & 63) == 63) sg[t >> 6] = incl;
+      __syncthreads();
+      int base = incl - (c0 + c1 + c2 + c3);
+      for (int w = 0; w < (t >> 6); w++) base += sg[w];
+      start[4 * t] = base; start[4 * t + 1] = base + c0; start[4 * t + 2] = base + c0 + c1; start[4 * t + 3] = base + c0 + c1 + c2;
+      if (t == 255) start[HBF_BUCKETS] = base + c0 + c1 + c2 + c3;
+      __syncthreads();
+      cur[4 * t] = 0; cur[4 * t + 1] = 0; cur[4 * t + 2] = 0; cur[4 * t + 3] = 0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nB; j += 256)
+      if (!(mB && mB[j])) {
+        const unsigned h = hbf_hash(gB[j]);
+        order[start[h] + atomicAdd(&cur[h], 1)] = (uint16_t)j;
+      }
+    __syncthreads();
+    if (a < nA) {
+      const unsigned h = hbf_hash(ga);
+      for (int e = start[h], e1 = start[h + 1]; e < e1; e++) {
+        const int j = order[e];
+        if (gB[j] != ga) continue;   // another group with the same hash
+        uint4 b0, b1;
+        load_desc(B + (size_t)j * 32, b0, b1);
+        hbf_update(best, second, hamming256(a0, a1, b0, b1), j);
       }
     }
-    __syncthreads();
-    const int cnt = min(256, nB - t0);
-    // partition p scans tile entries p*32 .. p*32+31: a thread's j sequence is increasing
-    for (int k = 0; k < 32; k++) {
-      const int jj = part * 32 + k;
-      if (jj >= cnt) break;
-      if (sm[jj]) continue;
-      if (P.groupA && sg[jj] != ga) continue;
-      const int d = hamming256(a0, a1, sb[2 * jj], sb[2 * jj + 1]);
-      if (d < bestd) { second = bestd; bestd = d; bestj = t0 + jj; }
-      else if (d < second) second = d;
+  } else {
+    for (int t0 = 0; t0 < nB; t0 += 256) {
+      __syncthreads();
+      {
+        const int j = t0 + threadIdx.x;
+        if (j < nB) {
+          const uint4* q = reinterpret_cast<const uint4*>(B + (size_t)j * 32);
+          sb[2 * threadIdx.x] = q[0];
+          sb[2 * threadIdx.x + 1] = q[1];
+          sg[threadIdx.x] = gB ? gB[j] : 0;
+          sm[threadIdx.x] = mB ? mB[j] : 0;
+        }
+      }
+      __syncthreads();
+      const int cnt = min(256, nB - t0);
+      for (int jj = 0; jj < cnt; jj++) {   // jj is wave-uniform: sb / sg / sm reads are broadcasts
+        if (sm[jj]) continue;
+        if (gB && sg[jj] != ga) continue;
+        hbf_update(best, second, hamming256(a0, a1, sb[2 * jj], sb[2 * jj + 1]), t0 + jj);
+      }
     }
   }
-  const unsigned best = bestj >= 0 ? (((unsigned)bestd << 16) | (unsigned)bestj) : 0xFFFFFFFFu;
-  mkey[part][threadIdx.x & 31] = best;
-  msec[part][threadIdx.x & 31] = second;
-  __syncthreads();
-  if (part == 0 && a < nA) {
-    // global best = lexicographic min of (dist, j); second = min over every partition's second and every
-    // partition's best except the winner's
-    unsigned b = 0xFFFFFFFFu;
-    for (int p = 0; p < 8; p++) b = min(b, mkey[p][threadIdx.x]);
-    int s = 256;
-    for (int p = 0; p < 8; p++) {
-      const unsigned k = mkey[p][threadIdx.x];
-      if (k != b && k != 0xFFFFFFFFu) s = min(s, (int)(k >> 16));
-      s = min(s, msec[p][threadIdx.x]);
-    }
+  if (a < nA) {
     orbfe_bf_match m;
-    if (b == 0xFFFFFFFFu) { m.best_idx = -1; m.best_dist = 256; m.second_dist = 256; }
-    else { m.best_idx = (int)(b & 0xffff); m.best_dist = (int)(b >> 16); m.second_dist = s; }
+    if (best == 0xFFFFFFFFu) { m.best_idx = -1; m.best_dist = 256; m.second_dist = 256; }
+    else { m.best_idx = (int)(best & 0xffff); m.best_dist = (int)(best >> 16); m.second_dist = second; }
     P.out[(size_t)set * P.strideA + a] = m;
   }
 }
@@ -1254,7 +1292,7 @@ void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int
 }
 void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, hipStream_t s) {
   if (max_nA < 1 || n_sets < 1) return;
-  dim3 grid((max_nA + 31) / 32, n_sets);
+  dim3 grid((max_nA + 255) / 256, n_sets);
   hipLaunchKernelGGL(hamming_bf_kernel, grid, dim3(256), 0, s, p);
 }
 void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {

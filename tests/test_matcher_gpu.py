@@ -71,6 +71,26 @@ def test_brute_force_best_second(nA, nB):
         assert (out[i]["best_idx"], out[i]["best_dist"], out[i]["second_dist"]) == (bi, b1, b2), i
 
 
+@pytest.mark.parametrize("nA,nB,ngroups", [(1000, 1000, 100), (600, 3000, 2500), (300, 9000, 64), (257, 700, 1)])
+def test_brute_force_grouped_by_node_id(nA, nB, ngroups):
+    """The SearchByBoW use of the brute force: vocabulary node ids as groups.  Wide id range (hash collisions inside the kernel's
+    bucket table), many more groups than buckets, a B set beyond the in-LDS sort (plain scan with the group test), one group."""
+    rng = np.random.default_rng(nA + 3 * nB + ngroups)
+    A = _rand_desc(rng, nA); B = _rand_desc(rng, nB)
+    ids = rng.integers(-2**31, 2**31 - 1, ngroups, dtype=np.int64).astype(np.int32)   # arbitrary ints, negative ones included
+    gA = ids[rng.integers(0, ngroups, nA)]; gB = ids[rng.integers(0, ngroups, nB)]
+    A[:50] = B[rng.integers(0, nB, 50)]                      # exact duplicates: ties on distance 0 across and inside groups
+    B[nB // 2] = B[3]; gB[nB // 2] = gB[3]
+    mB = (rng.random(nB) < 0.1).astype(np.uint8)
+    D = _np_dist(A, B)
+    for mask in (None, mB):
+        out = ORBmatcher.BruteForce(A, B, gA, gB, mask)
+        for i in range(nA):
+            js = [j for j in np.nonzero(gB == gA[i])[0] if mask is None or not mask[j]]
+            bi, b1, b2 = _seq_best_second(D[i], js)
+            assert (out[i]["best_idx"], out[i]["best_dist"], out[i]["second_dist"]) == (bi, b1, b2), (i, mask is None)
+
+
 def _two_frames(w, h, nfeat, with_right=False, seed=5):
     ex = ORBextractor(nfeat)
     seq = synth.sequence(w, h, 2, seq=seed)
