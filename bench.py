@@ -536,11 +536,11 @@ def main():
         per_launch_ms[dom] = st_dom[0] / max(cnt, 1)              # the dominant kernel: live, over the timed region
         achieved = alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9
         # HBM-side traffic of the dominant kernel: FETCH_SIZE (x2 for 16-byte-per-lane streams on gfx950) + WRITE_SIZE from the
-        # committed PMC pass of THIS kernel build (profiles/r02_pmc_dominant.json), scaled to this launch's image count;
+        # committed PMC pass of THIS kernel build (profiles/r03_pmc_dominant.json), scaled to this launch's image count;
         # null when the pass covers another kernel or configuration
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_dominant.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_dominant.json")))
             if pmc["stage"] == dom and pmc["config"] == args.config:
                 traffic = int((pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
                 traffic_src = f"committed rocprofv3 --pmc pass ({pmc['kernel']}), not measured in this run"

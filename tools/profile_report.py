@@ -37,7 +37,8 @@ def counters(tag_dir):
 def main(tag_dir, out_prefix, config="kitti_stereo"):
     stats = glob.glob(os.path.join(tag_dir, "**", "stats_kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(stats)))
-    bench_line = open(os.path.join(tag_dir, "stats.log")).read().strip().split("\n")[-1]
+    lines = [l for l in open(os.path.join(tag_dir, "stats.log")).read().split("\n") if l.startswith("{")]
+    bench_line = lines[-1] if lines else ""
     try:
         b = json.loads(bench_line)
         head = f"{b['value']:.0f} {b['unit']} under the profiler ({b['ms_per_step']:.3f} ms per step of {b['config']['frames_per_gpu_per_step']} stereo frames)"
