@@ -243,9 +243,11 @@ def per_frame_latency(cfg, n_frames: int):
     med = re.search(r"median tracking time: ([0-9.eE+-]+)", r.stdout)
     mean = re.search(r"mean tracking time: ([0-9.eE+-]+)", r.stdout)
     stats = re.search(r"keypoints/left image: ([0-9.]+), stereo matches/frame: ([0-9.]+), tracked/frame: ([0-9.]+)", r.stdout)
+    ph = re.search(r"two threads\) ([0-9.]+), ComputeStereoMatches ([0-9.]+), SearchByProjection\(cur,last\) ([0-9.]+)", r.stdout)
     return {"median_ms": round(float(med.group(1)) * 1e3, 4), "mean_ms": round(float(mean.group(1)) * 1e3, 4), "frames": n_frames,
             "keypoints_per_left_image": float(stats.group(1)), "stereo_matches_per_frame": float(stats.group(2)),
             "tracked_per_frame": float(stats.group(3)),
+            "median_ms_by_phase": ({"extract_x2": float(ph.group(1)), "stereo": float(ph.group(2)), "search_by_projection": float(ph.group(3))} if ph else None),
             "path": "examples/stereo_kitti.cc: C++ ORBextractor x2 on two threads + orbfe_host::ComputeStereoMatches + "
                     "ORBmatcher::SearchByProjection(cur,last), host images in, host keypoints / matches out, one pair at a time"}
 

@@ -116,6 +116,7 @@ int main(int argc, char** argv) {
   std::vector<std::unique_ptr<MapPoint>> lastPoints;          // UpdateLastFrame's temporal points
   std::unordered_map<MapPoint*, int> lastIndex;               // point -> keypoint index in the last frame
   long nKeys = 0, nStereo = 0, nTracked = 0;
+  std::vector<double> tPhase[3];   // per frame: extraction (two threads), ComputeStereoMatches, SearchByProjection incl. frame set-up
   cv::Mat imLeft, imRight;
   for (int ni = 0; ni < nImages; ni++) {
     if (!ReadGray(vstrImageLeft[(size_t)ni], imLeft) || !ReadGray(vstrImageRight[(size_t)ni], imRight)) {
@@ -123,6 +124,9 @@ int main(int argc, char** argv) {
       return 65;
     }
     const auto t1 = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point a) {
+      return std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - a).count();
+    };
 
     // ---- Frame::Frame(imLeft, imRight, ...)   L/src/Frame.cc:66-127
     Frame mCurrentFrame;
@@ -142,9 +146,13 @@ int main(int argc, char** argv) {
       threadLeft.join();
       threadRight.join();
     }
+    tPhase[0].push_back(since(t1));
+    const auto tS = std::chrono::steady_clock::now();
     mCurrentFrame.N = (int)mCurrentFrame.mvKeys.size();
     mCurrentFrame.mvKeysUn = mCurrentFrame.mvKeys;                       // UndistortKeyPoints with k1 == 0 (:~700)
     orbfe_host::ComputeStereoMatches(mCurrentFrame, mpORBextractorLeft, mpORBextractorRight);
+    tPhase[1].push_back(since(tS));
+    const auto tM = std::chrono::steady_clock::now();
     mCurrentFrame.mvpMapPoints.assign((size_t)mCurrentFrame.N, static_cast<MapPoint*>(NULL));
     mCurrentFrame.mvbOutlier.assign((size_t)mCurrentFrame.N, false);
     Frame::mnMinX = 0.0f; Frame::mnMaxX = (float)imLeft.cols;             // ComputeImageBounds without distortion
@@ -156,6 +164,7 @@ int main(int argc, char** argv) {
     int nmatches = 0;
     if (ni > 0) nmatches = matcher.SearchByProjection(mCurrentFrame, mLastFrame, th, false);
 
+    tPhase[2].push_back(since(tM));
     const auto t2 = std::chrono::steady_clock::now();
     vTimesTrack[(size_t)ni] = (float)std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
 
@@ -211,6 +220,9 @@ int main(int argc, char** argv) {
   printf("mean tracking time: %g\n", totaltime / nImages);
   printf("frames: %d, keypoints/left image: %.1f, stereo matches/frame: %.1f, tracked/frame: %.1f\n", nImages,
          (double)nKeys / nImages, (double)nStereo / nImages, (double)nTracked / std::max(nImages - 1, 1));
+  for (auto& v : tPhase) std::sort(v.begin(), v.end());
+  printf("median per phase [ms]: ORBextractor x2 (two threads) %.4f, ComputeStereoMatches %.4f, SearchByProjection(cur,last) %.4f\n",
+         1e3 * tPhase[0][tPhase[0].size() / 2], 1e3 * tPhase[1][tPhase[1].size() / 2], 1e3 * tPhase[2][tPhase[2].size() / 2]);
   delete mpORBextractorLeft;
   delete mpORBextractorRight;
   return 0;

@@ -46,6 +46,22 @@ static int mb_alloc(MBuf& b, size_t bytes) {
   return ORBFE_OK;
 }
 
+static int pin_alloc(void*& p, size_t& have, size_t bytes) {
+  if (p && bytes <= have) return ORBFE_OK;
+  if (p) HIPCHK(hipHostFree(p));
+  p = nullptr;
+  have = 0;
+  bytes = (bytes + 65535) & ~(size_t)65535;
+  HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  have = bytes;
+  return ORBFE_OK;
+}
+// lays parts out at 256-byte boundaries of a staging buffer
+struct Layout {
+  size_t off = 0;
+  size_t add(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+
 struct orbfe_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -55,8 +71,11 @@ struct orbfe_matcher {
   MBuf h_keys, h_desc, h_ur, h_q, h_n, h_nq, h_blocked, h_assigned, h_nm;
   // SearchLocalPoints: generated queries (device) and staging of the host entry point
   MBuf lp_q, lp_pts, lp_fr, lp_track, lp_cnt;
-  // orbfe_stereo_match (one pair, host pointers): packed inputs / outputs
+  // the per-frame host-pointer entry points (orbfe_stereo_match, the SearchByProjection family): ONE packed upload and ONE packed
+  // download per call through a pinned host mirror of a device staging buffer -- every hipMemcpyAsync costs 5-10 us of latency
   MBuf st_in, st_out;
+  void* h_pin = nullptr;
+  size_t h_pin_bytes = 0;
   std::mutex mu;
 };
 
@@ -92,6 +111,7 @@ extern "C" int orbfe_matcher_destroy(orbfe_matcher* m) {
                   &m->lp_q, &m->lp_pts, &m->lp_fr, &m->lp_track, &m->lp_cnt, &m->st_in, &m->st_out};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
+  if (m->h_pin) (void)hipHostFree(m->h_pin);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return ORBFE_OK;
@@ -306,20 +326,38 @@ static int search_host(const orbfe_frame_view* f, const orbfe_query* q, int nq, 
   std::lock_guard<std::mutex> lk(m->mu);
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = m->stream;
-  if ((rc = stage_host(m, f, q, nq, s))) return rc;
-  HIPCHK(hipMemcpyAsync(m->h_blocked.p, blocked, f->n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(m->h_assigned.p, assigned, sizeof(int32_t) * f->n, hipMemcpyHostToDevice, s));
-  rc = proj_enqueue(m, 1, (const orbfe_keypoint*)m->h_keys.p, (const uint8_t*)m->h_desc.p, (const int32_t*)m->h_n.p,
-                    (f->u_right && stereo_gate) ? (const float*)m->h_ur.p : nullptr, f->n, f->min_x, f->max_x, f->min_y,
-                    f->max_y, (const orbfe_query*)m->h_q.p, (const int32_t*)m->h_nq.p, nq, mode, nnratio, check_ori,
-                    (uint8_t*)m->h_blocked.p, (int32_t*)m->h_assigned.p, (int32_t*)m->h_nm.p, true, s, th_high);
-  if (rc) return rc;
-  int32_t nm = 0;
-  HIPCHK(hipMemcpyAsync(blocked, m->h_blocked.p, f->n, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(assigned, m->h_assigned.p, sizeof(int32_t) * f->n, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(&nm, m->h_nm.p, 4, hipMemcpyDeviceToHost, s));
+  // one packed upload [n, nq | keys | desc | mvuRight | queries | blocked | assigned | n_matches], the three kernels, one packed
+  // download of the tail [blocked | assigned | n_matches]
+  const size_t n = (size_t)f->n;
+  const bool ur = f->u_right && stereo_gate;
+  Layout L;
+  const size_t o_hdr = L.add(16), o_keys = L.add(sizeof(orbfe_keypoint) * n), o_desc = L.add(32 * n);
+  const size_t o_ur = L.add(ur ? sizeof(float) * n : 0), o_q = L.add(sizeof(orbfe_query) * (size_t)nq);
+  const size_t o_out = L.off;
+  const size_t o_blocked = L.add(n), o_assigned = L.add(sizeof(int32_t) * n), o_nm = L.add(16);
+  if ((rc = pin_alloc(m->h_pin, m->h_pin_bytes, L.off)) || (rc = mb_alloc(m->st_in, L.off))) return rc;
+  uint8_t* h = (uint8_t*)m->h_pin;
+  uint8_t* d = (uint8_t*)m->st_in.p;
+  ((int32_t*)(h + o_hdr))[0] = f->n;
+  ((int32_t*)(h + o_hdr))[1] = nq;
+  memcpy(h + o_keys, f->keys_un, sizeof(orbfe_keypoint) * n);
+  memcpy(h + o_desc, f->desc, 32 * n);
+  if (ur) memcpy(h + o_ur, f->u_right, sizeof(float) * n);
+  memcpy(h + o_q, q, sizeof(orbfe_query) * (size_t)nq);
+  memcpy(h + o_blocked, blocked, n);
+  memcpy(h + o_assigned, assigned, sizeof(int32_t) * n);
+  *(int32_t*)(h + o_nm) = 0;
+  HIPCHK(hipMemcpyAsync(d, h, L.off, hipMemcpyHostToDevice, s));
+  rc = proj_enqueue(m, 1, (const orbfe_keypoint*)(d + o_keys), d + o_desc, (const int32_t*)(d + o_hdr),
+                    ur ? (const float*)(d + o_ur) : nullptr, f->n, f->min_x, f->max_x, f->min_y, f->max_y,
+                    (const orbfe_query*)(d + o_q), (const int32_t*)(d + o_hdr) + 1, nq, mode, nnratio, check_ori, d + o_blocked,
+                    (int32_t*)(d + o_assigned), (int32_t*)(d + o_nm), true, s, th_high);
+  if (rc) { (void)hipStreamSynchronize(s); return rc; }
+  HIPCHK(hipMemcpyAsync(h + o_out, d + o_out, L.off - o_out, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  *n_matches = nm;
+  memcpy(blocked, h + o_blocked, n);
+  memcpy(assigned, h + o_assigned, sizeof(int32_t) * n);
+  *n_matches = *(const int32_t*)(h + o_nm);
   return ORBFE_OK;
 }
 
@@ -937,27 +975,31 @@ extern "C" int orbfe_stereo_match(orbfe_extractor* left, orbfe_extractor* right,
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const int cap = std::max(n_l, n_r);
-  // device staging: [n_l, n_r | keys_l | keys_r | desc_l | desc_r], every part 256-byte aligned; outputs [u_right | depth | n]
-  const size_t kb = ((sizeof(orbfe_keypoint) * (size_t)cap + 255) / 256) * 256, db = (((size_t)32 * cap + 255) / 256) * 256;
-  const size_t fb = ((sizeof(float) * (size_t)cap + 255) / 256) * 256;
-  if ((rc = mb_alloc(m->st_in, 256 + 2 * kb + 2 * db)) || (rc = mb_alloc(m->st_out, 2 * fb + 256))) return rc;
-  uint8_t* in = (uint8_t*)m->st_in.p;
-  uint8_t* out = (uint8_t*)m->st_out.p;
-  const int32_t hdr[2] = {n_l, n_r};
-  HIPCHK(hipMemcpyAsync(in, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(in + 256, kps_l, sizeof(orbfe_keypoint) * (size_t)n_l, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(in + 256 + kb, kps_r, sizeof(orbfe_keypoint) * (size_t)n_r, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(in + 256 + 2 * kb, desc_l, (size_t)32 * n_l, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(in + 256 + 2 * kb + db, desc_r, (size_t)32 * n_r, hipMemcpyHostToDevice, s));
-  rc = stereo_enqueue(m, left, right, 1, (const orbfe_keypoint*)(in + 256), in + 256 + 2 * kb, (const int32_t*)in,
-                      (const orbfe_keypoint*)(in + 256 + kb), in + 256 + 2 * kb + db, (const int32_t*)in + 1, cap, mbf, mb,
-                      (float*)out, (float*)(out + fb), (int32_t*)(out + 2 * fb), s);
-  if (rc) { (void)hipStreamSynchronize(s); return rc; }   // hdr lives on this stack frame
-  int32_t nm = 0;
-  HIPCHK(hipMemcpyAsync(u_right, out, sizeof(float) * (size_t)n_l, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(depth, out + fb, sizeof(float) * (size_t)n_l, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(&nm, out + 2 * fb, sizeof(nm), hipMemcpyDeviceToHost, s));
+  // one packed upload [n_l, n_r | keys_l | keys_r | desc_l | desc_r], three kernels, one packed download [u_right | depth | n]
+  Layout L;
+  const size_t o_hdr = L.add(16), o_kl = L.add(sizeof(orbfe_keypoint) * (size_t)cap), o_kr = L.add(sizeof(orbfe_keypoint) * (size_t)cap);
+  const size_t o_dl = L.add((size_t)32 * cap), o_dr = L.add((size_t)32 * cap);
+  const size_t o_out = L.off;
+  const size_t o_ur = L.add(sizeof(float) * (size_t)cap), o_dp = L.add(sizeof(float) * (size_t)cap), o_nm = L.add(16);
+  if ((rc = pin_alloc(m->h_pin, m->h_pin_bytes, L.off)) || (rc = mb_alloc(m->st_in, L.off))) return rc;
+  uint8_t* h = (uint8_t*)m->h_pin;
+  uint8_t* d = (uint8_t*)m->st_in.p;
+  ((int32_t*)(h + o_hdr))[0] = n_l;
+  ((int32_t*)(h + o_hdr))[1] = n_r;
+  memcpy(h + o_kl, kps_l, sizeof(orbfe_keypoint) * (size_t)n_l);
+  memcpy(h + o_kr, kps_r, sizeof(orbfe_keypoint) * (size_t)n_r);
+  memcpy(h + o_dl, desc_l, (size_t)32 * n_l);
+  memcpy(h + o_dr, desc_r, (size_t)32 * n_r);
+  HIPCHK(hipMemcpyAsync(d, h, o_out, hipMemcpyHostToDevice, s));
+  rc = stereo_enqueue(m, left, right, 1, (const orbfe_keypoint*)(d + o_kl), d + o_dl, (const int32_t*)(d + o_hdr),
+                      (const orbfe_keypoint*)(d + o_kr), d + o_dr, (const int32_t*)(d + o_hdr) + 1, cap, mbf, mb, (float*)(d + o_ur),
+                      (float*)(d + o_dp), (int32_t*)(d + o_nm), s);
+  if (rc) { (void)hipStreamSynchronize(s); return rc; }
+  HIPCHK(hipMemcpyAsync(h + o_out, d + o_out, L.off - o_out, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  memcpy(u_right, h + o_ur, sizeof(float) * (size_t)n_l);
+  memcpy(depth, h + o_dp, sizeof(float) * (size_t)n_l);
+  const int32_t nm = *(const int32_t*)(h + o_nm);
   if (n_matched) *n_matched = nm;
   return ORBFE_OK;
 }
