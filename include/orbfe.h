@@ -115,7 +115,12 @@ int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* imgs, int n_im
 /* Device-resident batch: all pointers are DEVICE pointers; asynchronous on `stream` (a hipStream_t, or
  * NULL for the handle's own stream).  d_imgs: image i at d_imgs + i*image_pitch, rows `stride` bytes
  * apart.  d_kps: n_images x cap, d_desc: n_images x cap x 32, d_n_out: n_images int32.  Work space is
- * (re)allocated when the geometry or batch size grows -- call once untimed before timing. */
+ * (re)allocated when the geometry or batch size grows -- call once untimed before timing.
+ * Level 0 in place: when d_imgs, stride and image_pitch are multiples of 16 and stride >= w rounded up to 16 (what
+ * hipMemcpy2D into a pitched allocation or an image decoder delivers) the images ARE pyramid level 0 -- no copy.  They must
+ * then stay unchanged until the results of this batch and every later read of its pyramid (orbfe_stereo_match_device,
+ * orbfe_device_pyramid, orbfe_pyramid_level*) are complete.  Other layouts (tightly packed odd-width rows) are copied into
+ * pitched planes first. */
 int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_imgs, int n_images, int w, int h, int stride,
                                size_t image_pitch, orbfe_keypoint* d_kps, uint8_t* d_desc, int cap,
                                int32_t* d_n_out, void* stream);

@@ -78,6 +78,10 @@ struct orbfe_extractor {
   int feat_per_level[ORBFE_MAX_LEVELS]{};
   // plan (depends on image geometry)
   int plan_w = 0, plan_h = 0;
+  // level 0 of the last device batch when the caller's images could be used in place (16-byte aligned rows): no pitched copy
+  const uint8_t* ext0 = nullptr;
+  int ext0_pitch = 0;
+  size_t ext0_plane = 0;
   LevelGeom lg[ORBFE_MAX_LEVELS]{};
   std::vector<CellDesc> cells;
   std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
@@ -424,6 +428,20 @@ static void make_view(const orbfe_extractor* e, const DevBuf& buf, PyrView& v) {
     v.w[l] = e->lg[l].w;
     v.h[l] = e->lg[l].h;
   }
+  if (&buf == &e->d_pyr && e->ext0) {   // level 0 = the caller's images themselves
+    v.base[0] = e->ext0;
+    v.img_stride[0] = e->ext0_plane;
+    v.pitch[0] = e->ext0_pitch;
+  }
+}
+// plane of image `image` at pyramid level `level` (raw pyramid) and its row pitch
+static const uint8_t* pyr_plane(const orbfe_extractor* e, int level, int image, int* pitch) {
+  if (level == 0 && e->ext0) {
+    *pitch = e->ext0_pitch;
+    return e->ext0 + (size_t)image * e->ext0_plane;
+  }
+  *pitch = e->lg[level].pitch;
+  return level_ptr(e, e->d_pyr, level, image);
 }
 
 struct StageTimer {
@@ -474,7 +492,7 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   {
     StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
     for (int l = 1; l < nl; l++)
-      orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], e->lg[l - 1].plane, const_cast<uint8_t*>(pv.base[l]),
+      orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], pv.img_stride[l - 1], const_cast<uint8_t*>(pv.base[l]),
                           pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
                           (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_mode[l], s);
   }
@@ -704,10 +722,23 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
   if ((rc = build_plan(e, w, h))) return rc;
   if ((rc = ensure_workspace(e, n_images))) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+  // Rows that start on 16-byte boundaries and are at least ceil16(w) bytes apart are what every kernel needs of a level (16-byte
+  // loads of whole chunks): such images ARE level 0 -- no pitched copy (233 KB of traffic per KITTI image).  They must then stay
+  // unchanged until this batch's results, and any later read of its pyramid (orbfe_stereo_match_device, orbfe_device_pyramid),
+  // are done.  Anything else (odd widths packed tightly, as cv::Mat rows are) is copied into the pitched level-0 planes.
+  const bool in_place = ((uintptr_t)d_imgs & 15) == 0 && (stride & 15) == 0 && (image_pitch & 15) == 0 && stride >= ((w + 15) & ~15) &&
+                        image_pitch >= (size_t)stride * (size_t)h;
   {
-    StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
-    orbfe_launch_copy0(d_imgs, stride, image_pitch, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w, h,
-                       n_images, s);
+    StageTimer t(e, s, ORBFE_STAGE_PYRAMID);   // kept when there is nothing to copy: the stage's event pairs stay two per batch
+    if (in_place) {
+      e->ext0 = d_imgs;
+      e->ext0_pitch = stride;
+      e->ext0_plane = image_pitch;
+    } else {
+      e->ext0 = nullptr;
+      orbfe_launch_copy0(d_imgs, stride, image_pitch, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w, h,
+                         n_images, s);
+    }
   }
   return enqueue_pipeline(e, n_images, d_kps, d_desc, cap, d_n_out, s);
 }
@@ -749,6 +780,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
   // straight into pinned host memory (hipHostMalloc memory is device-addressable); each memcpy on the stream costs a launch
   // and a dependency gap (~10 us) that a 120 KB result does not repay.  Larger batches keep the DMA copies.
   const bool zc = n_images <= 2;
+  e->ext0 = nullptr;   // host images are staged and copied into the pitched level-0 planes
   uint8_t* ho = (uint8_t*)e->h_out;
   if (!zc) HIPCHK(hipMemcpyAsync(e->d_in_stage.p, e->h_in, img_bytes * B, hipMemcpyHostToDevice, s));
   {
@@ -810,9 +842,10 @@ extern "C" int orbfe_pyramid_level(orbfe_extractor* e, int level, uint8_t* dst, 
   if (dst) {
     if (dst_stride < g.w) return ORBFE_ERR_INVALID;
     const size_t bytes = (size_t)g.pitch * g.h;
-    int rc;
+    int rc, sp = 0;
     if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, bytes))) return rc;
-    HIPCHK(hipMemcpyAsync(e->h_out, level_ptr(e, e->d_pyr, level, 0), bytes, hipMemcpyDeviceToHost, e->stream));
+    const uint8_t* src = pyr_plane(e, level, 0, &sp);
+    HIPCHK(hipMemcpy2DAsync(e->h_out, g.pitch, src, sp, g.w, g.h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int y = 0; y < g.h; y++) memcpy(dst + (size_t)y * dst_stride, (uint8_t*)e->h_out + (size_t)y * g.pitch, (size_t)g.w);
   }
@@ -831,7 +864,10 @@ extern "C" int orbfe_pyramid_levels(orbfe_extractor* e, uint8_t* const* dst, con
   size_t off = 0;
   for (int l = 0; l < nl; l++) {  // image 0 of every level: contiguous pitched plane -> pinned, one sync for all
     const size_t bytes = (size_t)e->lg[l].pitch * e->lg[l].h;
-    HIPCHK(hipMemcpyAsync((uint8_t*)e->h_out + off, level_ptr(e, e->d_pyr, l, 0), bytes, hipMemcpyDeviceToHost, e->stream));
+    int sp = 0;
+    const uint8_t* src = pyr_plane(e, l, 0, &sp);
+    if (sp == e->lg[l].pitch) HIPCHK(hipMemcpyAsync((uint8_t*)e->h_out + off, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    else HIPCHK(hipMemcpy2DAsync((uint8_t*)e->h_out + off, e->lg[l].pitch, src, sp, e->lg[l].w, e->lg[l].h, hipMemcpyDeviceToHost, e->stream));
     off += bytes;
   }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -849,8 +885,10 @@ extern "C" int orbfe_device_pyramid(const orbfe_extractor* e, int image, int lev
                                     int* w, int* h) {
   if (!e || level < 0 || level >= e->prm.n_levels || image < 0 || image >= e->cap_images || e->plan_w == 0)
     return ORBFE_ERR_INVALID;
-  if (d_ptr) *d_ptr = level_ptr(e, e->d_pyr, level, image);
-  if (pitch) *pitch = e->lg[level].pitch;
+  int sp = 0;
+  const uint8_t* src = pyr_plane(e, level, image, &sp);
+  if (d_ptr) *d_ptr = src;
+  if (pitch) *pitch = sp;
   if (w) *w = e->lg[level].w;
   if (h) *h = e->lg[level].h;
   return ORBFE_OK;
@@ -925,7 +963,9 @@ extern "C" int orbfe_debug_pyramid(orbfe_extractor* e, int image, int level, uin
   HIPCHK(hipSetDevice(e->device));
   const LevelGeom& g = e->lg[level];
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy2D(dst, dst_stride, level_ptr(e, e->d_pyr, level, image), g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
+  int sp = 0;
+  const uint8_t* src = pyr_plane(e, level, image, &sp);
+  HIPCHK(hipMemcpy2D(dst, dst_stride, src, sp, g.w, g.h, hipMemcpyDeviceToHost));
   return ORBFE_OK;
 }
 

@@ -120,6 +120,50 @@ def test_batch_equals_single_and_is_idempotent():
     ex.close()
 
 
+def test_aligned_device_images_are_level0_in_place():
+    """Device images whose rows start on 16-byte boundaries (pitch 1280 for a 1241-pixel row) are used as pyramid level 0 without
+    the pitched copy: results, the level-0 plane seen through orbfe_device_pyramid / debug_pyramid, and a stereo match on the
+    in-place pyramids must equal the copied path (tightly packed rows) and the oracle."""
+    import torch
+    from refactored_orb_slam2_amd._lib import KP_DTYPE
+    from refactored_orb_slam2_amd.matcher import Matcher
+    w, h, nf, B = 1241, 376, 2000, 3
+    pairs = synth.sequence(w, h, B, seq=31, stereo=True)
+    cap = None
+    outs = {}
+    for name, pitch in (("packed", w), ("in_place", 1280)):
+        exL, exR, mt = ORBextractor(nf), ORBextractor(nf), Matcher(0)
+        cap = exL.max_keypoints(w, h)
+        bufs = []
+        for side in (0, 1):
+            full = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
+            full[:, :, :w] = torch.from_numpy(np.stack([p[side] for p in pairs])).cuda()
+            bufs.append(full)
+        z = lambda *s, dt=torch.uint8: torch.zeros(s, dtype=dt, device="cuda")
+        kl, dl, nl, kr, dr, nr = z(B, cap, 28), z(B, cap, 32), z(B, dt=torch.int32), z(B, cap, 28), z(B, cap, 32), z(B, dt=torch.int32)
+        ur, dp, ns = z(B, cap, dt=torch.float32), z(B, cap, dt=torch.float32), z(B, dt=torch.int32)
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        exL.extract_batch_device(bufs[0][:, :, :w], kl, dl, nl, stream=st)
+        exR.extract_batch_device(bufs[1][:, :, :w], kr, dr, nr, stream=st)
+        mt.stereo_match(exL, exR, kl, dl, nl, kr, dr, nr, 386.1448, 386.1448 / 718.856, ur, dp, ns, stream=st)
+        torch.cuda.synchronize()
+        exL.device_status(); exR.device_status()
+        lvl0 = exL.debug_pyramid(1, 0)
+        np.testing.assert_array_equal(lvl0, pairs[1][0])
+        outs[name] = [t.cpu().numpy() for t in (kl, dl, nl, ur, dp, ns)]
+        for hnd in (exL, exR, mt):
+            hnd.close()
+    for a, b in zip(outs["packed"], outs["in_place"]):
+        np.testing.assert_array_equal(a, b)
+    orc = ol.OracleExtractor(nf)
+    ok, od = orc(pairs[0][0])
+    n0 = int(outs["in_place"][2][0])
+    np.testing.assert_array_equal(outs["in_place"][0][0, :n0].view(KP_DTYPE).reshape(-1), ok)
+    np.testing.assert_array_equal(outs["in_place"][1][0, :n0], od)
+    assert int(outs["in_place"][5].min()) > 800
+
+
 def test_batch_of_19_images_covers_both_workgroup_orders():
     """orient_describe hands whole images to XCDs in sets of eight and keeps the dispatch order for the remainder: 19 images
     exercise both in one launch; every image must equal its single-image extraction"""
