@@ -185,50 +185,49 @@ __global__ __launch_bounds__(256) void hamming_bf_kernel(HammingBfParams P) {
 
 // ------------------------------------------------------------------------------------------------ grid
 // One block per frame: 64x48 grid in CSR form (cell = ix*48 + iy), lists in ascending keypoint index.
-__global__ __launch_bounds__(256) void grid_build_kernel(FrameBatch F) {
+#define GB_THREADS 1024   // one block per frame and one frame per CU: the block's own parallelism is all there is to hide latency with
+__global__ __launch_bounds__(GB_THREADS) void grid_build_kernel(FrameBatch F) {
   __shared__ int cnt[GRID_CELLS];
   __shared__ int start[GRID_CELLS + 1];
-  __shared__ int tmp[8];
+  __shared__ int tmp[GB_THREADS / 64];
+  static_assert(GRID_CELLS % GB_THREADS == 0, "cells per thread");
+  constexpr int CPT = GRID_CELLS / GB_THREADS;   // consecutive cells per thread in the scan
   const int f = blockIdx.x, tid = threadIdx.x;
   const int n = F.n[f];
   const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
   int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
   int32_t* ci = F.cell_idx + (size_t)f * F.cap;
-  for (int c = tid; c < GRID_CELLS; c += 256) cnt[c] = 0;
+  for (int c = tid; c < GRID_CELLS; c += GB_THREADS) cnt[c] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += GB_THREADS) {
     const int px = (int)roundf((keys[i].x - F.min_x) * F.gw_inv);
     const int py = (int)roundf((keys[i].y - F.min_y) * F.gh_inv);
     if (px >= 0 && px < ORBFE_GRID_COLS && py >= 0 && py < ORBFE_GRID_ROWS) atomicAdd(&cnt[px * ORBFE_GRID_ROWS + py], 1);
   }
   __syncthreads();
-  // exclusive scan: 12 consecutive cells per thread
+  // exclusive scan: CPT consecutive cells per thread, DPP wave scan, wave totals through LDS
   {
     int local = 0;
-    for (int k = 0; k < 12; k++) local += cnt[tid * 12 + k];
-    int v = local;
-    const int lane = tid & 63;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int t = __shfl_up(v, d, WAVE);
-      if (lane >= d) v += t;
-    }
-    if (lane == 63) tmp[tid >> 6] = v;
+    for (int k = 0; k < CPT; k++) local += cnt[tid * CPT + k];
+    const int v = wave_incl_scan_i(local);
+    if ((tid & 63) == 63) tmp[tid >> 6] = v;
     __syncthreads();
     int off = 0;
     for (int w = 0; w < (tid >> 6); w++) off += tmp[w];
     int run = off + v - local;
-    for (int k = 0; k < 12; k++) {
-      start[tid * 12 + k] = run;
-      run += cnt[tid * 12 + k];
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+      start[tid * CPT + k] = run;
+      run += cnt[tid * CPT + k];
     }
-    if (tid == 255) start[GRID_CELLS] = run;
+    if (tid == GB_THREADS - 1) start[GRID_CELLS] = run;
   }
   __syncthreads();
-  for (int c = tid; c <= GRID_CELLS; c += 256) cs[c] = start[c];
-  for (int c = tid; c < GRID_CELLS; c += 256) cnt[c] = 0;
+  for (int c = tid; c <= GRID_CELLS; c += GB_THREADS) cs[c] = start[c];
+  for (int c = tid; c < GRID_CELLS; c += GB_THREADS) cnt[c] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += GB_THREADS) {
     const int px = (int)roundf((keys[i].x - F.min_x) * F.gw_inv);
     const int py = (int)roundf((keys[i].y - F.min_y) * F.gh_inv);
     if (px >= 0 && px < ORBFE_GRID_COLS && py >= 0 && py < ORBFE_GRID_ROWS) {
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(256) void grid_build_kernel(FrameBatch F) {
   }
   __syncthreads();
   // insertion order of the reference = ascending index: sort each (tiny) cell list
-  for (int c = tid; c < GRID_CELLS; c += 256) {
+  for (int c = tid; c < GRID_CELLS; c += GB_THREADS) {
     const int s = start[c], e = start[c + 1];
     for (int i = s + 1; i < e; i++) {
       const int v = ci[i];
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(256) void grid_build_kernel(FrameBatch F) {
   const float* ur = F.u_right ? F.u_right + (size_t)f * F.cap : nullptr;
   uint4* cr = reinterpret_cast<uint4*>(F.cell_rec) + (size_t)f * F.cap;
   const int total = start[GRID_CELLS];
-  for (int e = tid; e < total; e += 256) {
+  for (int e = tid; e < total; e += GB_THREADS) {
     const int i = ci[e];
     const orbfe_keypoint kp = keys[i];
     cr[e] = make_uint4((uint32_t)i | ((uint32_t)kp.octave << 24), (uint32_t)__float_as_int(kp.x), (uint32_t)__float_as_int(kp.y),
@@ -1296,7 +1295,7 @@ void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, h
   hipLaunchKernelGGL(hamming_bf_kernel, grid, dim3(256), 0, s, p);
 }
 void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {
-  hipLaunchKernelGGL(grid_build_kernel, dim3(n_frames), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(grid_build_kernel, dim3(n_frames), dim3(GB_THREADS), 0, s, f);
 }
 void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
                                   int max_cand, int n_frames, hipStream_t s) {
