@@ -573,12 +573,16 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         if (x >= c_hi) continue;   // the pair straddling the right edge of the tested region
         // the centre and the sixteen ring bytes, packed in ring order as eight (q_2j, q_2j+1) pairs (d16 byte loads would
         // build the pairs for free, but with SRAM ECC they zero the other half of the register)
-        const uint8_t* c = tile + e;
-        const uint32_t v = c[0];
+        // (addressed from the ring's top-left corner: every offset is then a non-negative immediate of ds_read_u8, where
+        // offsets relative to the centre cost eight address additions)
+        int eb = e - (3 * PB + 3);
+        asm("" : "+v"(eb));   // keep THIS base: the compiler would fold the constant back and re-create the negative offsets
+        const uint8_t* c = tile + eb;
+        const uint32_t v = c[3 * PB + 3];
         uint32_t P[8];
 #pragma unroll
         for (int j = 0; j < 8; j++)
-          P[j] = (uint32_t)c[RDY[2 * j] * PB + RDX[2 * j]] | ((uint32_t)c[RDY[2 * j + 1] * PB + RDX[2 * j + 1]] << 16);
+          P[j] = (uint32_t)c[(RDY[2 * j] + 3) * PB + RDX[2 * j] + 3] | ((uint32_t)c[(RDY[2 * j + 1] + 3) * PB + RDX[2 * j + 1] + 3] << 16);
         const uint32_t VV = v | (v << 16);
         const bool bright = (en & 0x4000u) != 0;
         int s = arc9_maxmin_pk(P, VV, bright ? ~0u : 0u) + (bright ? 1 : 0);
