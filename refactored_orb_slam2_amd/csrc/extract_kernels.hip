@@ -30,22 +30,28 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   return v;
 }
 
-// Inclusive scan over the 256 threads of a block (thread order = threadIdx.x).  tmp: >= 5 ints of LDS.
+// Inclusive scan over the T threads of a block (thread order = threadIdx.x; T a multiple of 64, <= 1024).  tmp: >= 16 ints of LDS.
 // Returns the inclusive prefix; *total receives the block sum.  Contains two __syncthreads().
-__device__ __forceinline__ int block_incl_scan256(int v, int* tmp, int* total) {
+template <int T>
+__device__ __forceinline__ int block_incl_scan_t(int v, int* tmp, int* total) {
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1), wid = tid >> 6;
   int s = wave_incl_scan(v);
+  if (T == WAVE) {   // one wave: no LDS, no barrier
+    *total = __builtin_amdgcn_readlane(s, WAVE - 1);
+    return s;
+  }
   __syncthreads();  // protect tmp from a previous use
   if (lane == WAVE - 1) tmp[wid] = s;
   __syncthreads();
-  int off = 0;
+  int off = 0, tot = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < T / WAVE; i++) {
     int t = tmp[i];
     if (i < wid) off += t;
+    tot += t;
   }
-  *total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  *total = tot;
   return s + off;
 }
 
@@ -822,6 +828,8 @@ extern "C" int orbfe_debug_oct_profile(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+#define OCT_T ORBFE_OCT_THREADS   // 256 measured best (64: 0.120, 128: 0.091, 256: 0.069, 512: 0.091 ms per 256 images)
+static_assert(ORBFE_MAX_INI <= ORBFE_OCT_THREADS, "one thread per root node in step 3");
 __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
@@ -857,11 +865,11 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 
   // 1. exclusive offsets of the cells' candidate lists (cell raster order == vToDistributeKeys order)
   int running = 0;
-  for (int base = 0; base < L.n_cells; base += 256) {
+  for (int base = 0; base < L.n_cells; base += OCT_T) {
     const int c = base + tid;
     const int v = c < L.n_cells ? cnt[c] : 0;
     int tot;
-    const int incl = block_incl_scan256(v, scan_tmp, &tot);
+    const int incl = block_incl_scan_t<OCT_T>(v, scan_tmp, &tot);
     if (c < L.n_cells) coff[c] = running + incl - v;
     running += tot;
   }
@@ -872,11 +880,11 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   }
   unsigned long long* keys = (C <= P.lds_keys) ? lkeys : (P.gkeys + (size_t)img * P.gkeys_per_image + L.key_off);
 
-  for (int i = tid; i < L.n_ini; i += 256) ini_cnt[i] = 0;
+  for (int i = tid; i < L.n_ini; i += OCT_T) ini_cnt[i] = 0;
   __syncthreads();
 
   // 2. gather keys, assign to the root nodes: vpIniNodes[kp.pt.x / hX] (L/src/ORBextractor.cc:559)
-  for (int c = tid; c < L.n_cells; c += 256) {
+  for (int c = tid; c < L.n_cells; c += OCT_T) {
     const int n = cnt[c];
     const int o = coff[c];
     const uint32_t* src = slots + cells[c].slot_off;
@@ -896,7 +904,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   {
     const int has = (tid < L.n_ini && ini_cnt[tid] > 0) ? 1 : 0;
     int tot;
-    const int incl = block_incl_scan256(has, scan_tmp, &tot);
+    const int incl = block_incl_scan_t<OCT_T>(has, scan_tmp, &tot);
     if (tid < L.n_ini) {
       ini_map[tid] = incl - has;
       if (has) {
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     size = tot;
   }
   __syncthreads();
-  for (int k = tid; k < C; k += 256) {
+  for (int k = tid; k < C; k += OCT_T) {
     unsigned long long kk = keys[k];
     const int nn = ini_map[KEY_NODE(kk)];
     keys[k] = (kk & ~(0xffffULL << 32)) | ((unsigned long long)(uint16_t)nn << 32);
@@ -928,10 +936,10 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     n_iter++;
 #endif
     const int prev = size;
-    for (int i = tid; i < size * 4; i += 256) cnt4[i] = 0;
+    for (int i = tid; i < size * 4; i += OCT_T) cnt4[i] = 0;
     __syncthreads();
     // keys -> quadrant counts of their leaf (DivideNode :505-517)
-    for (int k = tid; k < C; k += 256) {
+    for (int k = tid; k < C; k += OCT_T) {
       unsigned long long kk = keys[k];
       const int p = KEY_NODE(kk);
       const OctNode nd = nodeA[p];
@@ -951,13 +959,13 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     if (phase == 1) {
       // every multi-key leaf splits, in list order (:592-643)
       int run = 0;
-      for (int base = 0; base < size; base += 256) {
+      for (int base = 0; base < size; base += OCT_T) {
         const int p = base + tid;
         int c = 0;
         if (p < size && nodeA[p].cnt > 1)
           c = (cnt4[p * 4] > 0) + (cnt4[p * 4 + 1] > 0) + (cnt4[p * 4 + 2] > 0) + (cnt4[p * 4 + 3] > 0);
         int tot;
-        const int incl = block_incl_scan256(c, scan_tmp, &tot);
+        const int incl = block_incl_scan_t<OCT_T>(c, scan_tmp, &tot);
         if (p < size) aux[p] = c > 0 ? run + incl - c : -1;  // childbase, -1 = stays
         run += tot;
       }
@@ -969,18 +977,18 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       unsigned long long* sortkey = reinterpret_cast<unsigned long long*>(childpos);  // dead until the rebuild below
       unsigned long long* sorted = reinterpret_cast<unsigned long long*>(nodeB);      // previous generation: dead
       int nE = 0;
-      for (int base = 0; base < size; base += 256) {
+      for (int base = 0; base < size; base += OCT_T) {
         const int p = base + tid;
         const int e = (p < size && nodeA[p].cnt > 1) ? 1 : 0;
         int tot;
-        const int incl = block_incl_scan256(e, scan_tmp, &tot);
+        const int incl = block_incl_scan_t<OCT_T>(e, scan_tmp, &tot);
         if (e) sortkey[nE + incl - 1] = ((unsigned long long)(0xFFFFFFFFu - (uint32_t)nodeA[p].cnt) << 32) | (uint32_t)p;
         if (p < size) aux[p] = -1;
         nE += tot;
       }
       __syncthreads();
       // rank sort (keys are unique)
-      for (int i = tid; i < nE; i += 256) {
+      for (int i = tid; i < nE; i += OCT_T) {
         const unsigned long long mine = sortkey[i];
         int r = 0;
         for (int j = 0; j < nE; j++) r += (sortkey[j] < mine) ? 1 : 0;
@@ -990,7 +998,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       // walk in sorted order: running list size after each split; first rank reaching N ends the walk
       if (tid == 0) sh[0] = nE;  // index of the last split rank + 1
       int run_inc = 0, run_c = 0;
-      for (int base = 0; base < nE; base += 256) {
+      for (int base = 0; base < nE; base += OCT_T) {
         const int r = base + tid;
         int c = 0, p = 0;
         if (r < nE) {
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
         }
         int tot;
         const int packed = ((c > 0 ? c - 1 : 0) << 16) | c;
-        const int incl = block_incl_scan256(packed, scan_tmp, &tot);
+        const int incl = block_incl_scan_t<OCT_T>(packed, scan_tmp, &tot);
         if (r < nE) {
           const int size_after = prev + run_inc + (incl >> 16);
           aux2[r] = run_c + (incl & 0xffff) - c;  // childbase by rank (temporarily in aux2)
@@ -1014,7 +1022,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       __syncthreads();
       if (tid == 0) sh[1] = 0;
       __syncthreads();
-      for (int r = tid; r < nsplit; r += 256) {
+      for (int r = tid; r < nsplit; r += OCT_T) {
         const int p = (int)(sorted[r] & 0xffffffffu);
         aux[p] = aux2[r];
         if (r == nsplit - 1) {
@@ -1029,11 +1037,11 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 
     // positions of the leaves that stay: after the K new children, old order preserved
     int S = 0;
-    for (int base = 0; base < size; base += 256) {
+    for (int base = 0; base < size; base += OCT_T) {
       const int p = base + tid;
       const int st = (p < size && aux[p] < 0) ? 1 : 0;
       int tot;
-      const int incl = block_incl_scan256(st, scan_tmp, &tot);
+      const int incl = block_incl_scan_t<OCT_T>(st, scan_tmp, &tot);
       if (st) aux2[p] = K + S + incl - 1;
       S += tot;
     }
@@ -1044,7 +1052,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     }
     __syncthreads();
     // build the new leaf array: children pushed to the front in creation order => reversed
-    for (int p = tid; p < size; p += 256) {
+    for (int p = tid; p < size; p += OCT_T) {
       const OctNode nd = nodeA[p];
       if (aux[p] >= 0) {
         const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
@@ -1071,7 +1079,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       }
     }
     __syncthreads();
-    for (int k = tid; k < C; k += 256) {
+    for (int k = tid; k < C; k += OCT_T) {
       unsigned long long kk = keys[k];
       const int p = KEY_NODE(kk);
       const int np = aux[p] >= 0 ? (int)childpos[p * 4 + KEY_Q(kk)] : aux2[p];
@@ -1084,9 +1092,9 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     if (phase == 1) {
       // nToExpand = leaves with more than one key (all of them are new children)
       int ne = 0;
-      for (int p = tid; p < size; p += 256) ne += nodeA[p].cnt > 1 ? 1 : 0;
+      for (int p = tid; p < size; p += OCT_T) ne += nodeA[p].cnt > 1 ? 1 : 0;
       int tot;
-      block_incl_scan256(ne, scan_tmp, &tot);
+      block_incl_scan_t<OCT_T>(ne, scan_tmp, &tot);
       if (size >= N || size == prev) finish = true;
       else if (size + 3 * tot > N) phase = 2;
     } else {
@@ -1097,14 +1105,14 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 
   // 5. best key of every leaf: max response, first candidate wins ties (:712-728)
   uint32_t* best = reinterpret_cast<uint32_t*>(cnt4);
-  for (int p = tid; p < size; p += 256) best[p] = 0;
+  for (int p = tid; p < size; p += OCT_T) best[p] = 0;
   __syncthreads();
-  for (int k = tid; k < C; k += 256) {
+  for (int k = tid; k < C; k += OCT_T) {
     const unsigned long long kk = keys[k];
     atomicMax(&best[KEY_NODE(kk)], ((uint32_t)KEY_SCORE(kk) << 24) | (0xFFFFFFu - (uint32_t)k));
   }
   __syncthreads();
-  for (int p = tid; p < size; p += 256) {
+  for (int p = tid; p < size; p += OCT_T) {
     const int k = (int)(0xFFFFFFu - (best[p] & 0xFFFFFFu));
     const unsigned long long kk = keys[k];
     if (p < L.kp_cap)

@@ -9,7 +9,9 @@
 #define ORBFE_CELL_MAX 66        // largest FAST cell ROI side the cell kernel stages in LDS
 #define ORBFE_BLUR_TILE_H 58      // rows of a blur tile (64 wide); must be even
 #define ORBFE_MAX_INI 256        // largest nIni (root nodes of DistributeOctTree) supported
+#ifndef ORBFE_OCT_THREADS
 #define ORBFE_OCT_THREADS 256
+#endif
 
 // Per-level geometry of one image pyramid, passed to kernels by value.
 struct PyrView {
