@@ -566,7 +566,8 @@ extern "C" int orbfe_extractor_create(const orbfe_params* p, int device, orbfe_e
   if (!p || !out) return ORBFE_ERR_INVALID;
   *out = nullptr;
   if (p->n_levels < 1 || p->n_levels > ORBFE_MAX_LEVELS || p->n_features < 1 || !(p->scale_factor > 1.0f) ||
-      p->ini_th_fast < 1 || p->ini_th_fast > 255 || p->min_th_fast < 1 || p->min_th_fast > p->ini_th_fast) {
+      p->ini_th_fast < 1 || p->ini_th_fast > 255 || p->min_th_fast < 1 || p->min_th_fast > 255) {   // min > ini is legal: the
+                                                          // reference runs FAST(ini) and, on an empty cell, FAST(min) whatever their order
     orbfe_set_error("invalid extractor parameters");
     return ORBFE_ERR_INVALID;
   }

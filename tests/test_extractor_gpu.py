@@ -238,6 +238,31 @@ def test_other_extractor_parameters(params):
     ex.close()
 
 
+@pytest.mark.parametrize("ini,mn", [(20, 7), (7, 7), (5, 12), (60, 2), (250, 1), (1, 1)])
+def test_threshold_order_and_fallback(ini, mn):
+    """FAST(iniThFAST) first, FAST(minThFAST) only for cells that came back empty (L/src/ORBextractor.cc:773-780), on an image
+    whose left half is soft (every cell falls back), whose right half is textured (no cell does) and whose middle band is mixed;
+    thresholds in the usual order, equal, inverted, and at the extremes.  Candidate lists per level and the final result vs the
+    oracle."""
+    from scipy.ndimage import gaussian_filter
+    w, h, nf = 752, 480, 1200
+    base = synth.frame(w, h, seq=12, f=3)
+    soft = np.clip(gaussian_filter(base.astype(np.float32), 2.5) * 0.6 + 50, 0, 255).astype(np.uint8)
+    img = base.copy()
+    img[:, : w // 2] = soft[:, : w // 2]
+    img[200:280, 300:450] = soft[200:280, 300:450]
+    ex = ORBextractor(nf, 1.2, 8, ini, mn)
+    orc = ol.OracleExtractor(nf, 1.2, 8, ini, mn)
+    k, d = ex(img)
+    ok, od = orc(img)
+    for l in range(8):
+        x, y, s = ex.debug_candidates(0, l)
+        ox, oy, os_ = orc.level_candidates(l)
+        np.testing.assert_array_equal(np.stack([x, y, s]), np.stack([ox, oy, os_]), err_msg=f"candidates of level {l} at ({ini}, {mn})")
+    np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
+    ex.close()
+
+
 @pytest.mark.parametrize("w,h,nf", [(91, 91, 300), (123, 95, 300), (1920, 1080, 4000), (2047, 211, 1500), (64, 64, 100)])
 def test_unusual_geometries(w, h, nf):
     """cell sizes at the extremes (one 59 x 59 cell per level; 64 x 34 cell rows of a full-HD frame; a strip), odd widths,
