@@ -571,12 +571,47 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
     //      recorded in the bitmap -- and at the end): exact score of list[0 .. n), the polarity (or, about once in 10^4, the
     //      two polarities) the quick test left possible
     auto score_list = [&](int n, bool mark, int th_cur) {
-      for (int i = lane; i < n; i += WAVE) {
-        const uint32_t en = list[i];
-        const int e = (int)(en & 0x3fffu);
-        const int y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
-        const int x = e - y * PB;
-        if (x >= c_hi) continue;   // the pair straddling the right edge of the tested region
+      // A pixel whose two polarities both survived the quick test (a blurred edge through the centre: 3-8 % of the survivors
+      // on the upper pyramid levels) needs both networks.  Running the second one under a wave-uniform branch cost a whole
+      // network whenever ANY of the 64 lanes had such a pixel -- nearly every round.  Instead the pixel is scored as dark here and
+      // appended to the list once more as bright-only (at most one of the two scores can reach the threshold: a ring has no room
+      // for two 9-arcs); only when the list is full does the second network run in place.
+      int n_end = n;
+      for (int done = 0; done < n_end;) {
+        const int start = done;
+        const int lim = min(start + WAVE, n_end);   // this round's entries
+        const int i = start + lane;
+        done = lim;
+        uint32_t en = i < lim ? list[i] : 0u;
+        int e = (int)(en & 0x3fffu);
+        int y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
+        int x = e - y * PB;
+        bool valid = i < lim && x < c_hi;   // not the pair straddling the right edge of the tested region
+        const bool both = valid && (en & 0xC000u) == 0xC000u;
+        const unsigned long long mb = __ballot(both);
+        bool second_here = false;
+        if (mb) {   // wave-uniform
+          const int nb = __popcll(mb);
+          if (n_end + nb <= FC_LIST_CAP) {
+            const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, (uint32_t)n_end));
+            if (both) list[r] = (uint16_t)((uint32_t)e | 0x4000u);
+            if (lim == n_end && lim - start + nb <= WAVE) {
+              // last round with idle lanes: they take the bright halves right away instead of forming a round of their own
+              if (i >= lim && i < lim + nb) {
+                en = list[i];
+                e = (int)(en & 0x3fffu);
+                y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
+                x = e - y * PB;
+                valid = true;
+              }
+              done = lim + nb;
+            }
+            n_end += nb;
+          } else {
+            second_here = true;
+          }
+        }
+        if (!valid) continue;
         // the centre and the sixteen ring bytes, packed in ring order as eight (q_2j, q_2j+1) pairs (d16 byte loads would
         // build the pairs for free, but with SRAM ECC they zero the other half of the register)
         // (addressed from the ring's top-left corner: every offset is then a non-negative immediate of ds_read_u8, where
@@ -590,10 +625,10 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         for (int j = 0; j < 8; j++)
           P[j] = (uint32_t)c[(RDY[2 * j] + 3) * PB + RDX[2 * j] + 3] | ((uint32_t)c[(RDY[2 * j + 1] + 3) * PB + RDX[2 * j + 1] + 3] << 16);
         const uint32_t VV = v | (v << 16);
-        const bool bright = (en & 0x4000u) != 0;
+        const bool bright = (en & 0xC000u) == 0x4000u;   // bright only; dark first where both are possible
         int s = arc9_maxmin_pk(P, VV, bright ? ~0u : 0u) + (bright ? 1 : 0);
-        if (__ballot((en & 0xC000u) == 0xC000u)) {   // both polarities survived the quick test (about once in 10^4): wave-uniform
-          if ((en & 0xC000u) == 0xC000u) s = max(s, arc9_maxmin_pk(P, VV, 0u));
+        if (second_here) {   // list full (wave-uniform): the bright network of the two-polarity pixels in place
+          if (both) s = max(s, arc9_maxmin_pk(P, VV, ~0u) + 1);
         }
         if (s - 1 >= th_cur) {
           const int ty = y - 3, tx = x - c_lo;
