@@ -609,3 +609,98 @@ def ref_search_for_initialization(keys1, desc1, F2, prev_matched, window, nnrati
         if vnMatches12[i1] >= 0:
             prev[i1] = (F2.x[vnMatches12[i1]], F2.y[vnMatches12[i1]])
     return nmatches, vnMatches12, prev
+
+
+def ref_compute_stereo_matches(keysL, descL, keysR, descR, pyrL, pyrR, scale_factors, inv_scale_factors, mbf, mb):
+    """Frame::ComputeStereoMatches (L/src/Frame.cc:477-646), second reading (per-row Python lists, numpy windows).  pyrL / pyrR:
+    lists of the level images of the two extractors' mvImagePyramid.  Returns (mvuRight, mvDepth) as float32 arrays.  Where the
+    reference would index out of range (rows outside the image, windows leaving a level) the keypoint gets no match."""
+    N = len(keysL)
+    mvuRight = np.full(N, -1.0, np.float32); mvDepth = np.full(N, -1.0, np.float32)
+    thOrbDist = (TH_HIGH + TH_LOW) // 2
+    nRows = pyrL[0].shape[0]
+    vRowIndices = [[] for _ in range(nRows)]
+    for iR in range(len(keysR)):
+        kpY = _f32(keysR["y"][iR])
+        r = _f32(2.0) * _f32(scale_factors[int(keysR["octave"][iR])])
+        maxr = int(math.ceil(kpY + r)); minr = int(math.floor(kpY - r))
+        for yi in range(minr, maxr + 1):
+            if 0 <= yi < nRows:
+                vRowIndices[yi].append(iR)
+    minZ = _f32(mb); minD = _f32(0); maxD = _f32(mbf) / minZ
+    vDistIdx = []
+    descR = np.asarray(descR, np.uint8)
+    for iL in range(N):
+        levelL = int(keysL["octave"][iL]); vL = _f32(keysL["y"][iL]); uL = _f32(keysL["x"][iL])
+        row = int(vL)
+        if row < 0 or row >= nRows:
+            continue
+        vCandidates = vRowIndices[row]
+        if not vCandidates:
+            continue
+        minU = uL - maxD; maxU = uL - minD
+        if maxU < 0:
+            continue
+        bestDist = TH_HIGH; bestIdxR = 0
+        for iR in vCandidates:
+            oR = int(keysR["octave"][iR])
+            if oR < levelL - 1 or oR > levelL + 1:
+                continue
+            uR = _f32(keysR["x"][iR])
+            if uR >= minU and uR <= maxU:
+                dist = descriptor_distance(descL[iL], descR[iR])
+                if dist < bestDist:
+                    bestDist = dist; bestIdxR = iR
+        if not (bestDist < thOrbDist):
+            continue
+        uR0 = _f32(keysR["x"][bestIdxR])
+        scaleFactor = _f32(inv_scale_factors[levelL])
+        scaleduL = _f32(c_round(uL * scaleFactor)); scaledvL = _f32(c_round(vL * scaleFactor)); scaleduR0 = _f32(c_round(uR0 * scaleFactor))
+        w = 5; L = 5
+        imL, imR = pyrL[levelL], pyrR[levelL]
+        y0, x0 = int(scaledvL - w), int(scaleduL - w)
+        if y0 < 0 or y0 + 2 * w + 1 > imL.shape[0] or x0 < 0 or x0 + 2 * w + 1 > imL.shape[1]:
+            continue      # cv::Mat::rowRange / colRange would throw
+        IL = imL[y0:y0 + 2 * w + 1, x0:x0 + 2 * w + 1].astype(np.float32)
+        IL = IL - IL[w, w]
+        iniu = scaleduR0 + _f32(L) - _f32(w); endu = scaleduR0 + _f32(L) + _f32(w) + _f32(1)
+        if iniu < 0 or endu >= imR.shape[1]:
+            continue
+        xr = int(scaleduR0)
+        if xr - L - w < 0 or xr + L + w + 1 > imR.shape[1] or y0 + 2 * w + 1 > imR.shape[0]:
+            continue
+        bestD = 2 ** 31 - 1; bestincR = 0
+        vDists = [0.0] * (2 * L + 1)
+        for incR in range(-L, L + 1):
+            IR = imR[y0:y0 + 2 * w + 1, xr + incR - w:xr + incR + w + 1].astype(np.float32)
+            IR = IR - IR[w, w]
+            dist = _f32(np.abs(IL - IR).sum(dtype=np.float64))     # NORM_L1 of integer-valued floats: exact
+            if dist < bestD:
+                bestD = int(dist); bestincR = incR
+            vDists[L + incR] = dist
+        if bestincR == -L or bestincR == L:
+            continue
+        dist1, dist2, dist3 = _f32(vDists[L + bestincR - 1]), _f32(vDists[L + bestincR]), _f32(vDists[L + bestincR + 1])
+        den = _f32(2.0) * (dist1 + dist3 - _f32(2.0) * dist2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            deltaR = (dist1 - dist3) / den
+        if deltaR < -1 or deltaR > 1:
+            continue
+        bestuR = _f32(scale_factors[levelL]) * (scaleduR0 + _f32(bestincR) + deltaR)
+        disparity = uL - bestuR
+        if disparity >= minD and disparity < maxD:
+            if disparity <= 0:
+                disparity = _f32(0.01)
+                bestuR = _f32(float(uL) - 0.01)
+            mvDepth[iL] = _f32(mbf) / disparity
+            mvuRight[iL] = bestuR
+            vDistIdx.append((bestD, iL))
+    if vDistIdx:
+        vDistIdx.sort()
+        median = _f32(vDistIdx[len(vDistIdx) // 2][0])
+        thDist = _f32(1.5) * _f32(1.4) * median
+        for i in range(len(vDistIdx) - 1, -1, -1):
+            if vDistIdx[i][0] < thDist:
+                break
+            mvuRight[vDistIdx[i][1]] = -1; mvDepth[vDistIdx[i][1]] = -1
+    return mvuRight, mvDepth

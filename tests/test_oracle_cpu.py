@@ -501,3 +501,20 @@ def test_matcher_loops_agree_with_second_reading_on_ties():
     ur = np.array([0.0, -1.0, 5.0, 0.0, 120.25], np.float32)[rng.integers(0, 5, len(kB))]
     assert _check_matchers(kA, dA, kB, dB, sf, w, h, ur, 7) >= 0
     assert _check_matchers(kA, dA, kA.copy(), dA.copy(), sf, w, h, None, 8) >= 0
+
+
+def test_stereo_matches_agree_with_second_reading():
+    """oo_compute_stereo_matches (C oracle) == the independent Python reading of Frame::ComputeStereoMatches on a synthetic
+    stereo pair (disparities 5 .. 60 px, all levels), including the median cut."""
+    w, h, nf = 640, 360, 800
+    L, R = synth.stereo_pair(w, h, seq=41, f=2)
+    oL, oR = ol.OracleExtractor(nf), ol.OracleExtractor(nf)
+    kL, dL = oL(L); kR, dR = oR(R)
+    pL = [oL.level_pixels(l).copy() for l in range(8)]; pR = [oR.level_pixels(l).copy() for l in range(8)]
+    sf, isf = oL.scale_factors, oL.inv_scale_factors
+    for mbf, mb in ((np.float32(386.1448), np.float32(386.1448 / 718.856)), (np.float32(47.9), np.float32(0.11))):
+        n, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, pL, pR, sf, isf, float(mbf), float(mb))
+        rur, rdepth = nr.ref_compute_stereo_matches(kL, dL, kR, dR, pL, pR, sf, isf, mbf, mb)
+        np.testing.assert_array_equal(ur, rur)
+        np.testing.assert_array_equal(depth, rdepth)
+        assert (ur >= 0).sum() > 150
