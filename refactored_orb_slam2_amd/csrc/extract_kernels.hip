@@ -1168,8 +1168,8 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 // memory request per window row in a row-major plane (~55 per keypoint).  They are therefore stored TILED: 16 pixels x 8 rows
 // = one 128-byte line, tiles in raster order (pitch / 16 tiles per tile row).  A window then touches ~4 x 6 tiles.
 // Byte offset of pixel (x, y); x, y >= 0:
-__device__ __forceinline__ size_t blur_tiled_offset(int x, int y, int pitch) {
-  return ((size_t)(y >> 3) * (size_t)(pitch >> 4) + (size_t)(x >> 4)) * 128 + (size_t)((y & 7) * 16 + (x & 15));
+__device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {   // a plane is < 2^25 bytes (4095 x 4095)
+  return (((uint32_t)(y >> 3) * (uint32_t)(pitch >> 4) + (uint32_t)(x >> 4)) << 7) + (uint32_t)((y & 7) * 16 + (x & 15));
 }
 // 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps [18,34,48,56,48,34,18], exact 16.16 accumulation,
 // round half up.  One 64x32 output tile per workgroup, separable through LDS.  Interior tiles stage the
@@ -1292,9 +1292,10 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     const uint32_t outE = __builtin_amdgcn_perm(aE[1], aE[0], 0x0c0c0602u) | __builtin_amdgcn_perm(aE[3], aE[2], 0x06020c0cu);
     const uint32_t outO = __builtin_amdgcn_perm(aO[1], aO[0], 0x0c0c0602u) | __builtin_amdgcn_perm(aO[3], aO[2], 0x06020c0cu);
     const int gy = oy + 2 * rp, gx = ox + 4 * g;
-    if (gx < w) {   // gx is a multiple of 4: the four pixels lie in one tile row
-      if (gy < h) *reinterpret_cast<uint32_t*>(D + blur_tiled_offset(gx, gy, dst.pitch[lvl])) = outE;
-      if (gy + 1 < h) *reinterpret_cast<uint32_t*>(D + blur_tiled_offset(gx, gy + 1, dst.pitch[lvl])) = outO;
+    if (gx < w) {   // gx is a multiple of 4: the four pixels lie in one tile row; gy is even: row gy + 1 is the next row of the same tile
+      uint8_t* o = D + blur_tiled_offset(gx, gy, dst.pitch[lvl]);
+      if (gy < h) *reinterpret_cast<uint32_t*>(o) = outE;
+      if (gy + 1 < h) *reinterpret_cast<uint32_t*>(o + 16) = outO;
     }
     }
   }
