@@ -1391,7 +1391,9 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 // (a, b) read from lane k.  The moments use v_dot4_u32_u8: a lane owns four (row, 4-column) items of the disc, the per-item
 // weights (u + 15, v + 15 and 1 inside the disc, 0 outside; a host-filled table) stay in registers for all eight keypoints, and
 // m10 = sum (u+15) I - 15 sum I, m01 = sum (v+15) I - 15 sum I -- integer, hence the same moments as the reference's loops.
+#ifndef OD_K
 #define OD_K 8
+#endif
 #if FC_TIMING
 __device__ unsigned long long g_od_prof[4096 * 8];
 extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
@@ -1472,7 +1474,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       P.out_n[img] = tot;
     }
   }
-  const unsigned valid_mask = (unsigned)(__ballot(i_out >= 0) & 0xffu);
+  const unsigned valid_mask = (unsigned)(__ballot(i_out >= 0) & ((1ull << OD_K) - 1ull));
   if (valid_mask == 0) return;
   FC_T(0);   // tables + slot bookkeeping
 
