@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -78,6 +79,12 @@ struct orbfe_extractor {
   int feat_per_level[ORBFE_MAX_LEVELS]{};
   // plan (depends on image geometry)
   int plan_w = 0, plan_h = 0;
+  // latency path (one or two host images): the 13 dependent launches of a call, captured once per geometry as a hipGraph
+  struct LaunchGraph {
+    hipGraphExec_t exec = nullptr;
+    int w = 0, h = 0, cap = 0, warm = 0;
+    unsigned long long epoch = 0;
+  } graphs[2];
   // level 0 of the last device batch when the caller's images could be used in place (16-byte aligned rows): no pitched copy
   const uint8_t* ext0 = nullptr;
   int ext0_pitch = 0;
@@ -117,8 +124,11 @@ struct orbfe_extractor {
   std::mutex mu;
 };
 
+// bumped whenever any buffer of any handle is (re)allocated: captured launch graphs hold raw pointers and are re-captured then
+static std::atomic<unsigned long long> g_alloc_epoch{1};
 static int dev_alloc(DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes && b.p) return ORBFE_OK;
+  g_alloc_epoch.fetch_add(1);
   if (b.p) HIPCHK(hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
@@ -129,6 +139,7 @@ static int dev_alloc(DevBuf& b, size_t bytes) {
 }
 static int pinned_alloc(void*& p, size_t& have, size_t bytes) {
   if (p && bytes <= have) return ORBFE_OK;
+  g_alloc_epoch.fetch_add(1);
   if (p) HIPCHK(hipHostFree(p));
   p = nullptr;
   have = 0;
@@ -632,6 +643,8 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   drain_events(e);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (auto& g : e->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   DevBuf* bufs[] = {&e->d_cells, &e->d_groups, &e->d_groups1, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
                     &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
   for (auto b : bufs) dev_free(*b);
@@ -784,16 +797,60 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
   e->ext0 = nullptr;   // host images are staged and copied into the pitched level-0 planes
   uint8_t* ho = (uint8_t*)e->h_out;
   if (!zc) HIPCHK(hipMemcpyAsync(e->d_in_stage.p, e->h_in, img_bytes * B, hipMemcpyHostToDevice, s));
-  {
-    StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
-    orbfe_launch_copy0((const uint8_t*)(zc ? e->h_in : e->d_in_stage.p), w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch,
-                       e->lg[0].plane, w, h, n_images, s);
-  }
   int32_t* d_hdr = (int32_t*)e->d_out_n.p;
-  if (zc) {
-    if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)(ho + hdr_bytes), ho + hdr_bytes + kp_bytes, cap, (int32_t*)ho, s))) return rc;
+  // the latency path's launches: level-0 copy out of the pinned staging buffer, the pipeline, the device error word
+  auto launch_zc = [&]() -> int {
+    {
+      StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
+      orbfe_launch_copy0((const uint8_t*)e->h_in, w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w, h,
+                         n_images, s);
+    }
+    int r = enqueue_pipeline(e, n_images, (orbfe_keypoint*)(ho + hdr_bytes), ho + hdr_bytes + kp_bytes, cap, (int32_t*)ho, s);
+    if (r) return r;
     HIPCHK(hipMemcpyAsync(ho + sizeof(int32_t) * B, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return ORBFE_OK;
+  };
+  if (zc) {
+    // Every pointer these launches take belongs to the handle (pinned staging in and out, work space), so the whole sequence is
+    // captured once per (geometry, capacity) into a hipGraph and replayed: one submission instead of thirteen dependent ones.
+    // The first calls launch directly (module loading and attribute calls stay outside the capture); any allocation re-captures.
+    orbfe_extractor::LaunchGraph& g = e->graphs[n_images - 1];
+    const unsigned long long epoch = g_alloc_epoch.load();
+    const bool same = g.w == w && g.h == h && g.cap == cap && g.epoch == epoch;
+    if (!same) {
+      if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+      g.w = w; g.h = h; g.cap = cap; g.epoch = epoch; g.warm = 0;
+    }
+    bool launched = false;
+    if (!e->profile && g.warm >= 2) {
+      if (!g.exec) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int r = launch_zc();
+          const hipError_t ce = hipStreamEndCapture(s, &graph);
+          if (r == ORBFE_OK && ce == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess)
+            g.exec = nullptr;
+          if (graph) (void)hipGraphDestroy(graph);
+          if (r != ORBFE_OK || ce != hipSuccess) g.exec = nullptr;
+        }
+        (void)hipGetLastError();
+        if (!g.exec) g.warm = -1000000;   // capture is not available here: direct launches from now on
+      }
+      if (g.exec) {
+        HIPCHK(hipGraphLaunch(g.exec, s));
+        launched = true;
+      }
+    }
+    if (!launched) {
+      if ((rc = launch_zc())) return rc;
+      g.warm++;
+    }
   } else {
+    {
+      StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
+      orbfe_launch_copy0((const uint8_t*)e->d_in_stage.p, w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w,
+                         h, n_images, s);
+    }
     if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap, d_hdr, s)))
       return rc;
     // results: header (counts + device error word) and the full padded records, one sync
