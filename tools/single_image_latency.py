@@ -3,6 +3,8 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from refactored_orb_slam2_amd import _lib
+if os.environ.get("ORBFE_AB_LIB"): _lib.LIB_PATH = os.path.join(_lib.CSRC, "_ab", "liborbfe_%s.so" % os.environ["ORBFE_AB_LIB"])
 from refactored_orb_slam2_amd import ORBextractor, synth
 
 for (w, h, nf) in ((1241, 376, 2000), (640, 480, 1000)):
