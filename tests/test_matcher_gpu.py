@@ -1031,3 +1031,33 @@ def test_mono_sequence_driver_on_kitti_layout(tmp_path):
         assert int(g[f"nm_{i}"]) == nm, (i, int(g[f"nm_{i}"]), nm)
         np.testing.assert_array_equal(g[f"m12_{i}"], m12, err_msg=f"vnMatches12 of frame {i}")
     assert states[:5] == ["reference", "matched", "matched", "reset", "reference"] and states[5] == "matched", states
+
+
+@pytest.mark.parametrize("geom", [(1241, 376, 2000), (752, 480, 1200)])
+def test_stereo_matches_one_pair_host_api(geom):
+    """orbfe_stereo_match: the per-frame call of Frame::Frame (L/src/Frame.cc:91-99) -- two host-API extractions, then the stereo
+    association on the pyramids still in HBM, host keypoints in, mvuRight / mvDepth out -- against oo_compute_stereo_matches and
+    against the independent Python reading; degenerate inputs (no right keypoints, mb <= 0) behave as documented."""
+    from refactored_orb_slam2_amd.matcher import compute_stereo_matches
+    from refactored_orb_slam2_amd import _lib
+    from tests import np_restatement as nr
+    w, h, nf = geom
+    L, R = synth.stereo_pair(w, h, seq=14, f=3)
+    exL, exR = ORBextractor(nf), ORBextractor(nf)
+    kL, dL = exL(L); kR, dR = exR(R)
+    mbf, mb = np.float32(386.1448), np.float32(386.1448 / 718.856)
+    nm, ur, depth = compute_stereo_matches(exL, exR, kL, dL, kR, dR, mbf, mb)
+    oL, oR = ol.OracleExtractor(nf), ol.OracleExtractor(nf)
+    okL, odL = oL(L); okR, odR = oR(R)
+    pL = [oL.level_pixels(l).copy() for l in range(8)]; pR = [oR.level_pixels(l).copy() for l in range(8)]
+    _, our, odepth = ol.compute_stereo_matches(okL, odL, okR, odR, pL, pR, oL.scale_factors, oL.inv_scale_factors, float(mbf), float(mb))
+    np.testing.assert_array_equal(ur, our); np.testing.assert_array_equal(depth, odepth)
+    assert nm == int((our >= 0).sum()) and nm > len(kL) // 3
+    if w < 1000:   # the second reading is pure Python: the smaller geometry only
+        rur, rdepth = nr.ref_compute_stereo_matches(okL, odL, okR, odR, pL, pR, oL.scale_factors, oL.inv_scale_factors, mbf, mb)
+        np.testing.assert_array_equal(ur, rur); np.testing.assert_array_equal(depth, rdepth)
+    nm0, ur0, depth0 = compute_stereo_matches(exL, exR, kL, dL, kR[:0], dR[:0], mbf, mb)
+    assert nm0 == 0 and np.all(ur0 == -1) and np.all(depth0 == -1)
+    with pytest.raises(_lib.OrbfeError):
+        compute_stereo_matches(exL, exR, kL, dL, kR, dR, mbf, 0.0)
+    exL.close(); exR.close()
