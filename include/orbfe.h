@@ -230,7 +230,8 @@ int orbfe_proj_candidates(const orbfe_frame_view* frame, const orbfe_query* q, i
  * *n_matches = return value of the reference.  HOST pointers, synchronous. */
 int orbfe_search_by_projection_points(const orbfe_frame_view* frame, const orbfe_query* q, int nq, float nnratio,
                                       uint8_t* blocked, int32_t* assigned, int* n_matches);
-/* SearchByProjection(Frame& cur, const Frame& last, th, bMono) (L/src/ORBmatcher.cc:1247-1383). */
+/* SearchByProjection(Frame& cur, const Frame& last, th, bMono) (L/src/ORBmatcher.cc:1247-1383).  A slot the rotation check clears
+ * (:1372 mvpMapPoints[...] = NULL) leaves with assigned = -1 and blocked = 0, as in the reference's frame. */
 int orbfe_search_by_projection_frame(const orbfe_frame_view* cur, const orbfe_query* q, int nq,
                                      int check_orientation, uint8_t* blocked, int32_t* assigned, int* n_matches);
 

@@ -979,7 +979,7 @@ int oo_search_by_projection_frame(const oo_frame* cur, const oo_query* q, int nq
     oo_three_maxima(rh.n, OO_HISTO_LENGTH, &i1, &i2, &i3);
     for (int i = 0; i < OO_HISTO_LENGTH; i++)
       if (i != i1 && i != i2 && i != i3)
-        for (int j = 0; j < rh.n[i]; j++) { assigned[rh.v[i][j]] = -1; nmatches--; }
+        for (int j = 0; j < rh.n[i]; j++) { assigned[rh.v[i][j]] = -1; blocked[rh.v[i][j]] = 0; nmatches--; }   /* the slot is NULL again */
   }
   rh_free(&rh);
   free(vIndices);
@@ -1163,7 +1163,7 @@ int oo_search_by_projection_keyframe(const oo_frame* cur, const oo_query* q, int
     oo_three_maxima(rh.n, OO_HISTO_LENGTH, &i1, &i2, &i3);
     for (int i = 0; i < OO_HISTO_LENGTH; i++)
       if (i != i1 && i != i2 && i != i3)
-        for (int j = 0; j < rh.n[i]; j++) { assigned[rh.v[i][j]] = -1; nmatches--; }
+        for (int j = 0; j < rh.n[i]; j++) { assigned[rh.v[i][j]] = -1; mappoint_set[rh.v[i][j]] = 0; nmatches--; }   /* :1496 = NULL */
   }
   rh_free(&rh);
   free(vIndices2);

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
     int removed = 0;
     for (int k = tid; k < np; k += RC_THREADS) {
       const int bin = push_bin[k];
-      if (bin != i1 && bin != i2 && bin != i3) { assigned[push_idx[k]] = -1; removed++; }
+      if (bin != i1 && bin != i2 && bin != i3) { assigned[push_idx[k]] = -1; blocked[push_idx[k]] = 0; removed++; }   // the slot is NULL again
     }
     if (removed) atomicSub(&sh_nm, removed);
   }

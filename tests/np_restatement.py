@@ -431,7 +431,8 @@ def ref_search_by_projection_points(F, points, nnratio, has_observed_point):
     """SearchByProjection(Frame&, vector<MapPoint*>&, th) (:45-128).  points: list of dicts with the MapPoint fields the loop
     reads after the caller's part -- skip (= !mbTrackInView || isBad()), proj_x, proj_y, proj_xr, level, radius
     (= r * mvScaleFactors[level]), observed (Observations() > 0), desc.  has_observed_point[idx]: F.mvpMapPoints[idx] exists
-    with Observations() > 0 before the call.  Returns (nmatches, point index per keypoint or -1)."""
+    with Observations() > 0 before the call.  Returns (nmatches, point index per keypoint or -1, and per keypoint whether
+    F.mvpMapPoints[idx] holds a point with Observations() > 0 after the call)."""
     mvpMapPoints = [None] * F.N                      # index of the point written by this call
     pre = list(has_observed_point)
     nmatches = 0
@@ -465,14 +466,17 @@ def ref_search_by_projection_points(F, points, nnratio, has_observed_point):
             mvpMapPoints[bestIdx] = iMP
             pre[bestIdx] = False
             nmatches += 1
-    return nmatches, [(-1 if v is None else v) for v in mvpMapPoints]
+    after = [bool(points[c]["observed"]) if c is not None else bool(pre[i]) for i, c in enumerate(mvpMapPoints)]
+    return nmatches, [(-1 if v is None else v) for v in mvpMapPoints], after
 
 
 def ref_search_by_projection_frame(F, last, check_orientation, has_observed_point):
     """SearchByProjection(Frame& cur, const Frame& last, th, bMono) from the window search on (:1289-1383).  last: list of
     dicts per LastFrame keypoint -- skip (no point / outlier / behind the camera / outside the image), u, v, ur
     (= u - mbf * invzc), radius, min_level, max_level (the bForward / bBackward / default choice made by the caller),
-    observed, angle (LastFrame.mvKeysUn[i].angle), desc."""
+    observed, angle (LastFrame.mvKeysUn[i].angle), desc.  Returns (nmatches, last-frame index per keypoint or -1, and per
+    keypoint whether CurrentFrame.mvpMapPoints[idx] holds a point with Observations() > 0 after the call -- a slot the rotation
+    check cleared is NULL again)."""
     mvpMapPoints = [None] * F.N
     pre = list(has_observed_point)
     rotHist = [[] for _ in range(HISTO_LENGTH)]
@@ -509,7 +513,8 @@ def ref_search_by_projection_frame(F, last, check_orientation, has_observed_poin
             for idx in rotHist[b]:
                 mvpMapPoints[idx] = -1          # static_cast<MapPoint*>(NULL)
                 nmatches -= 1
-    return nmatches, [(-1 if v is None else v) for v in mvpMapPoints]
+    after = [(c >= 0 and bool(last[c]["observed"])) if c is not None else bool(pre[i]) for i, c in enumerate(mvpMapPoints)]
+    return nmatches, [(-1 if v is None else v) for v in mvpMapPoints], after
 
 
 def ref_search_by_bow(descKF, angleKF, validKF, featvecKF, descF, angleF, featvecF, nnratio, check_orientation):
@@ -557,6 +562,132 @@ def ref_search_by_bow(descKF, angleKF, validKF, featvecKF, descF, angleF, featve
                 matches[j] = -1
                 nmatches -= 1
     return nmatches, matches
+
+
+def _featvec_walk(fvA, fvB):
+    """The lock-step walk over two DBoW2::FeatureVector maps (ascending node ids, lower_bound on a mismatch): yields the lists of
+    feature indices of every node both hold."""
+    idsA, idsB = sorted(fvA), sorted(fvB)
+    a = b = 0
+    while a < len(idsA) and b < len(idsB):
+        if idsA[a] == idsB[b]:
+            yield fvA[idsA[a]], fvB[idsB[b]]
+            a += 1
+            b += 1
+        elif idsA[a] < idsB[b]:
+            while a < len(idsA) and idsA[a] < idsB[b]:
+                a += 1
+        else:
+            while b < len(idsB) and idsB[b] < idsA[a]:
+                b += 1
+
+
+def ref_search_by_bow_kf(desc1, angle1, valid1, featvec1, desc2, angle2, valid2, featvec2, nnratio, check_orientation):
+    """SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (:494-612).  valid*[i]: the keyframe's map point i exists and is not
+    bad.  Returns (nmatches, index in keyframe 2 per feature of keyframe 1 or -1)."""
+    vpMatches12 = [-1] * len(desc1)
+    vbMatched2 = [False] * len(desc2)
+    rotHist = [[] for _ in range(HISTO_LENGTH)]
+    nmatches = 0
+    for node1, node2 in _featvec_walk(featvec1, featvec2):
+        for idx1 in node1:
+            if not valid1[idx1]:
+                continue
+            bestDist1, bestIdx2, bestDist2 = 256, -1, 256
+            for idx2 in node2:
+                if vbMatched2[idx2] or not valid2[idx2]:
+                    continue
+                dist = descriptor_distance(desc1[idx1], desc2[idx2])
+                if dist < bestDist1:
+                    bestDist2, bestDist1, bestIdx2 = bestDist1, dist, idx2
+                elif dist < bestDist2:
+                    bestDist2 = dist
+            if bestDist1 < TH_LOW:
+                if _f32(bestDist1) < _f32(nnratio) * _f32(bestDist2):
+                    vpMatches12[idx1] = bestIdx2
+                    vbMatched2[bestIdx2] = True
+                    if check_orientation:
+                        rotHist[_rot_bin(angle1[idx1], angle2[bestIdx2])].append(idx1)
+                    nmatches += 1
+    if check_orientation:
+        ind = compute_three_maxima([len(h) for h in rotHist])
+        for i in range(HISTO_LENGTH):
+            if i in ind:
+                continue
+            for j in rotHist[i]:
+                vpMatches12[j] = -1
+                nmatches -= 1
+    return nmatches, vpMatches12
+
+
+def check_dist_epipolar_line(x1, y1, x2, y2, octave2, F12, level_sigma2):
+    """ORBmatcher::CheckDistEpipolarLine (:137-159): float products and sums left to right, the last comparison in double (3.84
+    is a double constant)."""
+    F = [[_f32(F12[r][c]) for c in range(3)] for r in range(3)]
+    x1, y1, x2, y2 = _f32(x1), _f32(y1), _f32(x2), _f32(y2)
+    a = x1 * F[0][0] + y1 * F[1][0] + F[2][0]
+    b = x1 * F[0][1] + y1 * F[1][1] + F[2][1]
+    c = x1 * F[0][2] + y1 * F[1][2] + F[2][2]
+    num = a * x2 + b * y2 + c
+    den = a * a + b * b
+    if den == 0:
+        return False
+    dsqr = num * num / den
+    return float(dsqr) < 3.84 * float(_f32(level_sigma2[octave2]))
+
+
+def ref_search_for_triangulation(keys1, desc1, u_right1, has_mp1, featvec1, keys2, desc2, u_right2, has_mp2, featvec2, F12, ex, ey,
+                                 scale_factors, level_sigma2, only_stereo, check_orientation):
+    """SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (:614-764) after the epipole (ex, ey) has been formed.
+    u_right*: mvuRight or None (monocular: every value -1).  vbMatched2 is read but never set by the reference -- kept so.  Returns
+    (nmatches, vMatches12)."""
+    n1, n2 = len(keys1), len(keys2)
+    ur1 = [_f32(-1)] * n1 if u_right1 is None else [_f32(v) for v in u_right1]
+    ur2 = [_f32(-1)] * n2 if u_right2 is None else [_f32(v) for v in u_right2]
+    ex, ey = _f32(ex), _f32(ey)
+    vbMatched2 = [False] * n2
+    vMatches12 = [-1] * n1
+    rotHist = [[] for _ in range(HISTO_LENGTH)]
+    nmatches = 0
+    for node1, node2 in _featvec_walk(featvec1, featvec2):
+        for idx1 in node1:
+            if has_mp1[idx1]:
+                continue
+            bStereo1 = ur1[idx1] >= 0
+            if only_stereo and not bStereo1:
+                continue
+            bestDist, bestIdx2 = TH_LOW, -1
+            for idx2 in node2:
+                if vbMatched2[idx2] or has_mp2[idx2]:
+                    continue
+                bStereo2 = ur2[idx2] >= 0
+                if only_stereo and not bStereo2:
+                    continue
+                dist = descriptor_distance(desc1[idx1], desc2[idx2])
+                if dist > TH_LOW or dist > bestDist:
+                    continue
+                x2, y2, o2 = _f32(keys2["x"][idx2]), _f32(keys2["y"][idx2]), int(keys2["octave"][idx2])
+                if not bStereo1 and not bStereo2:
+                    distex = ex - x2
+                    distey = ey - y2
+                    if distex * distex + distey * distey < _f32(100) * _f32(scale_factors[o2]):
+                        continue
+                if check_dist_epipolar_line(keys1["x"][idx1], keys1["y"][idx1], x2, y2, o2, F12, level_sigma2):
+                    bestIdx2, bestDist = idx2, dist
+            if bestIdx2 >= 0:
+                vMatches12[idx1] = bestIdx2
+                nmatches += 1
+                if check_orientation:
+                    rotHist[_rot_bin(keys1["angle"][idx1], keys2["angle"][bestIdx2])].append(idx1)
+    if check_orientation:
+        ind = compute_three_maxima([len(h) for h in rotHist])
+        for i in range(HISTO_LENGTH):
+            if i in ind:
+                continue
+            for j in rotHist[i]:
+                vMatches12[j] = -1
+                nmatches -= 1
+    return nmatches, vMatches12
 
 
 def ref_search_for_initialization(keys1, desc1, F2, prev_matched, window, nnratio, check_orientation):
@@ -704,3 +835,288 @@ def ref_compute_stereo_matches(keysL, descL, keysR, descR, pyrL, pyrR, scale_fac
                 break
             mvuRight[vDistIdx[i][1]] = -1; mvDepth[vDistIdx[i][1]] = -1
     return mvuRight, mvDepth
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Second reading of the keyframe-rate projection searches (Fuse x2, SearchBySim3, SearchByProjection(KF, Scw) and
+# SearchByProjection(Frame, KF)).  cv::Mat arithmetic as DESIGN.md's primitive list has it (the same assumptions as the C
+# oracle -- this reading checks the loops, gates and orders, not OpenCV's kernels): A * x + b on 3x3 / 3x1 CV_32F = float dot
+# products, the sum with b in double, rounded once; cv::norm and Mat::dot accumulate in double.  logf comes from the C library
+# (MapPoint::PredictScale calls std::log on a float).
+import ctypes as _ct
+import ctypes.util as _ctu
+
+_libm = _ct.CDLL(_ctu.find_library("m") or "libm.so.6")
+_libm.logf.restype = _ct.c_float
+_libm.logf.argtypes = [_ct.c_float]
+
+
+def _gemm3(R, x, t):
+    out = []
+    for r in range(3):
+        d = _f32(R[3 * r]) * _f32(x[0]) + _f32(R[3 * r + 1]) * _f32(x[1]) + _f32(R[3 * r + 2]) * _f32(x[2])
+        out.append(_f32(float(d) * 1.0 + float(_f32(t[r])) * 1.0))
+    return out
+
+
+def _norm3(v):
+    s = 0.0
+    for e in v:
+        s += float(e) * float(e)
+    return _f32(math.sqrt(s))
+
+
+def _dot3(a, b):
+    s = 0.0
+    for x, y in zip(a, b):
+        s += float(x) * float(y)
+    return s
+
+
+def predict_scale(max_distance, current_dist, log_scale_factor, n_levels):
+    """MapPoint::PredictScale (MapPoint.cc:393-423): ceil(logf(ratio) / mfLogScaleFactor) in float, clamped."""
+    ratio = _f32(max_distance) / _f32(current_dist)
+    n = int(math.ceil(_f32(_libm.logf(float(ratio))) / _f32(log_scale_factor)))
+    return 0 if n < 0 else (n_levels - 1 if n >= n_levels else n)
+
+
+def _kf_in_image(cam, u, v):
+    """KeyFrame::IsInImage (KeyFrame.cc:569-571)."""
+    return u >= cam["min_x"] and u < cam["max_x"] and v >= cam["min_y"] and v < cam["max_y"]
+
+
+def _pinhole(cam, pc, double_invz):
+    """u, v of a camera-frame point.  `1 / z` is a float division in Fuse and SearchByProjection(KF, Scw) (:797, :317), `1.0 / z` a
+    double one in Fuse(Sim3) and SearchBySim3 (:945, :1083)."""
+    invz = _f32(1.0 / float(pc[2])) if double_invz else _f32(1) / pc[2]
+    x = pc[0] * invz
+    y = pc[1] * invz
+    return cam["fx"] * x + cam["cx"], cam["fy"] * y + cam["cy"], invz
+
+
+def _viewing_gates(cam, p):
+    """dist3D inside [0.8 min, 1.2 max] and PO . Pn >= 0.5 dist3D; returns dist3D or None."""
+    PO = [_f32(p["pos"][k]) - _f32(cam["Ow"][k]) for k in range(3)]
+    dist3D = _norm3(PO)
+    if dist3D < _f32(0.8) * _f32(p["min_distance"]) or dist3D > _f32(1.2) * _f32(p["max_distance"]):
+        return None
+    if _dot3(PO, [_f32(v) for v in p["normal"]]) < 0.5 * float(dist3D):
+        return None
+    return dist3D
+
+
+def _cam_f32(cam):
+    c = {k: (_f32(v) if np.ndim(v) == 0 and k != "n_levels" else v) for k, v in cam.items()}
+    c["n_levels"] = int(cam["n_levels"])
+    return c
+
+
+def ref_fuse(KF, inv_level_sigma2, cam, points):
+    """Fuse(KeyFrame*, vpMapPoints, th) (:766-912) up to the map update: per point the keypoint the reference acts on (bestIdx when
+    bestDist <= TH_LOW is the caller's test; here (bestIdx, bestDist) or (-1, 256)).  KF: RefFrame of the keyframe (the grid is the
+    Frame's); points[i]: pos, normal, min_distance, max_distance, skip (NULL / isBad / IsInKeyFrame), desc."""
+    cam = _cam_f32(cam)
+    out = []
+    for p in points:
+        res = (-1, 256)
+        out.append(res)
+        if p["skip"]:
+            continue
+        pc = _gemm3(cam["R"], p["pos"], cam["t"])
+        if pc[2] < _f32(0.0):
+            continue
+        u, v, invz = _pinhole(cam, pc, False)
+        if not _kf_in_image(cam, u, v):
+            continue
+        ur = u - cam["mbf"] * invz
+        dist3D = _viewing_gates(cam, p)
+        if dist3D is None:
+            continue
+        lvl = predict_scale(p["max_distance"], dist3D, cam["log_scale_factor"], cam["n_levels"])
+        radius = cam["th"] * _f32(cam["scale_factors"][lvl])
+        vIndices = KF.GetFeaturesInArea(u, v, radius)
+        if not vIndices:
+            continue
+        bestDist, bestIdx = 256, -1
+        for idx in vIndices:
+            kpLevel = KF.octave[idx]
+            if kpLevel < lvl - 1 or kpLevel > lvl:
+                continue
+            ex = u - KF.x[idx]
+            ey = v - KF.y[idx]
+            if KF.u_right is not None and KF.u_right[idx] >= 0:
+                er = ur - KF.u_right[idx]
+                e2 = ex * ex + ey * ey + er * er
+                if float(e2 * _f32(inv_level_sigma2[kpLevel])) > 7.8:
+                    continue
+            else:
+                e2 = ex * ex + ey * ey
+                if float(e2 * _f32(inv_level_sigma2[kpLevel])) > 5.99:
+                    continue
+            dist = descriptor_distance(p["desc"], KF.desc[idx])
+            if dist < bestDist:
+                bestDist, bestIdx = dist, idx
+        out[-1] = (bestIdx, bestDist if bestIdx >= 0 else 256)
+    return out
+
+
+def ref_fuse_sim3(KF, cam, points):
+    """Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:914-1041) after Scw has been decomposed (cam: R, t, Ow), up to the map
+    update.  skip = isBad() or already a point of the keyframe."""
+    cam = _cam_f32(cam)
+    out = []
+    for p in points:
+        out.append((-1, 256))
+        if p["skip"]:
+            continue
+        pc = _gemm3(cam["R"], p["pos"], cam["t"])
+        if pc[2] < _f32(0.0):
+            continue
+        u, v, _ = _pinhole(cam, pc, True)
+        if not _kf_in_image(cam, u, v):
+            continue
+        dist3D = _viewing_gates(cam, p)
+        if dist3D is None:
+            continue
+        lvl = predict_scale(p["max_distance"], dist3D, cam["log_scale_factor"], cam["n_levels"])
+        vIndices = KF.GetFeaturesInArea(u, v, cam["th"] * _f32(cam["scale_factors"][lvl]))
+        if not vIndices:
+            continue
+        bestDist, bestIdx = 2 ** 31 - 1, -1
+        for idx in vIndices:
+            if KF.octave[idx] < lvl - 1 or KF.octave[idx] > lvl:
+                continue
+            dist = descriptor_distance(p["desc"], KF.desc[idx])
+            if dist < bestDist:
+                bestDist, bestIdx = dist, idx
+        out[-1] = (bestIdx, bestDist if bestIdx >= 0 else 256)
+    return out
+
+
+def ref_search_by_sim3_dir(KF, cam, points):
+    """One direction of SearchBySim3 (:1063-1146; :1149-1222 with the roles swapped): cam R/t = the source keyframe's pose, R2/t2 =
+    sR21 / t21; no viewing-angle gate, the distance is that of the point in the target camera."""
+    cam = _cam_f32(cam)
+    out = []
+    for p in points:
+        out.append((-1, 256))
+        if p["skip"]:
+            continue
+        pc1 = _gemm3(cam["R"], p["pos"], cam["t"])
+        pc2 = _gemm3(cam["R2"], pc1, cam["t2"])
+        if float(pc2[2]) < 0.0:
+            continue
+        u, v, _ = _pinhole(cam, pc2, True)
+        if not _kf_in_image(cam, u, v):
+            continue
+        dist3D = _norm3(pc2)
+        if dist3D < _f32(0.8) * _f32(p["min_distance"]) or dist3D > _f32(1.2) * _f32(p["max_distance"]):
+            continue
+        lvl = predict_scale(p["max_distance"], dist3D, cam["log_scale_factor"], cam["n_levels"])
+        vIndices = KF.GetFeaturesInArea(u, v, cam["th"] * _f32(cam["scale_factors"][lvl]))
+        if not vIndices:
+            continue
+        bestDist, bestIdx = 2 ** 31 - 1, -1
+        for idx in vIndices:
+            if KF.octave[idx] < lvl - 1 or KF.octave[idx] > lvl:
+                continue
+            dist = descriptor_distance(p["desc"], KF.desc[idx])
+            if dist < bestDist:
+                bestDist, bestIdx = dist, idx
+        out[-1] = (bestIdx, bestDist if bestIdx >= 0 else 256)
+    return out
+
+
+def ref_search_by_projection_kf_scw(KF, cam, points, matched, th_low=TH_LOW):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:275-386) after the decomposition of Scw.  matched[idx]:
+    vpMatched[idx] != NULL on entry.  Returns (nmatches, keypoint index written per point or -1, updated matched)."""
+    cam = _cam_f32(cam)
+    vpMatched = [bool(m) for m in matched]
+    written = []
+    nmatches = 0
+    for p in points:
+        written.append(-1)
+        if p["skip"]:
+            continue
+        pc = _gemm3(cam["R"], p["pos"], cam["t"])
+        if float(pc[2]) < 0.0:
+            continue
+        u, v, _ = _pinhole(cam, pc, False)
+        if not _kf_in_image(cam, u, v):
+            continue
+        dist = _viewing_gates(cam, p)
+        if dist is None:
+            continue
+        lvl = predict_scale(p["max_distance"], dist, cam["log_scale_factor"], cam["n_levels"])
+        vIndices = KF.GetFeaturesInArea(u, v, cam["th"] * _f32(cam["scale_factors"][lvl]))
+        if not vIndices:
+            continue
+        bestDist, bestIdx = 256, -1
+        for idx in vIndices:
+            if vpMatched[idx]:
+                continue
+            if KF.octave[idx] < lvl - 1 or KF.octave[idx] > lvl:
+                continue
+            d = descriptor_distance(p["desc"], KF.desc[idx])
+            if d < bestDist:
+                bestDist, bestIdx = d, idx
+        if bestDist <= th_low:
+            vpMatched[bestIdx] = True
+            written[-1] = bestIdx
+            nmatches += 1
+    return nmatches, written, vpMatched
+
+
+def ref_search_by_projection_frame_kf(F, cam, points, has_point, orb_dist, check_orientation):
+    """SearchByProjection(Frame& CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (:1385-1504).  points[i] = the keyframe's map
+    point i: skip (NULL / isBad / in sAlreadyFound), pos, min/max_distance, desc, angle (pKF->mvKeysUn[i].angle).  has_point[i2]:
+    CurrentFrame.mvpMapPoints[i2] != NULL on entry.  Returns (nmatches, point index per frame keypoint or -1, updated has_point)."""
+    cam = _cam_f32(cam)
+    mvp = [bool(m) for m in has_point]
+    who = [-1] * F.N
+    rotHist = [[] for _ in range(HISTO_LENGTH)]
+    nmatches = 0
+    for i, p in enumerate(points):
+        if p["skip"]:
+            continue
+        xc3 = _gemm3(cam["R"], p["pos"], cam["t"])
+        xc, yc = xc3[0], xc3[1]
+        invzc = _f32(1.0 / float(xc3[2]))
+        u = cam["fx"] * xc * invzc + cam["cx"]
+        v = cam["fy"] * yc * invzc + cam["cy"]
+        if u < cam["min_x"] or u > cam["max_x"]:
+            continue
+        if v < cam["min_y"] or v > cam["max_y"]:
+            continue
+        PO = [_f32(p["pos"][k]) - _f32(cam["Ow"][k]) for k in range(3)]
+        dist3D = _norm3(PO)
+        if dist3D < _f32(0.8) * _f32(p["min_distance"]) or dist3D > _f32(1.2) * _f32(p["max_distance"]):
+            continue
+        lvl = predict_scale(p["max_distance"], dist3D, cam["log_scale_factor"], cam["n_levels"])
+        radius = cam["th"] * _f32(cam["scale_factors"][lvl])
+        vIndices2 = F.GetFeaturesInArea(u, v, radius, lvl - 1, lvl + 1)
+        if not vIndices2:
+            continue
+        bestDist, bestIdx2 = 256, -1
+        for i2 in vIndices2:
+            if mvp[i2]:
+                continue
+            dist = descriptor_distance(p["desc"], F.desc[i2])
+            if dist < bestDist:
+                bestDist, bestIdx2 = dist, i2
+        if bestDist <= orb_dist:
+            mvp[bestIdx2] = True
+            who[bestIdx2] = i
+            nmatches += 1
+            if check_orientation:
+                rotHist[_rot_bin(p["angle"], F.angle[bestIdx2])].append(bestIdx2)
+    if check_orientation:
+        ind = compute_three_maxima([len(h) for h in rotHist])
+        for b in range(HISTO_LENGTH):
+            if b in ind:
+                continue
+            for j in rotHist[b]:
+                mvp[j] = False
+                who[j] = -1
+                nmatches -= 1
+    return nmatches, who, mvp

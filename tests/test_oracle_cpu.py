@@ -435,15 +435,15 @@ def _check_matchers(kA, dA, kB, dB, sf, w, h, u_right, seed, dx=0.0, dy=0.0):
     blocked = (rng.random(len(kB)) < 0.1).astype(np.uint8)
     # SearchByProjection(Frame&, MapPoints)  :45-128
     q = _queries_from(kA, dA, sf, rng, dx, dy, "points")
-    nm, assigned, _ = oB.search_by_projection_points(q, 0.8, blocked)
-    rnm, rassigned = nr.ref_search_by_projection_points(rB, _as_points(q), 0.8, blocked.astype(bool))
-    assert nm == rnm and list(assigned) == rassigned
+    nm, assigned, after = oB.search_by_projection_points(q, 0.8, blocked)
+    rnm, rassigned, rafter = nr.ref_search_by_projection_points(rB, _as_points(q), 0.8, blocked.astype(bool))
+    assert nm == rnm and list(assigned) == rassigned and [bool(v) for v in after] == rafter
     # SearchByProjection(cur, last)  :1247-1383, with and without the rotation check
     q = _queries_from(kA, dA, sf, rng, dx, dy, "frame")
     for ori in (True, False):
-        nm, assigned, _ = oB.search_by_projection_frame(q, ori, blocked)
-        rnm, rassigned = nr.ref_search_by_projection_frame(rB, _as_last(q), ori, blocked.astype(bool))
-        assert nm == rnm and list(assigned) == rassigned, ori
+        nm, assigned, after = oB.search_by_projection_frame(q, ori, blocked)
+        rnm, rassigned, rafter = nr.ref_search_by_projection_frame(rB, _as_last(q), ori, blocked.astype(bool))
+        assert nm == rnm and list(assigned) == rassigned and [bool(v) for v in after] == rafter, ori
     # SearchByBoW(KF, F)  :161-273
     gA, gB = _bow_groups(dA), _bow_groups(dB)
     valid = (rng.random(len(kA)) < 0.85).astype(np.uint8)
@@ -451,6 +451,29 @@ def _check_matchers(kA, dA, kB, dB, sf, w, h, u_right, seed, dx=0.0, dy=0.0):
         nm, mB = ol.search_by_bow(dA, kA["angle"], valid, gA, dB, kB["angle"], gB, 0.7, ori)
         rnm, rmB = nr.ref_search_by_bow(dA, kA["angle"], valid, gA, dB, kB["angle"], gB, 0.7, ori)
         assert nm == rnm and list(mB) == rmB, ori
+    # SearchByBoW(KF, KF)  :494-612 (vbMatched2 blocks later features; strict TH_LOW)
+    valid2 = (rng.random(len(kB)) < 0.85).astype(np.uint8)
+    for ori in (True, False):
+        nm, mA = ol.search_by_bow_kf(dA, kA["angle"], valid, gA, dB, kB["angle"], valid2, gB, 0.8, ori)
+        rnm, rmA = nr.ref_search_by_bow_kf(dA, kA["angle"], valid, gA, dB, kB["angle"], valid2, gB, 0.8, ori)
+        assert nm == rnm and list(mA) == rmA, ori
+    # SearchForTriangulation  :614-764 with CheckDistEpipolarLine :137-159; F12 of a sideways translation plus a small
+    # perturbation, so that lines are near-horizontal and both outcomes of the chi-square gate occur
+    ep = np.zeros(1, ol.EPIPOLAR_DTYPE)
+    ep["F12"][0] = np.array([0, 1e-5, -2e-3, -1e-5, 0, -1e-2, 2e-3, 1e-2, 0], np.float32) * np.float32(1 + 0.01 * (seed % 7))
+    ep["ex"], ep["ey"] = np.float32(w * 0.5 + dx), np.float32(h * 0.5 + dy)
+    ep["scale_factors"][0, :len(sf)] = sf
+    ep["level_sigma2"][0, :len(sf)] = sf * sf
+    hasA = (rng.random(len(kA)) < 0.3).astype(np.uint8); hasB = (rng.random(len(kB)) < 0.3).astype(np.uint8)
+    urA = np.where(rng.random(len(kA)) < 0.5, kA["x"] - np.float32(3), np.float32(-1)).astype(np.float32)
+    for (ua, ub, only) in ((None, None, False), (urA, u_right, False), (urA, u_right, True)):
+        if only and ub is None:
+            continue
+        for ori in (True, False):
+            nm, mA = ol.search_for_triangulation(kA, dA, ua, hasA, gA, kB, dB, ub, hasB, gB, ep, only, ori)
+            rnm, rmA = nr.ref_search_for_triangulation(kA, dA, ua, hasA, gA, kB, dB, ub, hasB, gB, ep["F12"][0].reshape(3, 3), ep["ex"][0],
+                                                       ep["ey"][0], sf, sf * sf, only, ori)
+            assert nm == rnm and list(mA) == rmA, (only, ori)
     # SearchForInitialization  :388-492 (match stealing through vMatchedDistance / vnMatches21)
     prev = np.stack([kA["x"] + np.float32(dx), kA["y"] + np.float32(dy)], 1).astype(np.float32)
     for win, ori in ((100, True), (20, False)):
@@ -518,3 +541,84 @@ def test_stereo_matches_agree_with_second_reading():
         np.testing.assert_array_equal(ur, rur)
         np.testing.assert_array_equal(depth, rdepth)
         assert (ur >= 0).sum() > 150
+
+
+# ------------------------------------------------------------------ keyframe-rate projection searches: C oracle vs the second reading
+def _kf_scene_cpu(seed, nlevels, w=640, h=480, nfeat=600):
+    """A keyframe (oracle extraction of a synthetic frame, partial mvuRight), its camera, and candidate map points that project onto
+    its keypoints plus points failing each gate (synth.local_map)."""
+    from refactored_orb_slam2_amd.matcher import make_frustum
+    ex = ol.OracleExtractor(nfeat, 1.2, nlevels)
+    k, d = ex(synth.frame(w, h, seq=seed, f=0))
+    sf, inv_s2 = ex.scale_factors.copy(), ex.inv_sigma2.copy()
+    rng = np.random.default_rng(seed)
+    R, t = synth.camera_pose(seed)
+    fr = make_frustum(R, t, 517.3, 516.5, 318.6, 255.3, 40.0, (0, w, 0, h), 1.2, nlevels)
+    mp = synth.local_map(k, d, fr, seed + 1, n_extra=200)
+    cam = np.zeros(1, ol.KF_CAMERA_DTYPE)
+    for f in ("fx", "fy", "cx", "cy", "mbf", "min_x", "max_x", "min_y", "max_y", "log_scale_factor", "n_levels"):
+        cam[f] = fr[f]
+    cam["R"] = fr["Rcw"]; cam["t"] = fr["tcw"]; cam["Ow"] = fr["Ow"]; cam["scale_factors"] = fr["scale_factors"]
+    pts = np.zeros(len(mp), ol.KF_POINT_DTYPE)
+    for f in ("pos", "normal", "min_distance", "max_distance", "skip", "desc"):
+        pts[f] = mp[f]
+    pts["angle"] = (rng.integers(0, 48, len(pts)) * 7.5).astype(np.float32)
+    ur = np.where(rng.random(len(k)) < 0.5, k["x"] - np.float32(20) + rng.normal(0, 1.5, len(k)).astype(np.float32), -1).astype(np.float32)
+    return k, d, sf, inv_s2, ur, cam, pts
+
+
+def _cam_dict(cam):
+    c = cam.reshape(-1)[0]
+    return {f: (c[f].copy() if c[f].ndim else c[f]) for f in cam.dtype.names}
+
+
+def _pt_dicts(pts):
+    return [dict(pos=p["pos"], normal=p["normal"], min_distance=p["min_distance"], max_distance=p["max_distance"], skip=bool(p["skip"]),
+                 angle=p["angle"], desc=p["desc"]) for p in pts]
+
+
+@pytest.mark.parametrize("nlevels", [8, 12])
+def test_keyframe_searches_agree_with_second_reading(nlevels):
+    """oo_fuse / oo_fuse_sim3 / oo_search_by_sim3_dir / oo_search_by_projection_loop / oo_reloc_query + oo_search_by_projection_keyframe
+    (C oracle) == tests/np_restatement.py's plain-Python reading of ORBmatcher::Fuse (:766-912), Fuse(Sim3) (:914-1041), SearchBySim3
+    (:1043-1245, one direction), SearchByProjection(KF, Scw) (:275-386) and SearchByProjection(Frame, KF) (:1385-1504): projection,
+    every gate, predicted level, window enumeration, level and chi-square filters, first-minimum rule, blocking, rotation histogram."""
+    w, h = 640, 480
+    k, d, sf, inv_s2, ur, cam, pts = _kf_scene_cpu(70 + nlevels, nlevels)
+    okf, rkf = ol.OracleFrame(k, d, sf, 0, w, 0, h, ur), nr.RefFrame(k, d, 0, w, 0, h, ur)
+    okf_mono, rkf_mono = ol.OracleFrame(k, d, sf, 0, w, 0, h), nr.RefFrame(k, d, 0, w, 0, h)
+    P = _pt_dicts(pts)
+
+    def same(ores, rres):
+        got = [(int(r["best_idx"]), int(r["best_dist"])) for r in ores]
+        assert got == [(int(a), int(b)) for a, b in rres]
+        return sum(1 for a, _ in rres if a >= 0)
+
+    cam["th"] = 3.0                                             # Fuse, LocalMapping's th; stereo and monocular keyframe
+    for o, r in ((okf, rkf), (okf_mono, rkf_mono)):
+        _, ores, _ = ol.kf_search(o, cam, pts, 1, inv_level_sigma2=inv_s2)
+        assert same(ores, nr.ref_fuse(r, inv_s2, _cam_dict(cam), P)) > 150
+    cam["th"] = 4.0                                             # Fuse(Sim3), LoopClosing::SearchAndFuse's th
+    _, ores, _ = ol.kf_search(okf, cam, pts, 2)
+    assert same(ores, nr.ref_fuse_sim3(rkf, _cam_dict(cam), P)) > 150
+    cam3 = cam.copy(); cam3["th"] = 7.5                         # SearchBySim3 direction
+    a = 0.01
+    R12 = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    cam3["R2"] = (np.float32(1.0 / 1.03) * R12.T).astype(np.float32).reshape(9)
+    cam3["t2"] = np.array([0.02, -0.01, 0.03], np.float32)
+    _, ores, _ = ol.kf_search(okf, cam3, pts, 3)
+    assert same(ores, nr.ref_search_by_sim3_dir(rkf, _cam_dict(cam3), P)) > 100
+    cam["th"] = 10.0                                            # SearchByProjection(KF, Scw): some keypoints already matched
+    rng = np.random.default_rng(5)
+    matched0 = (rng.random(len(k)) < 0.15).astype(np.uint8)
+    on, ores, oblk = ol.kf_search(okf, cam, pts, 4, matched=matched0, th_low=50)
+    rn, rwritten, rblk = nr.ref_search_by_projection_kf_scw(rkf, _cam_dict(cam), P, matched0, 50)
+    assert on == rn and [int(v) for v in ores["best_idx"]] == rwritten and [bool(v) for v in oblk] == rblk and rn > 100
+    for check in (True, False):                                 # SearchByProjection(Frame, KF): relocalisation
+        on, ores, oblk = ol.kf_search(okf_mono, cam, pts, 5, matched=matched0, th_low=100, check_orientation=check)
+        rn, rwho, rmvp = nr.ref_search_by_projection_frame_kf(rkf_mono, _cam_dict(cam), P, matched0, 100, check)
+        who = [-1] * len(k)
+        for i, b in enumerate(ores["best_idx"]):
+            if b >= 0:
+                who[int(b)] = i
+        assert on == rn and who == rwho and [bool(v) for v in oblk] == rmvp and rn > 50, check
