@@ -492,7 +492,9 @@ int orbfe_vocabulary_load_binary(const char* path, int device, orbfe_vocabulary*
 int orbfe_vocabulary_destroy(orbfe_vocabulary* v);
 int orbfe_vocabulary_info(const orbfe_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words);
 /* Tree descent only, DEVICE pointers, asynchronous: per descriptor the word id, the node at level L - levelsup and
- * the word weight. */
+ * the word weight.  A descent that ends in a leaf ABOVE level L - levelsup never reaches `*nid = final_id`
+ * (TemplatedVocabulary.h:1249) and the reference's caller reads an uninitialised NodeId (:1149); this library reports node 0
+ * (the root) for such a feature.  ORBvoc.txt with levelsup = 4 has no leaf above level 2, so the case does not arise there. */
 int orbfe_bow_transform_device(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, int32_t* d_word,
                                int32_t* d_node, double* d_weight, void* stream);
 /* The whole transform for one frame, HOST pointers, synchronous.  BowVector as ascending (bow_ids, bow_vals) pairs,

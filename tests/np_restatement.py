@@ -1120,3 +1120,69 @@ def ref_search_by_projection_frame_kf(F, cam, points, has_point, orb_dist, check
                 who[j] = -1
                 nmatches -= 1
     return nmatches, who, mvp
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Second reading of Frame::ComputeBoW's work: DBoW2 TemplatedVocabulary::transform (ThirdParty/DBoW2/DBoW2-local/include/DBoW2/
+# TemplatedVocabulary.h:1125-1192 and :1216-1257) on a tree as ORBVocabulary::loadFromTextFile builds it (ORBVocabulary.cc:79-123:
+# node ids in file order, children appended in that order, word ids numbering the nodes flagged leaf in that order).
+def ref_vocab_transform(L, parent, leaf_flag, node_desc, node_weight, features, levelsup, scoring=0, weighting=0):
+    """Returns (BowVector as {word id: value}, FeatureVector as {node id: [feature indices]}).  scoring: 0 L1, 1 L2, 2 chi-square,
+    3 KL, 4 Bhattacharyya, 5 dot product (ScoringObject.h:73-88); weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY."""
+    n = len(parent)
+    children = [[] for _ in range(n)]
+    word_id = [-1] * n
+    n_words = 0
+    for nid in range(1, n):
+        children[int(parent[nid])].append(nid)
+        if leaf_flag[nid]:
+            word_id[nid] = n_words
+            n_words += 1
+    bow, fv = {}, {}
+    if n <= 1:                                       # empty(): no words
+        return bow, fv
+    for i_feature, f in enumerate(features):
+        nid_level = L - levelsup
+        nid = 0   # root when nid_level <= 0 (:1225); ALSO when the descent ends above nid_level: the reference then reads an
+                  # uninitialised NodeId (:1149, :1249 never reached) -- undefined there, defined as the root here and in the oracle
+        final_id, current_level = 0, 0
+        while True:
+            current_level += 1
+            nodes = children[final_id]
+            final_id = nodes[0]
+            best_d = float(descriptor_distance(f, node_desc[final_id]))
+            for c in nodes[1:]:
+                d = float(descriptor_distance(f, node_desc[c]))
+                if d < best_d:
+                    best_d, final_id = d, c
+            if current_level == nid_level:
+                nid = final_id
+            if not children[final_id]:               # Node::isLeaf() = children.empty()
+                break
+        w = float(node_weight[final_id])
+        if w > 0:
+            wid = word_id[final_id]
+            if weighting in (0, 1):
+                bow[wid] = bow.get(wid, 0.0) + w     # addWeight
+            elif wid not in bow:
+                bow[wid] = w                         # addIfNotExist
+            fv.setdefault(nid, []).append(i_feature)
+    must = scoring != 5
+    if weighting in (0, 1) and bow and not must:
+        nd = float(len(bow))
+        for k in bow:
+            bow[k] /= nd
+    if must:
+        keys = sorted(bow)
+        norm = 0.0
+        if scoring == 1:
+            for k in keys:
+                norm += bow[k] * bow[k]
+            norm = math.sqrt(norm)
+        else:
+            for k in keys:
+                norm += abs(bow[k])
+        if norm > 0.0:
+            for k in keys:
+                bow[k] /= norm
+    return bow, fv

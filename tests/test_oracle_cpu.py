@@ -622,3 +622,25 @@ def test_keyframe_searches_agree_with_second_reading(nlevels):
             if b >= 0:
                 who[int(b)] = i
         assert on == rn and who == rwho and [bool(v) for v in oblk] == rmvp and rn > 50, check
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_vocabulary_transform_agrees_with_second_reading(ragged):
+    """oo_vocab_transform (C oracle) == the plain-Python reading of DBoW2's transform: descent with the first minimum, the node at
+    level L - levelsup (root when that is <= 0, and -- by this repo's definition, the reference reads an uninitialised variable --
+    when a ragged tree ends the descent above that level), stopped words dropped from both vectors, addWeight / addIfNotExist, the
+    scoring object's normalisation.  Values compared as doubles, bit for bit; the nodes / features of the FeatureVector in order."""
+    k, L = 6, 3
+    parent, leaf, desc, weight = ol.synthetic_vocabulary(k, L, seed=17 + ragged, stop_fraction=0.1, ragged=ragged)
+    rng = np.random.default_rng(3)
+    feats = desc[rng.integers(1, len(parent), 300)].copy()
+    feats[np.arange(300), rng.integers(0, 32, 300)] ^= rng.integers(0, 256, 300).astype(np.uint8)
+    feats[::9] = rng.integers(0, 256, (len(feats[::9]), 32), dtype=np.uint8)
+    for scoring, weighting in ((0, 0), (1, 0), (5, 0), (0, 1), (5, 1), (0, 2), (2, 3), (5, 3)):
+        v = ol.OracleVocabulary.from_arrays(k, L, parent, leaf, desc, weight, scoring, weighting)
+        for levelsup in (0, 1, 2, L, L + 2):
+            bow, fv, _ = v.transform(feats, levelsup)
+            rbow, rfv = nr.ref_vocab_transform(L, parent, leaf, desc, weight, feats, levelsup, scoring, weighting)
+            assert sorted(bow) == sorted(rbow) and all(bow[w] == rbow[w] for w in bow), (scoring, weighting, levelsup)
+            assert fv == {k_: v_ for k_, v_ in rfv.items()}, (scoring, weighting, levelsup)
+            assert len(bow) > 20
