@@ -321,6 +321,60 @@ def hamming(a, b):
     return int(np.unpackbits(np.bitwise_xor(np.asarray(a, np.uint8), np.asarray(b, np.uint8))).sum())
 
 
+# ------------------------------------------------------------------------------ whole extraction (A1-A9)
+def extractor_tables(nfeatures, scale_factor, nlevels):
+    """ORBextractor::ORBextractor (L/src/ORBextractor.cc:408-441): mvScaleFactor (float x the double member scaleFactor,
+    L/include/ORBextractor.h:91), mvInvScaleFactor, mnFeaturesPerLevel (float arithmetic, cvRound)."""
+    f = np.float32
+    sf = [f(1.0)]
+    for i in range(1, nlevels):
+        sf.append(f(np.float64(sf[i - 1]) * np.float64(f(scale_factor))))
+    inv = [f(1.0) / v for v in sf]
+    factor = f(1.0) / f(scale_factor)
+    nd = f(nfeatures) * (f(1) - factor) / (f(1) - f(np.float64(factor) ** np.float64(nlevels)))
+    per, tot = [], 0
+    for _ in range(nlevels - 1):
+        per.append(int(np.rint(np.float64(nd))))
+        tot += per[-1]
+        nd = nd * factor
+    per.append(max(nfeatures - tot, 0))
+    return sf, inv, per
+
+
+def ref_extract(img, nfeatures, scale_factor, nlevels, ini_th, min_th, pattern):
+    """ORBextractor::operator() (L/src/ORBextractor.cc:983-1038) composed from the primitives above: ComputePyramid (:1040-1066, each
+    level resized from the previous one), ComputeKeyPointsOctTree (:733-813), computeOrientation, blur + descriptors per level,
+    coordinates scaled by mvScaleFactor[level].  Returns (list of (x, y, size, angle, response, octave), descriptors (n, 32))."""
+    f = np.float32
+    sf, inv, per = extractor_tables(nfeatures, scale_factor, nlevels)
+    h0, w0 = img.shape
+    pyr = []
+    for l in range(nlevels):
+        w = int(np.rint(np.float64(f(w0) * inv[l]))); h = int(np.rint(np.float64(f(h0) * inv[l])))
+        pyr.append(img.copy() if l == 0 else resize_linear(pyr[l - 1], w, h))
+    kps, descs = [], []
+    for l in range(nlevels):
+        im = pyr[l]
+        h, w = im.shape
+        x, y, s = fast_candidates(im, ini_th, min_th)
+        if len(x) == 0:
+            continue
+        sel = distribute_octree(x, y, s, 16, w - 16, 16, h - 16, per[l])
+        if len(sel) == 0:
+            continue
+        size = int(f(31) * sf[l])
+        blurred = gaussian_blur7(im)
+        for k in sel:
+            px, py = int(x[k]) + 16, int(y[k]) + 16
+            ang = ic_angle(im, px, py)
+            descs.append(orb_descriptor(blurred, px, py, ang, pattern))
+            fx, fy = f(px), f(py)
+            if l != 0:
+                fx, fy = fx * sf[l], fy * sf[l]
+            kps.append((fx, fy, f(size), ang, f(s[k]), l))
+    return kps, (np.stack(descs) if descs else np.zeros((0, 32), np.uint8))
+
+
 # ============================================================================================ matchers (second reading)
 # An INDEPENDENT restatement of the order-dependent matcher loops, written from the reference sources alone
 # (L/src/ORBmatcher.cc:45-128, 161-273, 388-492, 1247-1383, 1506-1556 and L/src/Frame.cc:250-263, 341-410) as plain Python

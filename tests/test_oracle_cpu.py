@@ -644,3 +644,30 @@ def test_vocabulary_transform_agrees_with_second_reading(ragged):
             assert sorted(bow) == sorted(rbow) and all(bow[w] == rbow[w] for w in bow), (scoring, weighting, levelsup)
             assert fv == {k_: v_ for k_, v_ in rfv.items()}, (scoring, weighting, levelsup)
             assert len(bow) > 20
+
+
+@pytest.mark.parametrize("case", ["demo", "synthetic", "lowtex"])
+def test_whole_extraction_agrees_with_numpy_reading(case):
+    """oo_extract (C oracle, literal per-cell loops and node lists) == tests/np_restatement.py's ref_extract (vectorised score map,
+    array octree, numpy pyramid / blur): keypoint order, coordinates, sizes, angles, responses, octaves and descriptor bytes of
+    ORBextractor::operator() on a real image, a synthetic frame and a low-texture frame whose cells fall back to minThFAST."""
+    if case == "demo":
+        g = np.load(os.path.join(GOLD, "real_demo.npz"))
+        img, nf, ini, mn = g["images"][2], 700, 20, 7
+    elif case == "synthetic":
+        img, nf, ini, mn = synth.frame(400, 300, seq=9, f=1), 500, 20, 7
+    else:
+        base = synth.frame(360, 240, seq=10, f=0).astype(np.float32)
+        img = (128 + (base - 128) * 0.18).astype(np.uint8)          # contrast low enough that most cells need the second threshold
+        nf, ini, mn = 400, 20, 7
+    ex = ol.OracleExtractor(nf, 1.2, 8, ini, mn)
+    k, d = ex(img)
+    pat = np.ctypeslib.as_array(ol.lib().oo_pattern(), (1024,)).copy()
+    rk, rd = nr.ref_extract(img, nf, 1.2, 8, ini, mn, pat)
+    assert len(k) == len(rk) and len(k) > 100
+    for name, col in (("x", 0), ("y", 1), ("size", 2), ("angle", 3), ("response", 4), ("octave", 5)):
+        np.testing.assert_array_equal(k[name], np.array([r[col] for r in rk], k[name].dtype), err_msg=name)
+    np.testing.assert_array_equal(d, rd)
+    sf, inv, per = nr.extractor_tables(nf, 1.2, 8)
+    np.testing.assert_array_equal(ex.scale_factors, np.array(sf, np.float32))
+    np.testing.assert_array_equal(ex.features_per_level, np.array(per))
