@@ -186,7 +186,100 @@ __global__ __launch_bounds__(256) void hamming_bf_kernel(HammingBfParams P) {
 // ------------------------------------------------------------------------------------------------ grid
 // One block per frame: 64x48 grid in CSR form (cell = ix*48 + iy), lists in ascending keypoint index.
 #define GB_THREADS 1024   // one block per frame and one frame per CU: the block's own parallelism is all there is to hide latency with
+#define GB_LDS_CAP 20000  // frames up to this capacity keep the per-keypoint state in LDS (6 bytes per keypoint)
+// LDS-resident form: two global round trips (keypoints in, records out) instead of nine.  A keypoint's place inside its cell is
+// its RANK among the cell's indices (cells hold a handful of keypoints), computed by the thread that owns the keypoint -- no sort,
+// and the 16-byte record is written from the owner's registers instead of through the index -> keypoint -> mvuRight chain.
 __global__ __launch_bounds__(GB_THREADS) void grid_build_kernel(FrameBatch F) {
+  __shared__ int cnt[GRID_CELLS];
+  __shared__ int start[GRID_CELLS + 1];
+  __shared__ int tmp[GB_THREADS / 64];
+  extern __shared__ __attribute__((aligned(16))) uint8_t gdyn[];
+  static_assert(GRID_CELLS % GB_THREADS == 0 && GRID_CELLS <= 4096, "cells per thread; the cell id travels in 12 bits");
+  constexpr int CPT = GRID_CELLS / GB_THREADS;   // consecutive cells per thread in the scan
+  uint32_t* cellslot = reinterpret_cast<uint32_t*>(gdyn);            // per keypoint: cell | arrival slot << 12 (~0u: outside the grid)
+  uint16_t* list = reinterpret_cast<uint16_t*>(cellslot + F.cap);    // per CSR entry: keypoint index, arrival order inside a cell
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = F.n[f];
+  const orbfe_keypoint* keys = F.keys + (size_t)f * F.cap;
+  const float* ur = F.u_right ? F.u_right + (size_t)f * F.cap : nullptr;
+  int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
+  int32_t* ci = F.cell_idx + (size_t)f * F.cap;
+  uint4* cr = reinterpret_cast<uint4*>(F.cell_rec) + (size_t)f * F.cap;
+  for (int c = tid; c < GRID_CELLS; c += GB_THREADS) cnt[c] = 0;
+  __syncthreads();
+  for (int i0 = tid; i0 < n; i0 += 2 * GB_THREADS) {   // two keypoints per thread and round trip
+    const int i1 = i0 + GB_THREADS;
+    const float x0 = keys[i0].x, y0 = keys[i0].y;
+    float x1 = 0.f, y1 = 0.f;
+    if (i1 < n) { x1 = keys[i1].x; y1 = keys[i1].y; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int i = k ? i1 : i0;
+      if (i >= n) break;
+      const int px = (int)roundf(((k ? x1 : x0) - F.min_x) * F.gw_inv);
+      const int py = (int)roundf(((k ? y1 : y0) - F.min_y) * F.gh_inv);
+      uint32_t v = ~0u;
+      if (px >= 0 && px < ORBFE_GRID_COLS && py >= 0 && py < ORBFE_GRID_ROWS) {
+        const int c = px * ORBFE_GRID_ROWS + py;
+        v = (uint32_t)c | ((uint32_t)atomicAdd(&cnt[c], 1) << 12);
+      }
+      cellslot[i] = v;
+    }
+  }
+  __syncthreads();
+  // exclusive scan: CPT consecutive cells per thread, DPP wave scan, wave totals through LDS
+  {
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; k++) local += cnt[tid * CPT + k];
+    const int v = wave_incl_scan_i(local);
+    if ((tid & 63) == 63) tmp[tid >> 6] = v;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < (tid >> 6); w++) off += tmp[w];
+    int run = off + v - local;
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+      start[tid * CPT + k] = run;
+      run += cnt[tid * CPT + k];
+    }
+    if (tid == GB_THREADS - 1) start[GRID_CELLS] = run;
+  }
+  __syncthreads();
+  for (int c = tid; c <= GRID_CELLS; c += GB_THREADS) cs[c] = start[c];
+  for (int i = tid; i < n; i += GB_THREADS) {
+    const uint32_t v = cellslot[i];
+    if (v != ~0u) list[start[v & 0xfffu] + (int)(v >> 12)] = (uint16_t)i;
+  }
+  __syncthreads();
+  for (int i0 = tid; i0 < n; i0 += 2 * GB_THREADS) {
+    const int i1 = i0 + GB_THREADS;
+    const orbfe_keypoint k0 = keys[i0];
+    const float u0 = ur ? ur[i0] : -1.0f;
+    orbfe_keypoint k1 = k0;
+    float u1 = -1.0f;
+    if (i1 < n) { k1 = keys[i1]; u1 = ur ? ur[i1] : -1.0f; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int i = k ? i1 : i0;
+      if (i >= n) break;
+      const uint32_t v = cellslot[i];
+      if (v == ~0u) continue;
+      const int c = (int)(v & 0xfffu);
+      const int s0 = start[c], s1 = start[c + 1];
+      int pos = s0;
+      for (int j = s0; j < s1; j++) pos += (int)list[j] < i;   // insertion order of the reference = ascending index
+      const orbfe_keypoint& kp = k ? k1 : k0;
+      ci[pos] = i;
+      cr[pos] = make_uint4((uint32_t)i | ((uint32_t)kp.octave << 24), (uint32_t)__float_as_int(kp.x), (uint32_t)__float_as_int(kp.y),
+                           (uint32_t)__float_as_int(k ? u1 : u0));
+    }
+  }
+}
+
+// the same for frames beyond GB_LDS_CAP keypoints: index lists sorted in global memory
+__global__ __launch_bounds__(GB_THREADS) void grid_build_global_kernel(FrameBatch F) {
   __shared__ int cnt[GRID_CELLS];
   __shared__ int start[GRID_CELLS + 1];
   __shared__ int tmp[GB_THREADS / 64];
@@ -435,8 +528,39 @@ __device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& in
 // mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)   -- best/second with the same-level ratio test
 // mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, th_high = TH_HIGH, rotation histogram;
 //         SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist) is the same walk with th_high = ORBdist (:1385-1504)
+#ifndef FC_TIMING
+#define FC_TIMING 0
+#endif
+#if FC_TIMING
+// -DFC_TIMING=1 (tools/search_latency.py): cycles of proj_resolve_kernel's workgroup 0 per phase (thread 0's clock after each barrier)
+__device__ unsigned long long g_rs_prof[16];
+extern "C" int orbfe_debug_rs_profile(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#define RS_T(i) do { const unsigned long long _t = __builtin_readcyclecounter(); rs_acc##i += (unsigned)(_t - rs_prev); rs_prev = _t; } while (0)
+#define RS_COUNT(i) do { rs_acc##i += 1; } while (0)
+#define RS_END() do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned a[11] = {rs_acc0, rs_acc1, rs_acc2, rs_acc3, rs_acc4, rs_acc5, rs_acc6, \
+    rs_acc7, rs_acc8, rs_acc9, rs_acc10}; for (int _i = 0; _i < 11; _i++) g_rs_prof[_i] += a[_i]; } } while (0)
+#else
+#define RS_T(i)
+#define RS_COUNT(i)
+#define RS_END()
+#endif
+// best / second-best entry by distance, first one wins ties (the reference's strict "<"); RC_INVALID loses against everything.
+// Values in, values out, no branches: with references (or a by-reference lambda) the compiler kept the pair in scratch memory
+// and selected the ADDRESS to store to -- private-memory round trips inside the fixed-point loop (7 k cycles per iteration).
+__device__ __forceinline__ void rc_take(uint32_t e, uint32_t& e1, uint32_t& e2) {
+  const uint32_t a = e1, b = e2;
+  const bool lt1 = (e >> 20) < (a >> 20), lt2 = (e >> 20) < (b >> 20);
+  e2 = lt1 ? a : (lt2 ? e : b);
+  e1 = lt1 ? e : a;
+}
 #define RC_THREADS 1024
-#define RC_LIST_CAP 16384  // staged candidate entries per chunk (64 KiB)
+#define RC_LIST_CAP 16384  // staged candidate entries per chunk (64 KiB): what does not fit the registers
+#define RC_REG 4           // candidates per query kept in registers
+#define RC_INVALID 0xFFFFFFFFu
 __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
                                                            const int32_t* __restrict__ n_cand, int max_cand, int mode, int th_high,
                                                            float nnratio, int check_ori, uint8_t* __restrict__ blocked_all,
@@ -465,23 +589,41 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
   for (int i = tid; i < F.cap; i += RC_THREADS) { blocked[i] = blocked_g[i]; claim[i] = 0x7fffffff; claimB[i] = 0x7fffffff; }
   if (tid < ORBFE_HISTO_LENGTH) hist[tid] = 0;
   if (tid == 0) { sh_nm = 0; sh_npush = 0; }
+#if FC_TIMING
+  unsigned rs_acc0 = 0, rs_acc1 = 0, rs_acc2 = 0, rs_acc3 = 0, rs_acc4 = 0, rs_acc5 = 0, rs_acc6 = 0, rs_acc7 = 0, rs_acc8 = 0, rs_acc9 = 0,
+           rs_acc10 = 0;
+  unsigned long long rs_prev = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+  RS_T(0);   // set-up
   const bool use_hist = (mode == 1) && check_ori;
   int q0 = 0;
   while (q0 < nq) {
+    RS_COUNT(8);
     const int qi = q0 + tid;
+    // one round trip: the query's flags, its candidate count and its first RC_REG candidates (slot rows exist for every qi < nq;
+    // entries beyond the count are masked below)
     int tot = 0, qblocks = 0;
     float qangle = 0.f;
-    if (qi < nq && qbase[qi].valid) {
-      tot = ncb[qi];
-      qblocks = qbase[qi].blocks != 0;
-      qangle = qbase[qi].angle;
+    uint2 craw[RC_REG];
+#pragma unroll
+    for (int u = 0; u < RC_REG; u++) craw[u] = make_uint2(0u, 0u);
+    if (qi < nq) {
+      const orbfe_query* qp = qbase + qi;
+      const int qvalid = qp->valid;
+      const int n = ncb[qi];
+      qblocks = qp->blocks != 0;
+      qangle = qp->angle;
+      const uint2* row = reinterpret_cast<const uint2*>(cand + ((size_t)f * Q.cap + qi) * max_cand);
+#pragma unroll
+      for (int u = 0; u < RC_REG; u++) craw[u] = row[min(u, max_cand - 1)];
+      tot = qvalid ? n : 0;
     }
     // chunk = queries q0 .. q0+len-1: stops before the first truncated list and before the staging area is full
     if (tid == 0) { sh_len = min(RC_THREADS, nq - q0); sh_changed[0] = 0; sh_changed[1] = 0; }
     __syncthreads();
     {
-      const int v = tot > max_cand ? 0 : tot;
+      const int v = tot > max_cand ? 0 : max(tot - RC_REG, 0);   // entries beyond the registers go through LDS
       const int w = wave_incl_scan_i(v);
       if (lane == WAVE - 1) scan_tmp[wid] = w;
       __syncthreads();
@@ -493,6 +635,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
       if (tot > max_cand || incl > RC_LIST_CAP) atomicMin(&sh_len, tid);
     }
     __syncthreads();
+    RS_T(1);   // query records + chunk scan
     const int len = sh_len;
     if (len == 0) {
       // ---- truncated list at q0: wave 0 re-enumerates this one window, the other waves wait
@@ -554,67 +697,78 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
       q0 += 1;
       continue;
     }
-    // ---- stage the candidate lists (each wave its own 64 queries, 8 lists in flight per step)
-    for (int j0 = 0; j0 < WAVE; j0 += 8) {
-      orbfe_cand c[8];
-      int dst[8];
+    // ---- the chunk's candidates, packed dist<<20 | octave<<16 | idx; RC_INVALID = beyond the count, or the keypoint is blocked
+    // (blocked[] only changes when a chunk commits, so the filter holds for every iteration below).  The first RC_REG stay in
+    // registers; longer lists (rare: 2.8 candidates per query on average at th = 7, 6.7 at th = 15) put the rest in LDS.
+    uint32_t creg[RC_REG];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int t = wid * WAVE + j0 + u;
-        const int tj = __shfl(tot, j0 + u, WAVE);
-        dst[u] = -1;
-        if (t < len && lane < tj) {
-          c[u] = cand[((size_t)f * Q.cap + q0 + t) * max_cand + lane];
-          dst[u] = loff[t] + lane;
+    for (int u = 0; u < RC_REG; u++) {
+      const uint32_t idx = craw[u].x & 0xffffu, dd = craw[u].y;
+      const uint32_t e = ((dd & 0xffffu) << 20) | (((dd >> 16) & 0xfu) << 16) | idx;
+      // (a distance of 256 never beats the reference's initial bestDist = 256: such an entry does not exist for the walk)
+      creg[u] = (tid < len && u < tot && (dd & 0xffffu) < 256u && !blocked[min(idx, (uint32_t)F.cap - 1u)]) ? e : RC_INVALID;
+    }
+    const int nover = (tid < len) ? max(tot - RC_REG, 0) : 0;
+    {
+      const uint2* row = reinterpret_cast<const uint2*>(cand + ((size_t)f * Q.cap + qi) * max_cand) + RC_REG;
+      uint32_t* dstl = lc + loff[tid < len ? tid : 0];
+      for (int c0 = 0; c0 < nover; c0 += 4) {
+        uint2 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = row[min(c0 + u, nover - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (c0 + u >= nover) break;
+          const uint32_t idx = r[u].x & 0xffffu, dd = r[u].y;
+          dstl[c0 + u] = (blocked[idx] || (dd & 0xffffu) >= 256u) ? RC_INVALID : (((dd & 0xffffu) << 20) | (((dd >> 16) & 0xfu) << 16) | idx);
         }
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (dst[u] >= 0)
-          lc[dst[u]] = ((uint32_t)(c[u].dist & 0xffff) << 20) | ((uint32_t)((c[u].dist >> 16) & 0xf) << 16) |
-                       (uint32_t)(c[u].idx & 0xffff);
     }
     __syncthreads();
+    RS_T(2);   // staging
     const bool active = tid < len && tot > 0;
     const uint32_t* mylist = lc + loff[tid < len ? tid : 0];
     // Fixed-point iteration over the chunk.  Thread t's choice = best candidate that is neither blocked nor
     // claimed (blocked-to-be) by an EARLIER thread of the chunk; claims come from the previous iteration.
     // Thread t's choice is final after at most t+1 iterations (it only depends on earlier threads), so the
     // iteration converges to exactly the sequential result; in practice the dependency chains are 2-4 deep.
-    uint32_t e1 = 0, e2 = 0;
-    bool has = false, has2 = false, accept = false;
+    // state = the two best entries; RC_INVALID (distance field 0xfff) = none.  Plain 32-bit values only: bool flags updated
+    // through a by-reference lambda ended up in scratch memory, several private-memory round trips per iteration (7 k cycles).
+    uint32_t e1 = RC_INVALID, e2 = RC_INVALID;
+    int accept = 0;
     int myclaim = -1;
     for (int iter = 0;; iter++) {
       int* cprev = (iter & 1) ? claimB : claim;
       int* cnew = (iter & 1) ? claim : claimB;
       const uint32_t pe1 = e1, pe2 = e2;
-      const bool phas = has, phas2 = has2;
-      int bestDist = 256, bestDist2 = 256;
-      e1 = e2 = 0;
-      has = has2 = accept = false;
+      e1 = e2 = RC_INVALID;
+      accept = 0;
       if (active) {
-        for (int c0 = 0; c0 < tot; c0 += 4) {  // 4 candidates in flight: independent LDS loads first, then the scan
-          uint32_t ev[4];
-          bool ok[4];
+        {
+          int cl[RC_REG];
 #pragma unroll
-          for (int u = 0; u < 4; u++) ev[u] = mylist[min(c0 + u, tot - 1)];
+          for (int u = 0; u < RC_REG; u++) cl[u] = cprev[creg[u] == RC_INVALID ? 0 : (int)(creg[u] & 0xffffu)];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int idx = (int)(ev[u] & 0xffff);
-            ok[u] = (c0 + u < tot) && !blocked[idx] && !(cprev[idx] < tid);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (!ok[u]) continue;
-            const uint32_t e = ev[u];
-            const int dist = (int)(e >> 20);
-            if (dist < bestDist) { bestDist2 = bestDist; e2 = e1; has2 = has; bestDist = dist; e1 = e; has = true; }
-            else if (dist < bestDist2) { bestDist2 = dist; e2 = e; has2 = true; }
+          for (int u = 0; u < RC_REG; u++) {
+            const uint32_t e = (cl[u] < tid) ? RC_INVALID : creg[u];   // claimed by an earlier query of the chunk
+            rc_take(e, e1, e2);
           }
         }
-        if (has) {
+        for (int c0 = 0; c0 < nover; c0 += 4) {  // 4 candidates in flight: independent LDS loads first, then the scan
+          uint32_t ev[4];
+          int cl[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) ev[u] = (c0 + u < nover) ? mylist[c0 + u] : RC_INVALID;
+#pragma unroll
+          for (int u = 0; u < 4; u++) cl[u] = cprev[ev[u] == RC_INVALID ? 0 : (int)(ev[u] & 0xffffu)];
+#pragma unroll
+          for (int u = 0; u < 4; u++) rc_take((cl[u] < tid) ? RC_INVALID : ev[u], e1, e2);
+        }
+        if (e1 != RC_INVALID) {
+          const int bestDist = (int)(e1 >> 20);
           if (mode == 0) {
-            const int bestLevel = (int)((e1 >> 16) & 0xf), bestLevel2 = has2 ? (int)((e2 >> 16) & 0xf) : -1;
+            const int bestDist2 = e2 != RC_INVALID ? (int)(e2 >> 20) : 256;
+            const int bestLevel = (int)((e1 >> 16) & 0xf), bestLevel2 = e2 != RC_INVALID ? (int)((e2 >> 16) & 0xf) : -1;
             accept = bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
           } else {
             accept = bestDist <= th_high;
@@ -624,13 +778,17 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
       const int bestIdx = (int)(e1 & 0xffff);
       const bool blk = accept && qblocks;
       if (blk) atomicMin(&cnew[bestIdx], tid);
-      if (iter == 0 || e1 != pe1 || e2 != pe2 || has != phas || has2 != phas2) sh_changed[iter & 1] = 1;
+      if (iter == 0 || e1 != pe1 || e2 != pe2) sh_changed[iter & 1] = 1;
+      RS_T(6);   // (iterations: wave 0's own scan)
       __syncthreads();
+      RS_T(7);   // (iterations: wait at the first barrier)
       const int again = sh_changed[iter & 1];
       if (myclaim >= 0) cprev[myclaim] = 0x7fffffff;  // everybody is done reading cprev: recycle it as the next cnew
       myclaim = blk ? bestIdx : -1;
       if (tid == 0) sh_changed[(iter + 1) & 1] = 0;
       __syncthreads();
+      RS_T(3);   // fixed-point iterations
+      RS_COUNT(9);
       if (!again) {
         // converged: commit every accepted query of the chunk.  Several queries may take the same keypoint
         // (only when the earlier ones do not block it): the last one in query order wins, as in the reference.
@@ -657,6 +815,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
         if (active && accept) cprev[bestIdx] = 0x7fffffff;
         if (myclaim >= 0) cnew[myclaim] = 0x7fffffff;
         __syncthreads();
+        RS_T(4);   // commit
         break;
       }
     }
@@ -683,6 +842,9 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
   __syncthreads();
   for (int i = tid; i < F.cap; i += RC_THREADS) blocked_g[i] = blocked[i];
   if (tid == 0) n_matches[f] = sh_nm;
+  RS_T(5);   // rotation check + write-back
+  RS_COUNT(10);
+  RS_END();
 }
 
 // ------------------------------------------------------------------------------------------------ SearchByBoW
@@ -1295,7 +1457,16 @@ void orbfe_launch_hamming_bf(const HammingBfParams& p, int max_nA, int n_sets, h
   hipLaunchKernelGGL(hamming_bf_kernel, grid, dim3(256), 0, s, p);
 }
 void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {
-  hipLaunchKernelGGL(grid_build_kernel, dim3(n_frames), dim3(GB_THREADS), 0, s, f);
+  if (f.cap > GB_LDS_CAP) {
+    hipLaunchKernelGGL(grid_build_global_kernel, dim3(n_frames), dim3(GB_THREADS), 0, s, f);
+    return;
+  }
+  static std::once_flag raised;
+  std::call_once(raised, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              6 * GB_LDS_CAP + 16);
+  });
+  hipLaunchKernelGGL(grid_build_kernel, dim3(n_frames), dim3(GB_THREADS), (size_t)6 * (size_t)f.cap + 16, s, f);
 }
 void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
                                   int max_cand, int n_frames, hipStream_t s) {

@@ -145,6 +145,40 @@ def test_proj_candidates_order_and_distances(geom):
     assert tot > len(q)  # the test exercises real windows
 
 
+@pytest.mark.parametrize("n", [1500, 9000, 20500])
+def test_grid_of_crowded_and_large_frames(n):
+    """The Frame grid (Frame.cc:250-263) from random keypoints instead of extracted ones: a quarter of them piled into two cells
+    (long cell lists: the rank-based placement), some outside the image bounds (no cell), 20 500 keypoints (beyond the LDS-resident
+    form: the kernel that sorts the cell lists in global memory).  Windows must list the same indices in the same order as the
+    oracle's GetFeaturesInArea."""
+    rng = np.random.default_rng(n)
+    w, h = 1241, 376
+    k = np.zeros(n, ol.KP_DTYPE)
+    k["x"] = rng.uniform(-8, w + 8, n).astype(np.float32); k["y"] = rng.uniform(-8, h + 8, n).astype(np.float32)
+    pile = rng.random(n) < (0.25 if n < 20000 else 0.03)   # (the global-memory form sorts a cell list serially: keep its piles moderate)
+    k["x"][pile] = (np.where(rng.random(pile.sum()) < 0.5, 300.0, 911.5) + rng.uniform(-6, 6, pile.sum())).astype(np.float32)
+    k["y"][pile] = (150.0 + rng.uniform(-3, 3, pile.sum())).astype(np.float32)
+    k["octave"] = rng.integers(0, 8, n); k["angle"] = rng.uniform(0, 360, n).astype(np.float32); k["size"] = 31; k["class_id"] = -1
+    d = _rand_desc(rng, n)
+    sf = np.array([np.float32(1.2) ** i for i in range(8)], np.float32)
+    fv = FrameView(k, d, 0, w, 0, h); of = ol.OracleFrame(k, d, sf, 0, w, 0, h)
+    nq = 96
+    q = make_queries(nq)
+    q["u"] = np.concatenate([rng.uniform(0, w, nq - 16), np.full(8, 300.0), np.full(8, 911.5)]).astype(np.float32)
+    q["v"] = np.concatenate([rng.uniform(0, h, nq - 16), np.full(16, 150.0)]).astype(np.float32)
+    q["u_r"] = q["u"]; q["radius"] = rng.uniform(4, 30, nq).astype(np.float32)
+    q["min_level"] = -1; q["max_level"] = -1
+    q["min_level"][::3] = 2; q["max_level"][::3] = 5
+    q["valid"] = 1; q["blocks"] = 1; q["desc"] = _rand_desc(rng, nq)
+    cand, cnt = ORBmatcher().ProjCandidates(fv, q, max_cand=4096)
+    for i in range(nq):
+        idx = of.features_in_area(float(q["u"][i]), float(q["v"][i]), float(q["radius"][i]), int(q["min_level"][i]), int(q["max_level"][i]))
+        assert cnt[i] == len(idx), i
+        m_ = min(len(idx), 4096)
+        np.testing.assert_array_equal(cand[i, :m_]["idx"], np.asarray(idx[:m_], np.int32), err_msg=f"query {i}")
+    assert cnt.max() > 100
+
+
 @pytest.mark.parametrize("geom,th", [((1241, 376, 2000), 7.0), ((640, 480, 1000), 15.0), ((640, 480, 1000), 40.0)])
 def test_search_by_projection_frame(geom, th):
     w, h, nf = geom
