@@ -481,27 +481,95 @@ __global__ __launch_bounds__(256) void proj_best_kernel(FrameBatch F, QueryBatch
   }
 }
 
-// One wave per query: candidate lists in enumeration order.
+// Candidate lists in enumeration order, SIXTEEN LANES PER QUERY (four queries per wave).  A search window holds a handful of
+// grid entries (2.8 survivors per query at th = 7), so a whole wave per query left three quarters of the lanes idle and the
+// kernel latency-bound on its four dependent round trips (query, cell ranges, cell records, descriptors) at full occupancy;
+// with four queries per wave a quarter of the waves make those trips.  Same order as enumerate_window: the window's grid
+// columns left to right (lane c of the group fetches column c's CSR range; 16 columns per batch), entries of the concatenated
+// ranges 16 at a time, survivors ranked by a ballot inside the group.
 __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, QueryBatch Q, orbfe_cand* __restrict__ cand,
                                                                int32_t* __restrict__ n_cand, int max_cand) {
   const int f = blockIdx.y;
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qi >= Q.cap) return;
-  // count, query record and query descriptor in ONE round trip (slot qi < cap is always readable)
-  const orbfe_query* qp = Q.q + (size_t)f * Q.cap + qi;
+  const int lane = threadIdx.x & (WAVE - 1), sl = lane & 15, gbase = lane & 48;
+  const int qi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const int nq = Q.n[f];
-  const orbfe_query q = *qp;
+  // the group's query: every lane of the group reads the same record (slot min(qi, cap - 1) is always readable)
+  const orbfe_query* qp = Q.q + (size_t)f * Q.cap + min(qi, Q.cap - 1);
+  const float x = qp->u, y = qp->v, r = qp->radius, qur = qp->u_r;
+  const int min_level = qp->min_level, max_level = qp->max_level;
+  const bool live = qi < nq && qi < Q.cap;
+  bool act = live && qp->valid;
   uint4 q0, q1;
   load_desc4(qp->desc, q0, q1);
-  if (qi >= nq) return;
-  orbfe_cand* out = cand + ((size_t)f * Q.cap + qi) * max_cand;
+  const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.gw_inv));
+  const int nMaxCellX = min(ORBFE_GRID_COLS - 1, (int)ceilf((x - F.min_x + r) * F.gw_inv));
+  const int nMinCellY = max(0, (int)floorf((y - F.min_y - r) * F.gh_inv));
+  const int nMaxCellY = min(ORBFE_GRID_ROWS - 1, (int)ceilf((y - F.min_y + r) * F.gh_inv));
+  if (nMinCellX >= ORBFE_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ORBFE_GRID_ROWS || nMaxCellY < 0) act = false;   // Frame.cc:347-366
+  const bool bCheckLevels = (min_level > 0) || (max_level >= 0);
+  const uint8_t* desc = F.desc + (size_t)f * F.cap * 32;
+  const bool has_ur = F.u_right != nullptr;
+  const int32_t* cs = F.cell_start + (size_t)f * (GRID_CELLS + 1);
+  const uint4* cr = reinterpret_cast<const uint4*>(F.cell_rec) + (size_t)f * F.cap;
+  orbfe_cand* out = cand + ((size_t)f * Q.cap + min(qi, Q.cap - 1)) * max_cand;
+  const int ncol = act ? nMaxCellX - nMinCellX + 1 : 0;
   int total = 0;
-  if (q.valid) {
-    total = enumerate_window(F, f, q, q0, q1, [&](int rank, int idx, int dist, int oct) {
-      if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = dist | (oct << 16); }
-    });
+  for (int cb = 0; __any(cb < ncol); cb += 16) {
+    int e0c = 0, cntc = 0;
+    if (cb + sl < ncol) {
+      const int ix = nMinCellX + cb + sl;
+      e0c = cs[ix * ORBFE_GRID_ROWS + nMinCellY];
+      cntc = cs[ix * ORBFE_GRID_ROWS + nMaxCellY + 1] - e0c;
+    }
+    int inclc = cntc;   // inclusive scan inside the 16-lane row
+    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x111, 0xf, 0xf, false);
+    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x112, 0xf, 0xf, false);
+    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x114, 0xf, 0xf, false);
+    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x118, 0xf, 0xf, false);
+    const int exclc = inclc - cntc;
+    const int n_entries = __shfl(inclc, gbase | 15, WAVE);
+    const int ncb = max(0, min(16, ncol - cb));            // columns of this batch (group-uniform)
+    int ncb_max = ncb;                                     // wave-uniform loop bound
+    ncb_max = max(ncb_max, __shfl_xor(ncb_max, 16, WAVE));
+    ncb_max = max(ncb_max, __shfl_xor(ncb_max, 32, WAVE));
+    ncb_max = __builtin_amdgcn_readfirstlane(ncb_max);
+    for (int base = 0; __any(base < n_entries); base += 16) {
+      const int t = base + sl;
+      int ent = -1;
+      for (int c = 0; c < ncb_max; c++) {
+        const int oc = __shfl(exclc, gbase | c, WAVE), nc = __shfl(cntc, gbase | c, WAVE), ec = __shfl(e0c, gbase | c, WAVE);
+        if (c < ncb && t >= oc && t < oc + nc) ent = ec + (t - oc);
+      }
+      bool ok = false;
+      int idx = 0, oct = 0;
+      if (ent >= 0) {
+        const uint4 rec = cr[ent];
+        idx = (int)(rec.x & 0xFFFFFFu);
+        oct = (int)(rec.x >> 24);
+        const float kx = __int_as_float((int)rec.y), ky = __int_as_float((int)rec.z), kur = __int_as_float((int)rec.w);
+        ok = true;
+        if (bCheckLevels) {
+          if (oct < min_level) ok = false;
+          if (max_level >= 0 && oct > max_level) ok = false;
+        }
+        const float distx = kx - x, disty = ky - y;
+        if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+        if (ok && has_ur && kur > 0) {           // the matcher's stereo gate
+          const float er = fabsf(qur - kur);
+          if (er > r) ok = false;
+        }
+      }
+      const unsigned bits = (unsigned)((__ballot(ok) >> gbase) & 0xffffull);
+      if (ok) {
+        uint4 d0, d1;
+        load_desc(desc + (size_t)idx * 32, d0, d1);
+        const int rank = total + __popc(bits & ((1u << sl) - 1u));
+        if (rank < max_cand) { out[rank].idx = idx; out[rank].dist = hamming256(q0, q1, d0, d1) | (oct << 16); }
+      }
+      total += __popc(bits);
+    }
   }
-  if ((threadIdx.x & 63) == 0) n_cand[(size_t)f * Q.cap + qi] = total;
+  if (sl == 0 && live) n_cand[(size_t)f * Q.cap + qi] = total;
 }
 
 // ComputeThreeMaxima (L/src/ORBmatcher.cc:1506-1538)
@@ -561,6 +629,7 @@ __device__ __forceinline__ void rc_take(uint32_t e, uint32_t& e1, uint32_t& e2) 
 #define RC_LIST_CAP 16384  // staged candidate entries per chunk (64 KiB): what does not fit the registers
 #define RC_REG 4           // candidates per query kept in registers
 #define RC_INVALID 0xFFFFFFFFu
+#define RC_TAG_MAX 0x1fffff // claim words: (RC_TAG_MAX - round) << 10 | thread, 0x7fffffff = never claimed
 __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, QueryBatch Q, const orbfe_cand* __restrict__ cand,
                                                            const int32_t* __restrict__ n_cand, int max_cand, int mode, int th_high,
                                                            float nnratio, int check_ori, uint8_t* __restrict__ blocked_all,
@@ -598,6 +667,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
   RS_T(0);   // set-up
   const bool use_hist = (mode == 1) && check_ori;
   int q0 = 0;
+  int round = 1;   // counts on across chunks: stamps the claims
   while (q0 < nq) {
     RS_COUNT(8);
     const int qi = q0 + tid;
@@ -697,127 +767,154 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
       q0 += 1;
       continue;
     }
-    // ---- the chunk's candidates, packed dist<<20 | octave<<16 | idx; RC_INVALID = beyond the count, or the keypoint is blocked
-    // (blocked[] only changes when a chunk commits, so the filter holds for every iteration below).  The first RC_REG stay in
-    // registers; longer lists (rare: 2.8 candidates per query on average at th = 7, 6.7 at th = 15) put the rest in LDS.
+    // ---- the chunk's candidates, packed dist<<20 | octave<<16 | idx, COMPACTED in list order: an entry is dropped when its
+    // keypoint is blocked (blocked[] only changes when a chunk commits, so that holds for every round below) or when its distance
+    // cannot matter -- beyond th_high it is never accepted, and as a second-best (mode 0) it rejects the best one only while
+    // nnratio * d < th_high.  What is left is the true match and a near miss or two: the first RC_REG entries stay in registers,
+    // a longer list puts the rest in LDS (and its owner re-selects in every round).
     uint32_t creg[RC_REG];
+#pragma unroll
+    for (int u = 0; u < RC_REG; u++) creg[u] = RC_INVALID;
+    int kept = 0, nover = 0;
+    auto matters = [&](uint32_t d) {
+      return d <= (uint32_t)th_high || (mode == 0 && d < 256u && nnratio * (float)d < (float)th_high);
+    };
 #pragma unroll
     for (int u = 0; u < RC_REG; u++) {
       const uint32_t idx = craw[u].x & 0xffffu, dd = craw[u].y;
       const uint32_t e = ((dd & 0xffffu) << 20) | (((dd >> 16) & 0xfu) << 16) | idx;
-      // (a distance of 256 never beats the reference's initial bestDist = 256: such an entry does not exist for the walk)
-      creg[u] = (tid < len && u < tot && (dd & 0xffffu) < 256u && !blocked[min(idx, (uint32_t)F.cap - 1u)]) ? e : RC_INVALID;
+      const bool ok = tid < len && u < tot && matters(dd & 0xffffu) && !blocked[min(idx, (uint32_t)F.cap - 1u)];
+#pragma unroll
+      for (int j = 0; j <= u; j++) creg[j] = (ok && kept == j) ? e : creg[j];
+      kept += ok;
     }
-    const int nover = (tid < len) ? max(tot - RC_REG, 0) : 0;
     {
+      const int nraw = (tid < len) ? max(tot - RC_REG, 0) : 0;
       const uint2* row = reinterpret_cast<const uint2*>(cand + ((size_t)f * Q.cap + qi) * max_cand) + RC_REG;
       uint32_t* dstl = lc + loff[tid < len ? tid : 0];
-      for (int c0 = 0; c0 < nover; c0 += 4) {
+      for (int c0 = 0; c0 < nraw; c0 += 4) {
         uint2 r[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) r[u] = row[min(c0 + u, nover - 1)];
+        for (int u = 0; u < 4; u++) r[u] = row[min(c0 + u, nraw - 1)];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          if (c0 + u >= nover) break;
           const uint32_t idx = r[u].x & 0xffffu, dd = r[u].y;
-          dstl[c0 + u] = (blocked[idx] || (dd & 0xffffu) >= 256u) ? RC_INVALID : (((dd & 0xffffu) << 20) | (((dd >> 16) & 0xfu) << 16) | idx);
+          if (c0 + u >= nraw || !matters(dd & 0xffffu) || blocked[idx]) continue;
+          const uint32_t e = ((dd & 0xffffu) << 20) | (((dd >> 16) & 0xfu) << 16) | idx;
+          if (kept < RC_REG) {
+#pragma unroll
+            for (int j = 0; j < RC_REG; j++) creg[j] = (kept == j) ? e : creg[j];
+          } else {
+            dstl[nover++] = e;
+          }
+          kept++;
         }
       }
     }
     __syncthreads();
     RS_T(2);   // staging
-    const bool active = tid < len && tot > 0;
+    const bool active = kept > 0;
     const uint32_t* mylist = lc + loff[tid < len ? tid : 0];
     // Fixed-point iteration over the chunk.  Thread t's choice = best candidate that is neither blocked nor
-    // claimed (blocked-to-be) by an EARLIER thread of the chunk; claims come from the previous iteration.
-    // Thread t's choice is final after at most t+1 iterations (it only depends on earlier threads), so the
-    // iteration converges to exactly the sequential result; in practice the dependency chains are 2-4 deep.
+    // claimed (blocked-to-be) by an EARLIER thread of the chunk; claims come from the previous round.
+    // Thread t's choice is final after at most t+1 rounds (it only depends on earlier threads), so the
+    // iteration converges to exactly the sequential result; in practice the dependency chains are 2-5 deep.
+    // One barrier per round: a claim is the word (RC_TAG_MAX - round) << 10 | thread, written by atomicMin into the buffer of
+    // the round's parity and read back from the other buffer in the next round -- a newer round always wins the min, an older
+    // word fails the tag test, so nothing is ever cleared (rounds count on across chunks; 2^21 of them fit).  The "somebody
+    // changed" flag carries the round number the same way.  A barrier costs ~0.5 us with sixteen waves, a round hardly more.
     // state = the two best entries; RC_INVALID (distance field 0xfff) = none.  Plain 32-bit values only: bool flags updated
     // through a by-reference lambda ended up in scratch memory, several private-memory round trips per iteration (7 k cycles).
     uint32_t e1 = RC_INVALID, e2 = RC_INVALID;
+    uint32_t pmask = ~0u;   // which of the register candidates an earlier query claimed, previous round
     int accept = 0;
-    int myclaim = -1;
-    for (int iter = 0;; iter++) {
-      int* cprev = (iter & 1) ? claimB : claim;
-      int* cnew = (iter & 1) ? claim : claimB;
-      const uint32_t pe1 = e1, pe2 = e2;
-      e1 = e2 = RC_INVALID;
-      accept = 0;
+    for (int iter = 0;; iter++, round++) {
+      const int* cprev = (round & 1) ? claim : claimB;   // written in round - 1
+      int* cnew = (round & 1) ? claimB : claim;
+      const int want = (RC_TAG_MAX - (round - 1));       // tag of a claim made in the previous round
+      bool changed = false;
       if (active) {
-        {
-          int cl[RC_REG];
+        int cl[RC_REG];
+        uint32_t m = 0;
+        if (iter > 0) {   // (the previous round of the first iteration belongs to the chunk before: no claims yet)
 #pragma unroll
           for (int u = 0; u < RC_REG; u++) cl[u] = cprev[creg[u] == RC_INVALID ? 0 : (int)(creg[u] & 0xffffu)];
 #pragma unroll
-          for (int u = 0; u < RC_REG; u++) {
-            const uint32_t e = (cl[u] < tid) ? RC_INVALID : creg[u];   // claimed by an earlier query of the chunk
-            rc_take(e, e1, e2);
-          }
+          for (int u = 0; u < RC_REG; u++)
+            m |= (creg[u] != RC_INVALID && (cl[u] >> 10) == want && (cl[u] & (RC_THREADS - 1)) < tid) ? (1u << u) : 0u;
         }
-        for (int c0 = 0; c0 < nover; c0 += 4) {  // 4 candidates in flight: independent LDS loads first, then the scan
-          uint32_t ev[4];
-          int cl[4];
+        // The choice is a function of the claim pattern alone: same pattern, same choice.
+        if (m != pmask || nover > 0) {
+          pmask = m;
+          const uint32_t pe1 = e1, pe2 = e2;
+          e1 = e2 = RC_INVALID;
+          accept = 0;
 #pragma unroll
-          for (int u = 0; u < 4; u++) ev[u] = (c0 + u < nover) ? mylist[c0 + u] : RC_INVALID;
+          for (int u = 0; u < RC_REG; u++) rc_take(((m >> u) & 1u) ? RC_INVALID : creg[u], e1, e2);
+          for (int c0 = 0; c0 < nover; c0 += 4) {  // 4 candidates in flight: independent LDS loads first, then the scan
+            uint32_t ev[4];
+            int co[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) cl[u] = cprev[ev[u] == RC_INVALID ? 0 : (int)(ev[u] & 0xffffu)];
+            for (int u = 0; u < 4; u++) ev[u] = (c0 + u < nover) ? mylist[c0 + u] : RC_INVALID;
 #pragma unroll
-          for (int u = 0; u < 4; u++) rc_take((cl[u] < tid) ? RC_INVALID : ev[u], e1, e2);
-        }
-        if (e1 != RC_INVALID) {
-          const int bestDist = (int)(e1 >> 20);
-          if (mode == 0) {
-            const int bestDist2 = e2 != RC_INVALID ? (int)(e2 >> 20) : 256;
-            const int bestLevel = (int)((e1 >> 16) & 0xf), bestLevel2 = e2 != RC_INVALID ? (int)((e2 >> 16) & 0xf) : -1;
-            accept = bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
-          } else {
-            accept = bestDist <= th_high;
+            for (int u = 0; u < 4; u++) co[u] = cprev[ev[u] == RC_INVALID ? 0 : (int)(ev[u] & 0xffffu)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool taken = iter > 0 && (co[u] >> 10) == want && (co[u] & (RC_THREADS - 1)) < tid;
+              rc_take(taken ? RC_INVALID : ev[u], e1, e2);
+            }
           }
+          if (e1 != RC_INVALID) {
+            const int bestDist = (int)(e1 >> 20);
+            if (mode == 0) {
+              const int bestDist2 = e2 != RC_INVALID ? (int)(e2 >> 20) : 256;
+              const int bestLevel = (int)((e1 >> 16) & 0xf), bestLevel2 = e2 != RC_INVALID ? (int)((e2 >> 16) & 0xf) : -1;
+              accept = bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+            } else {
+              accept = bestDist <= th_high;
+            }
+          }
+          changed = e1 != pe1 || e2 != pe2;
         }
       }
       const int bestIdx = (int)(e1 & 0xffff);
-      const bool blk = accept && qblocks;
-      if (blk) atomicMin(&cnew[bestIdx], tid);
-      if (iter == 0 || e1 != pe1 || e2 != pe2) sh_changed[iter & 1] = 1;
-      RS_T(6);   // (iterations: wave 0's own scan)
+      if (accept && qblocks) atomicMin(&cnew[bestIdx], ((RC_TAG_MAX - round) << 10) | tid);
+      if (iter == 0 || changed) sh_changed[round & 1] = round;
       __syncthreads();
-      RS_T(7);   // (iterations: wait at the first barrier)
-      const int again = sh_changed[iter & 1];
-      if (myclaim >= 0) cprev[myclaim] = 0x7fffffff;  // everybody is done reading cprev: recycle it as the next cnew
-      myclaim = blk ? bestIdx : -1;
-      if (tid == 0) sh_changed[(iter + 1) & 1] = 0;
-      __syncthreads();
-      RS_T(3);   // fixed-point iterations
+      RS_T(3);   // fixed-point rounds
       RS_COUNT(9);
-      if (!again) {
-        // converged: commit every accepted query of the chunk.  Several queries may take the same keypoint
-        // (only when the earlier ones do not block it): the last one in query order wins, as in the reference.
-        if (active && accept) atomicMin(&cprev[bestIdx], RC_THREADS - 1 - tid);
-        __syncthreads();
-        if (active && accept) {
-          if (cprev[bestIdx] == RC_THREADS - 1 - tid) {
-            assigned[bestIdx] = qi;
-            blocked[bestIdx] = (uint8_t)qblocks;
-          }
-          atomicAdd(&sh_nm, 1);
-          if (use_hist) {
-            float rot = qangle - keys[bestIdx].angle;
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));  // the reference's factor (sic), :1255
-            if (bin == ORBFE_HISTO_LENGTH) bin = 0;
-            const int pos = atomicAdd(&sh_npush, 1);
-            push_idx[pos] = bestIdx;
-            push_bin[pos] = (uint8_t)bin;
-            atomicAdd(&hist[bin], 1);
-          }
+#ifdef RS_X_FIXED
+      if ((sh_changed[round & 1] == round && RS_X_FIXED == 0) || iter < RS_X_FIXED - 1) continue;
+#else
+      if (sh_changed[round & 1] == round) continue;
+#endif
+      // converged: commit every accepted query of the chunk.  Several queries may take the same keypoint
+      // (only when the earlier ones do not block it): the last one in query order wins, as in the reference.
+      round++;
+      int* cw = (round & 1) ? claimB : claim;
+      const int mine = ((RC_TAG_MAX - round) << 10) | (RC_THREADS - 1 - tid);
+      if (active && accept) atomicMin(&cw[bestIdx], mine);
+      __syncthreads();
+      if (active && accept) {
+        if (cw[bestIdx] == mine) {
+          assigned[bestIdx] = qi;
+          blocked[bestIdx] = (uint8_t)qblocks;
         }
-        __syncthreads();
-        if (active && accept) cprev[bestIdx] = 0x7fffffff;
-        if (myclaim >= 0) cnew[myclaim] = 0x7fffffff;
-        __syncthreads();
-        RS_T(4);   // commit
-        break;
+        atomicAdd(&sh_nm, 1);
+        if (use_hist) {
+          float rot = qangle - keys[bestIdx].angle;
+          if (rot < 0.0f) rot += 360.0f;
+          int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));  // the reference's factor (sic), :1255
+          if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+          const int pos = atomicAdd(&sh_npush, 1);
+          push_idx[pos] = bestIdx;
+          push_bin[pos] = (uint8_t)bin;
+          atomicAdd(&hist[bin], 1);
+        }
       }
+      round++;   // (no barrier here: the next chunk's first round writes the other buffer, and its set-up has barriers of its own)
+      RS_T(4);   // commit
+      break;
     }
     q0 += len;
   }
@@ -1471,7 +1568,7 @@ void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {
 void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
                                   int max_cand, int n_frames, hipStream_t s) {
   if (q.cap < 1) return;
-  dim3 grid((q.cap + 3) / 4, n_frames);
+  dim3 grid((q.cap + 15) / 16, n_frames);   // 16 queries per 256-thread block
   hipLaunchKernelGGL(proj_candidates_kernel, grid, dim3(256), 0, s, f, q, cand, n_cand, max_cand);
 }
 void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
