@@ -883,11 +883,7 @@ __global__ __launch_bounds__(RC_THREADS) void proj_resolve_kernel(FrameBatch F, 
       __syncthreads();
       RS_T(3);   // fixed-point rounds
       RS_COUNT(9);
-#ifdef RS_X_FIXED
-      if ((sh_changed[round & 1] == round && RS_X_FIXED == 0) || iter < RS_X_FIXED - 1) continue;
-#else
       if (sh_changed[round & 1] == round) continue;
-#endif
       // converged: commit every accepted query of the chunk.  Several queries may take the same keypoint
       // (only when the earlier ones do not block it): the last one in query order wins, as in the reference.
       round++;

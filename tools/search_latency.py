@@ -49,7 +49,7 @@ if True:
         for _ in range(100):
             call()
         fn(out, 0)
-        names = ["set-up", "query records + scan", "staging", "iterations", "commit", "rotation check + write-back"]
-        tot = sum(out[i] for i in range(8))
+        names = ["set-up", "query records + scan", "staging", "rounds", "commit", "rotation check + write-back"]
+        tot = sum(out[i] for i in range(6))
         print("proj_resolve phases, cycles per call (workgroup 0): " + ", ".join(f"{n} {out[i] / 100:.0f}" for i, n in enumerate(names)) +
-              f"; of the iterations: wave 0's scan {out[6] / 100:.0f}, first barrier {out[7] / 100:.0f}; total {tot / 100:.0f}; chunks {out[8] / 100:.1f}, iterations {out[9] / 100:.1f}")
+              f"; total {tot / 100:.0f}; chunks {out[8] / 100:.1f}, rounds {out[9] / 100:.1f}")
