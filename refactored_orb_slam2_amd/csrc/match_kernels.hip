@@ -487,11 +487,16 @@ __global__ __launch_bounds__(256) void proj_best_kernel(FrameBatch F, QueryBatch
 // with four queries per wave a quarter of the waves make those trips.  Same order as enumerate_window: the window's grid
 // columns left to right (lane c of the group fetches column c's CSR range; 16 columns per batch), entries of the concatenated
 // ranges 16 at a time, survivors ranked by a ballot inside the group.
+#ifndef ORBFE_CAND_LANES
+#define ORBFE_CAND_LANES 16
+#endif
+template <int G>   // lanes per query: 16 or 8
 __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, QueryBatch Q, orbfe_cand* __restrict__ cand,
                                                                int32_t* __restrict__ n_cand, int max_cand) {
   const int f = blockIdx.y;
-  const int lane = threadIdx.x & (WAVE - 1), sl = lane & 15, gbase = lane & 48;
-  const int qi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  constexpr int QPW = WAVE / G;   // queries per wave
+  const int lane = threadIdx.x & (WAVE - 1), sl = lane & (G - 1), gbase = lane & ~(G - 1);
+  const int qi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * QPW + lane / G;
   const int nq = Q.n[f];
   // the group's query: every lane of the group reads the same record (slot min(qi, cap - 1) is always readable)
   const orbfe_query* qp = Q.q + (size_t)f * Q.cap + min(qi, Q.cap - 1);
@@ -514,26 +519,27 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, Quer
   orbfe_cand* out = cand + ((size_t)f * Q.cap + min(qi, Q.cap - 1)) * max_cand;
   const int ncol = act ? nMaxCellX - nMinCellX + 1 : 0;
   int total = 0;
-  for (int cb = 0; __any(cb < ncol); cb += 16) {
+  for (int cb = 0; __any(cb < ncol); cb += G) {
     int e0c = 0, cntc = 0;
     if (cb + sl < ncol) {
       const int ix = nMinCellX + cb + sl;
       e0c = cs[ix * ORBFE_GRID_ROWS + nMinCellY];
       cntc = cs[ix * ORBFE_GRID_ROWS + nMaxCellY + 1] - e0c;
     }
-    int inclc = cntc;   // inclusive scan inside the 16-lane row
-    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x111, 0xf, 0xf, false);
-    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x112, 0xf, 0xf, false);
-    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x114, 0xf, 0xf, false);
-    inclc += __builtin_amdgcn_update_dpp(0, inclc, 0x118, 0xf, 0xf, false);
+    int inclc = cntc;   // inclusive scan inside the group (DPP row shifts; a shift that would cross into the group below adds 0)
+    { const int a = __builtin_amdgcn_update_dpp(0, inclc, 0x111, 0xf, 0xf, false); inclc += sl >= 1 ? a : 0; }
+    { const int a = __builtin_amdgcn_update_dpp(0, inclc, 0x112, 0xf, 0xf, false); inclc += sl >= 2 ? a : 0; }
+    { const int a = __builtin_amdgcn_update_dpp(0, inclc, 0x114, 0xf, 0xf, false); inclc += sl >= 4 ? a : 0; }
+    if (G > 8) { const int a = __builtin_amdgcn_update_dpp(0, inclc, 0x118, 0xf, 0xf, false); inclc += sl >= 8 ? a : 0; }
     const int exclc = inclc - cntc;
-    const int n_entries = __shfl(inclc, gbase | 15, WAVE);
-    const int ncb = max(0, min(16, ncol - cb));            // columns of this batch (group-uniform)
+    const int n_entries = __shfl(inclc, gbase | (G - 1), WAVE);
+    const int ncb = max(0, min(G, ncol - cb));             // columns of this batch (group-uniform)
     int ncb_max = ncb;                                     // wave-uniform loop bound
+    if (G < 16) ncb_max = max(ncb_max, __shfl_xor(ncb_max, 8, WAVE));
     ncb_max = max(ncb_max, __shfl_xor(ncb_max, 16, WAVE));
     ncb_max = max(ncb_max, __shfl_xor(ncb_max, 32, WAVE));
     ncb_max = __builtin_amdgcn_readfirstlane(ncb_max);
-    for (int base = 0; __any(base < n_entries); base += 16) {
+    for (int base = 0; __any(base < n_entries); base += G) {
       const int t = base + sl;
       int ent = -1;
       for (int c = 0; c < ncb_max; c++) {
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(FrameBatch F, Quer
           if (er > r) ok = false;
         }
       }
-      const unsigned bits = (unsigned)((__ballot(ok) >> gbase) & 0xffffull);
+      const unsigned bits = (unsigned)((__ballot(ok) >> gbase) & ((1ull << G) - 1ull));
       if (ok) {
         uint4 d0, d1;
         load_desc(desc + (size_t)idx * 32, d0, d1);
@@ -1564,8 +1570,9 @@ void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {
 void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
                                   int max_cand, int n_frames, hipStream_t s) {
   if (q.cap < 1) return;
-  dim3 grid((q.cap + 15) / 16, n_frames);   // 16 queries per 256-thread block
-  hipLaunchKernelGGL(proj_candidates_kernel, grid, dim3(256), 0, s, f, q, cand, n_cand, max_cand);
+  constexpr int G = ORBFE_CAND_LANES;       // lanes per query
+  dim3 grid((q.cap + 4 * (64 / G) - 1) / (4 * (64 / G)), n_frames);
+  hipLaunchKernelGGL(proj_candidates_kernel<G>, grid, dim3(256), 0, s, f, q, cand, n_cand, max_cand);
 }
 void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const orbfe_cand* cand, const int32_t* n_cand,
                                int max_cand, int mode, int th_high, float nnratio, int check_ori, uint8_t* blocked,
