@@ -593,12 +593,11 @@ __device__ void three_maxima(const int* hs, int L, int& ind1, int& ind2, int& in
 }
 
 // Order-dependent assignment of SearchByProjection.  One 1024-thread workgroup per frame.  Queries are taken
-// up to RC_THREADS (1024) at a time (one per thread) and resolved SPECULATIVELY against the current blocked[] state; a
-// thread's result is exact unless an earlier thread of the same chunk blocks its best (mode 0: best or
-// second-best) candidate.  Threads before the first such conflict commit together, the rest are recomputed --
-// the outcome is identical to walking the queries one by one (L/src/ORBmatcher.cc:52-125, 1270-1361), and
-// conflicts are rare.  A query whose candidate list was truncated (> max_cand) ends the chunk and is handled
-// alone by wave 0, which re-enumerates its window.
+// up to RC_THREADS (1024) at a time, one per thread, and resolved by a fixed-point iteration against the blocked[] state the
+// chunks before left: a thread's choice is its best candidate (mode 0: best and second-best) that no EARLIER thread of the chunk
+// claims; claims are exchanged once per round, and the rounds converge to exactly the result of walking the queries one by one
+// (L/src/ORBmatcher.cc:52-125, 1270-1361).  A query whose candidate list was truncated (> max_cand) ends the chunk and is
+// handled alone by wave 0, which re-enumerates its window.
 // mode 0: SearchByProjection(Frame&, vector<MapPoint*>&)   -- best/second with the same-level ratio test
 // mode 1: SearchByProjection(Frame& cur, const Frame& last) -- best only, th_high = TH_HIGH, rotation histogram;
 //         SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist) is the same walk with th_high = ORBdist (:1385-1504)
@@ -623,8 +622,9 @@ extern "C" int orbfe_debug_rs_profile(unsigned long long* out, int reset) {
 #define RS_END()
 #endif
 // best / second-best entry by distance, first one wins ties (the reference's strict "<"); RC_INVALID loses against everything.
-// Values in, values out, no branches: with references (or a by-reference lambda) the compiler kept the pair in scratch memory
-// and selected the ADDRESS to store to -- private-memory round trips inside the fixed-point loop (7 k cycles per iteration).
+// The pair is read into locals and written back with selects, no branches: with `if (...) e1 = e; else e2 = e;` on references (or a
+// by-reference lambda) the compiler kept the pair in scratch memory and selected the ADDRESS to store to -- private-memory round
+// trips inside the fixed-point loop (7 k cycles per round).
 __device__ __forceinline__ void rc_take(uint32_t e, uint32_t& e1, uint32_t& e2) {
   const uint32_t a = e1, b = e2;
   const bool lt1 = (e >> 20) < (a >> 20), lt2 = (e >> 20) < (b >> 20);
