@@ -398,8 +398,11 @@ def test_search_by_projection_keyframe(th, orb_dist):
         np.testing.assert_array_equal(blocked, oblocked)
 
 
-@pytest.mark.parametrize("geom,th,ratio", [((1241, 376, 2000), 1.0, 0.8), ((640, 480, 1000), 3.0, 0.8), ((752, 480, 1200), 5.0, 0.6)])
+@pytest.mark.parametrize("geom,th,ratio", [((1241, 376, 2000), 1.0, 0.8), ((640, 480, 1000), 3.0, 0.8), ((752, 480, 1200), 5.0, 0.6),
+                                           ((640, 480, 1000), 3.0, 0.3), ((640, 480, 1000), 5.0, 0.95), ((640, 480, 1000), 3.0, 1.25)])
 def test_search_by_projection_points(geom, th, ratio):
+    """ratios 0.3 / 0.95 / 1.25: the resolver drops candidates whose distance cannot matter (beyond TH_HIGH and nnratio * d >=
+    TH_HIGH); the cut moves with the ratio -- no cut at all at 0.3, at TH_HIGH itself from 1.0 on -- and must never change a result"""
     w, h, nf = geom
     k0, d0, k1, d1, sf = _two_frames(w, h, nf)
     rng = np.random.default_rng(9)
