@@ -1274,150 +1274,188 @@ __device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) 
   asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-#ifndef FC_TIMING
-#define FC_TIMING 0
+// DPP rotations inside a row of 16 lanes: every lane of the row ends up with the row's minimum / sum / or
+#define ORBFE_ROW_ALL(op, v) do { \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false)); /* row_ror:8 */ \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false)); /* row_ror:4 */ \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false)); /* row_ror:2 */ \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false)); /* row_ror:1 */ \
+  } while (0)
+__device__ __forceinline__ unsigned op_min_u(unsigned a, unsigned b) { return min(a, b); }
+__device__ __forceinline__ unsigned op_add_u(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned op_or_u(unsigned a, unsigned b) { return a | b; }
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) { ORBFE_ROW_ALL(op_min_u, v); return v; }
+__device__ __forceinline__ unsigned row_sum_u32(unsigned v) { ORBFE_ROW_ALL(op_add_u, v); return v; }
+__device__ __forceinline__ unsigned row_or_u32(unsigned v) { ORBFE_ROW_ALL(op_or_u, v); return v; }
+
+// Per-level constants a lane needs once its keypoint's level is a per-lane value (kernel arguments cannot be indexed by a VGPR)
+struct SmLevel {
+  const uint8_t* baseL; const uint8_t* baseR;
+  unsigned long long strideL, strideR;
+  int pitchL, pitchR, wL, hL, wR, hR;
+  float scale, inv_scale;
+};
+#define SM_G 16                      // lanes per left keypoint
+#define SM_KPB (256 / SM_G)          // left keypoints per workgroup
+#ifndef SM_ROUNDS
+#define SM_ROUNDS 2
 #endif
-#if FC_TIMING
-// -DFC_TIMING=1 (tools/fc_phase_profile.py): wave-cycles of stereo_match_kernel per phase, 4096 accumulation slots
-__device__ unsigned long long g_sm_prof[4096 * 8];
-extern "C" int orbfe_debug_sm_profile(unsigned long long* out, int reset) {
-  static unsigned long long h[4096 * 8];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sm_prof), sizeof(h)) != hipSuccess) return 1;
-  for (int i = 0; i < 8; i++) out[i] = 0;
-  for (int sl = 0; sl < 4096; sl++)
-    for (int i = 0; i < 8; i++) out[i] += h[sl * 8 + i];
-  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_sm_prof), h, sizeof(h)) != hipSuccess) return 1; }
-  return 0;
-}
-#define SM_T(i) do { const uint32_t _t = (uint32_t)__builtin_readcyclecounter(); tacc##i += _t - tprev; tprev = _t; } while (0)
-#define SM_END() do { if (lane == 0) { unsigned long long* pr = g_sm_prof + (size_t)((((unsigned)iL + 4099u * (unsigned)pair) * 2654435761u) >> 20) * 8; \
-    atomicAdd(&pr[0], (unsigned long long)tacc0); atomicAdd(&pr[1], (unsigned long long)tacc1); atomicAdd(&pr[2], (unsigned long long)tacc2); \
-    atomicAdd(&pr[3], (unsigned long long)tacc3); atomicAdd(&pr[4], (unsigned long long)tacc4); atomicAdd(&pr[5], (unsigned long long)tacc5); \
-    atomicAdd(&pr[6], 1ull); } } while (0)
-#else
-#define SM_T(i)
-#define SM_END()
-#endif
-#define SAD_LP 20   // LDS pitch of the staged left window (5 dwords)
-#define SAD_RP 24   // LDS pitch of the staged right window (6 dwords)
+// SM_ROUNDS: bucket entries requested up front per keypoint: SM_ROUNDS * SM_G
+#define SAD_LP 16   // LDS pitch of the staged left window: 11 pixels at byte offset <= 3 of 4 aligned dwords
+#define SAD_RP 24   // LDS pitch of the staged right window: 21 pixels at byte offset <= 3 of 6 aligned dwords
+#define SAD_WIN (11 * SAD_LP + 11 * SAD_RP + 8)
+// Sixteen lanes per left keypoint, four keypoints per wave (L/src/Frame.cc:504-632).  What the whole-wave kernel paid once per
+// keypoint -- the wave-uniform set-up, six 64-lane reductions, the scalar epilogue -- is paid once per FOUR here: the keypoint's
+// own values live in the lanes of its DPP row, reductions are four row rotations, the first-minimum / parabola epilogue runs with
+// lane k = shift k.  A keypoint that drops out (no candidate, window outside the level) only idles its row; the wave leaves when
+// all four have.
 __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   const int pair = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1);
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sub = lane & (SM_G - 1);
+  const int grp = threadIdx.x / SM_G;
+  const int iL = blockIdx.x * SM_KPB + grp;
+  __shared__ SmLevel s_lv[ORBFE_MAX_LEVELS];
   __shared__ float s_r[ORBFE_MAX_LEVELS];  // r = 2 * scale[octave] of a right keypoint (L/src/Frame.cc:496)
-  __shared__ __attribute__((aligned(16))) uint8_t sad_win[4][11 * SAD_LP + 11 * SAD_RP + 16];
-  if (threadIdx.x < ORBFE_MAX_LEVELS) s_r[threadIdx.x] = 2.0f * P.scale[threadIdx.x];
+  __shared__ __attribute__((aligned(16))) uint8_t sad_win[SM_KPB][SAD_WIN];
+  __shared__ uint8_t s_offL[128], s_offR[128];   // window pixel p = 11 * yy + xx -> byte offset inside the staged windows
+  if (threadIdx.x >= 128) {
+    const unsigned p = threadIdx.x - 128, yy = p / 11u, xx = p - yy * 11u;
+    s_offL[p] = (uint8_t)(p < 121 ? yy * SAD_LP + xx : 0);
+    s_offR[p] = (uint8_t)(p < 121 ? yy * SAD_RP + xx : 0);
+  }
+  if (threadIdx.x < ORBFE_MAX_LEVELS) {
+    const int l = threadIdx.x;
+    const bool in = l < P.n_levels;
+    SmLevel v;
+    v.baseL = P.pyrL.base[l] + (size_t)pair * P.pyrL.img_stride[l];
+    v.baseR = P.pyrR.base[l] + (size_t)pair * P.pyrR.img_stride[l];
+    v.strideL = 0; v.strideR = 0;
+    v.pitchL = P.pyrL.pitch[l]; v.pitchR = P.pyrR.pitch[l];
+    v.wL = in ? P.pyrL.w[l] : 0; v.hL = in ? P.pyrL.h[l] : 0;
+    v.wR = in ? P.pyrR.w[l] : 0; v.hR = in ? P.pyrR.h[l] : 0;
+    v.scale = P.scale[l]; v.inv_scale = P.inv_scale[l];
+    s_lv[l] = v;
+    s_r[l] = 2.0f * P.scale[l];
+  }
   __syncthreads();
-  if (iL >= P.cap) return;
-  float* out_ur = P.u_right + (size_t)pair * P.cap;
-  float* out_depth = P.depth + (size_t)pair * P.cap;
-  int32_t* out_sad = P.sad + (size_t)pair * P.cap;
-  const orbfe_keypoint* kl = P.kpsL + (size_t)pair * P.cap;
-  const uint8_t* dl = P.descL + (size_t)pair * P.cap * 32;
-  const uint8_t* dr = P.descR + (size_t)pair * P.cap * 32;
-  // first round trip: count, left keypoint record and left descriptor together (slot iL < cap is always readable)
+  const int cap = P.cap, nl = P.n_levels;
+  float* out_ur = P.u_right + (size_t)pair * cap;
+  float* out_depth = P.depth + (size_t)pair * cap;
+  int32_t* out_sad = P.sad + (size_t)pair * cap;
+  const orbfe_keypoint* kl = P.kpsL + (size_t)pair * cap;
+  const uint8_t* dl = P.descL + (size_t)pair * cap * 32;
+  const uint8_t* dr = P.descR + (size_t)pair * cap * 32;
+  // first round trip: count, left keypoint record and left descriptor together (the slot is clamped into the array)
   const int nL = P.nL[pair];
-  const orbfe_keypoint kpL = kl[iL];
+  const int iLc = min(iL, cap - 1);
+  const float uL = kl[iLc].x, vL = kl[iLc].y;
+  const int octL = kl[iLc].octave;
   uint4 a0, a1;
-  load_desc(dl + (size_t)iL * 32, a0, a1);
-#if FC_TIMING
-  uint32_t tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tacc4 = 0, tacc5 = 0, tprev = (uint32_t)__builtin_readcyclecounter();
-#endif
-  if (lane == 0) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
-  if (iL >= nL) return;
-  // every lane read the same record: tell the compiler, so that the per-level parameters become scalar loads
-  const int levelL = __builtin_amdgcn_readfirstlane(kpL.octave);
-  const float vL = kpL.y, uL = kpL.x;
+  load_desc(dl + (size_t)iLc * 32, a0, a1);
+  if (sub == 0 && iL < cap) { out_ur[iL] = -1.0f; out_depth[iL] = -1.0f; out_sad[iL] = -1; }
+  const int levelL = min(max(octL, 0), nl - 1);
   const int nRows = P.pyrL.h[0];
-  const int row = __builtin_amdgcn_readfirstlane((int)vL);
-  if (row < 0 || row >= nRows) return;
+  const int row = (int)vL;
   const float minD = 0, maxD = P.maxD;
   const float minU = uL - maxD, maxU = uL - minD;
-  if (maxU < 0) return;
+  bool act = iL < nL && row >= 0 && row < nRows && !(maxU < 0);
+  const int32_t* bs = P.bucket_start + (size_t)pair * (P.n_keys + 1);
+  const int4* bent = reinterpret_cast<const int4*>(P.bucket_idx) + (size_t)pair * cap * STEREO_BUCKET_SPAN;
+  // the run of this row bucket's entries with octave levelL - 1 .. levelL + 1 (L/src/Frame.cc:538-539 keeps nothing else)
+  const int kb = act ? (row >> 3) * nl : 0;
+  const int e0 = bs[kb + max(levelL - 1, 0)];
+  const int e1 = act ? bs[kb + min(levelL + 1, nl - 1) + 1] : e0;
   unsigned best = ((unsigned)ORBFE_TH_HIGH << 16) | 0xffffu;  // bestDist starts at TH_HIGH; strict <
   float best_x = 0.f;                                         // x of this lane's best candidate
-  const int32_t* bs = P.bucket_start + (size_t)pair * (P.n_keys + 1);
-  const int4* bent = reinterpret_cast<const int4*>(P.bucket_idx) + (size_t)pair * P.cap * STEREO_BUCKET_SPAN;
-  // the run of this row bucket's entries with octave levelL - 1 .. levelL + 1 (L/src/Frame.cc:538-539 keeps nothing else)
-  const int kb = (row >> 3) * P.n_levels;
-  const int e0 = bs[kb + max(levelL - 1, 0)], e1 = bs[kb + min(levelL + 1, P.n_levels - 1) + 1];
-#if FC_TIMING
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-  SM_T(0);   // own record, descriptor, bucket range
-  // 64 entries per round: bucket records (index, x, y, octave), then -- for the survivors of the band / disparity tests --
-  // their descriptors: two memory round trips, and one round for all but a few left keypoints
-  for (int eb = e0; eb < e1; eb += WAVE) {
-    const int e = eb + lane;
-    const int4 rec = e < e1 ? bent[e] : make_int4(-1, 0, 0, 0);
-    const float rx = __int_as_float(rec.y), ry = __int_as_float(rec.z);
-    const float r = s_r[rec.w & (ORBFE_MAX_LEVELS - 1)];
-    const int maxr = (int)ceilf(ry + r), minr = (int)floorf(ry - r);
-    const bool ok = rec.x >= 0 && !(row < minr || row > maxr) && (rx >= minU && rx <= maxU);
-    if (ok) {
-      uint4 b0, b1;
-      load_desc(dr + (size_t)rec.x * 32, b0, b1);
-      const unsigned key = ((unsigned)hamming256(a0, a1, b0, b1) << 16) | (unsigned)rec.x;
-      if (key < best && (key >> 16) < (unsigned)ORBFE_TH_HIGH) {  // (dist, index) minimum among dist < TH_HIGH
-        best = key;
-        best_x = rx;
+  const float rowm1 = (float)(row - 1), rowp1 = (float)(row + 1);   // exact: |row| < 2^24 where act
+  // SM_ROUNDS x 16 entries of each keypoint per trip: all bucket records (index, x, y, octave) are requested together, then the
+  // descriptors of the survivors of the band / disparity tests (the others read descriptor 0: one cached line), then the
+  // distances -- two memory round trips for the four keypoints of the wave unless one of them has more than 64 entries
+  for (int eb = e0; __ballot(eb < e1) != 0ull; eb += SM_ROUNDS * SM_G) {
+    int4 rec[SM_ROUNDS];
+    bool ok[SM_ROUNDS];
+    float rx[SM_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SM_ROUNDS; r++) {
+      const int e = eb + r * SM_G + sub;
+      ok[r] = e < e1;
+      rec[r] = bent[max(min(e, e1 - 1), 0)];
+    }
+    uint4 b0[SM_ROUNDS], b1[SM_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SM_ROUNDS; r++) {
+      rx[r] = __int_as_float(rec[r].y);
+      const float ry = __int_as_float(rec[r].z);
+      const float rad = s_r[rec[r].w & (ORBFE_MAX_LEVELS - 1)];
+      // minr = floor(ry - rad) <= row <= ceil(ry + rad) = maxr (L/src/Frame.cc:497-501) for the integer row:
+      // ceil(t) >= row <=> t > row - 1, floor(t) <= row <=> t < row + 1, on the same rounded float sums
+      ok[r] = ok[r] && (ry + rad > rowm1) && (ry - rad < rowp1) && (rx[r] >= minU && rx[r] <= maxU);
+      load_desc(dr + (size_t)(ok[r] ? rec[r].x : 0) * 32, b0[r], b1[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < SM_ROUNDS; r++) {
+      if (__ballot(ok[r]) != 0ull) {
+        const unsigned key = ((unsigned)hamming256(a0, a1, b0[r], b1[r]) << 16) | (unsigned)rec[r].x;
+        if (ok[r] && key < best) {   // (distance, index) minimum among distance < TH_HIGH (best starts at TH_HIGH << 16 | 0xffff)
+          best = key;
+          best_x = rx[r];
+        }
       }
     }
   }
-  SM_T(1);   // bucket records + descriptors + Hamming
   // first minimum in index order; the winning lane also holds the right keypoint's x
-  float uR0;
   {
     const unsigned k = ((best >> 16) < (unsigned)ORBFE_TH_HIGH) ? best : 0xFFFFFFFFu;
-    best = wave_min_u32(k);
-    if (best == 0xFFFFFFFFu) { SM_END(); return; }
-    const unsigned long long wm = __ballot(k == best);
-    uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_x), __ffsll((long long)wm) - 1));
+    best = row_min_u32(k);
+    best_x = __int_as_float((int)row_or_u32((k == best && k != 0xFFFFFFFFu) ? (unsigned)__float_as_int(best_x) : 0u));
   }
-  const int bestDist = (int)(best >> 16);
+  const float uR0 = best_x;
   const int thOrbDist = (ORBFE_TH_HIGH + ORBFE_TH_LOW) / 2;
-  if (!(bestDist < thOrbDist)) { SM_END(); return; }
-  SM_T(2);   // reduction
+  act = act && best != 0xFFFFFFFFu && (int)(best >> 16) < thOrbDist;
+  if (__ballot(act) == 0ull) return;
 
   // sub-pixel refinement by 11x11 SAD over 11 shifts (L/src/Frame.cc:557-631)
-  const float sfac = P.inv_scale[levelL];
-  const float scaleduL = roundf(kpL.x * sfac);
-  const float scaledvL = roundf(kpL.y * sfac);
+  const SmLevel lv = s_lv[levelL];
+  const float sfac = lv.inv_scale;
+  const float scaleduL = roundf(uL * sfac);
+  const float scaledvL = roundf(vL * sfac);
   const float scaleduR0 = roundf(uR0 * sfac);
   const int w = 5, L = 5;
   const float iniu = scaleduR0 + L - w;
   const float endu = scaleduR0 + L + w + 1;
-  if (iniu < 0 || endu >= (float)P.pyrR.w[levelL]) return;
-  const int yL0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w), xRc = (int)scaleduR0;
+  act = act && !(iniu < 0 || endu >= (float)lv.wR);
+  const int yW = (int)(scaledvL - w), xW = (int)(scaleduL - w), xRc = (int)scaleduR0;
+  const int xR0 = xRc - L - w;
   // the reference reads these windows unchecked (cv::Mat::rowRange/colRange would throw); treat as no match
-  if (yL0 < 0 || yL0 + 2 * w >= P.pyrL.h[levelL] || xL0 < 0 || xL0 + 2 * w >= P.pyrL.w[levelL] ||
-      xRc - L - w < 0 || xRc + L + w >= P.pyrR.w[levelL] || yL0 + 2 * w >= P.pyrR.h[levelL])
-    return;
-  const uint8_t* imL = P.pyrL.base[levelL] + (size_t)pair * P.pyrL.img_stride[levelL];
-  const uint8_t* imR = P.pyrR.base[levelL] + (size_t)pair * P.pyrR.img_stride[levelL];
-  const int sL = P.pyrL.pitch[levelL], sR = P.pyrR.pitch[levelL];
-  // stage the 11 x 11 left window and the 11 x 21 right window (all 11 shifts) in the wave's LDS slice with aligned
-  // dword loads: 55 + 66 dwords per wave instead of 24 byte loads per lane; the windows' positions are wave-uniform
-  uint8_t* winL = &sad_win[threadIdx.x >> 6][0];
+  act = act && !(yW < 0 || yW + 2 * w >= lv.hL || xW < 0 || xW + 2 * w >= lv.wL || xR0 < 0 || xRc + L + w >= lv.wR ||
+                 yW + 2 * w >= lv.hR);
+  if (__ballot(act) == 0ull) return;
+  // stage the 11 x 11 left window and the 11 x 21 right window (all 11 shifts) of the row's keypoint in its LDS slice: lane r of
+  // the row loads window row r -- 16 bytes of the left level and 24 of the right one from the aligned dword below the window's
+  // first column (dwordx4 / dwordx2 loads need dword alignment only) -- three load instructions for the wave's four keypoints
+  uint8_t* winL = &sad_win[grp][0];
   uint8_t* winR = winL + 11 * SAD_LP;
-  const int xR0 = __builtin_amdgcn_readfirstlane(xRc - L - w);
-  const int yW = __builtin_amdgcn_readfirstlane(yL0), xW = __builtin_amdgcn_readfirstlane(xL0);
   const int axL = xW & ~3, axR = xR0 & ~3;
-  {
-    uint32_t vl = 0, vr0 = 0, vr1 = 0;
-    const int rl = lane / 5, cl = lane - rl * 5;      // 11 rows x 5 dwords
-    const int rr = lane / 6, cr = lane - rr * 6;      // 11 rows x 6 dwords: lanes 0..63 + two more
-    if (lane < 55) vl = *reinterpret_cast<const uint32_t*>(imL + (size_t)(yW + rl) * sL + axL + 4 * cl);
-    vr0 = *reinterpret_cast<const uint32_t*>(imR + (size_t)(yW + rr) * sR + axR + 4 * cr);
-    if (lane < 2) vr1 = *reinterpret_cast<const uint32_t*>(imR + (size_t)(yW + 10) * sR + axR + 4 * (4 + lane));
-    if (lane < 55) reinterpret_cast<uint32_t*>(winL)[rl * (SAD_LP / 4) + cl] = vl;
-    reinterpret_cast<uint32_t*>(winR)[rr * (SAD_RP / 4) + cr] = vr0;
-    if (lane < 2) reinterpret_cast<uint32_t*>(winR)[10 * (SAD_RP / 4) + 4 + lane] = vr1;
+  if (act && sub < 11) {
+    // (a pointer that comes out of LDS is a generic one to the compiler: say that it is global memory, or the loads are flat_load)
+    typedef const __attribute__((address_space(1))) uint8_t* gptr_t;
+    gptr_t pl = (gptr_t)(uintptr_t)lv.baseL + ((yW + sub) * lv.pitchL + axL);
+    gptr_t pr = (gptr_t)(uintptr_t)lv.baseR + ((yW + sub) * lv.pitchR + axR);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x4 vl = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(pl);
+    const u32x4 vr0 = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(pr);
+    const u32x2 vr1 = *reinterpret_cast<const __attribute__((address_space(1))) u32x2*>(pr + 16);
+    *reinterpret_cast<u32x4*>(winL + sub * SAD_LP) = vl;
+    u32x2* wr = reinterpret_cast<u32x2*>(winR + sub * SAD_RP);
+    wr[0] = vr0.xy;
+    wr[1] = vr0.zw;
+    wr[2] = vr1;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  SM_T(3);   // SAD windows: global loads -> LDS
   const uint8_t* WL = winL + (xW - axL);
   const uint8_t* WR = winR + (xR0 - axR);
   // |a - b| with a = IL - cL, b = IR - cR[k]: both biased by +255 so that v_sad_u32 (|x - y| + acc) applies
@@ -1428,48 +1466,47 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   unsigned acc[11];
 #pragma unroll
   for (int k = 0; k < 11; k++) acc[k] = 0;
-  for (int p = lane; p < 121; p += WAVE) {
-    const int yy = p / 11, xx = p - yy * 11;
-    const unsigned a = (unsigned)((int)WL[yy * SAD_LP + xx] - cLm);
-    const uint8_t* rrow = WR + yy * SAD_RP + xx;
 #pragma unroll
-    for (int k = 0; k < 11; k++) acc[k] = sad_u32(a, (unsigned)((int)rrow[k] - cRm[k]), acc[k]);
+  for (int t = 0; t < 8; t++) {
+    const int p = sub + SM_G * t;
+    if (t < 7 || p < 121) {
+      const unsigned a = (unsigned)((int)WL[s_offL[p]] - cLm);
+      const uint8_t* rrow = WR + s_offR[p];
+#pragma unroll
+      for (int k = 0; k < 11; k++) acc[k] = sad_u32(a, (unsigned)((int)rrow[k] - cRm[k]), acc[k]);
+    }
   }
-  // every sum is <= 121 * 510 < 65536: reduce two per register
+  // every sum is <= 121 * 510 < 65536: reduce two per register inside the row; every lane of the row gets the totals
+  unsigned pk[6];
+#pragma unroll
+  for (int j = 0; j < 5; j++) pk[j] = acc[2 * j] | (acc[2 * j + 1] << 16);
+  pk[5] = acc[10];
+#pragma unroll
+  for (int j = 0; j < 6; j++) pk[j] = row_sum_u32(pk[j]);
+  // lane k of the row takes the sum of shift k (k < 11).  The reference's `dist < bestDist` walk over float distances
+  // (L/src/Frame.cc:593-600; the sums are integers < 2^16, exact as floats) is an integer first-minimum: the minimum of
+  // (sum, k) keys over the row.
+  unsigned mine = pk[0];
   {
-    unsigned pk[6];
-#pragma unroll
-    for (int j = 0; j < 5; j++) pk[j] = acc[2 * j] | (acc[2 * j + 1] << 16);
-    pk[5] = acc[10];
-#pragma unroll
-    for (int j = 0; j < 6; j++) pk[j] = (unsigned)wave_sum_i32((int)pk[j]);
-#pragma unroll
-    for (int j = 0; j < 5; j++) { acc[2 * j] = pk[j] & 0xffffu; acc[2 * j + 1] = pk[j] >> 16; }
-    acc[10] = pk[5];
+    const int t = sub >> 1;
+    mine = t == 1 ? pk[1] : mine; mine = t == 2 ? pk[2] : mine; mine = t == 3 ? pk[3] : mine;
+    mine = t == 4 ? pk[4] : mine; mine = t == 5 ? pk[5] : mine;
+    mine = (sub & 1) ? (mine >> 16) : (mine & 0xffffu);
   }
-  // The eleven sums are wave-uniform integers (< 2^16, exact as floats): the reference's `dist < bestDist` walk over float
-  // distances is an integer first-minimum, done here on the scalar unit -- a vector instruction costs the same issue slots with
-  // one active lane as with 64, and this epilogue was a fifth of the kernel's vector instructions.
-  SM_T(4);   // SAD sums + wave reductions
-  SM_END();
-  int sadBest = 2147483647, bk = 0;
-  int sacc[11];
-#pragma unroll
-  for (int k = 0; k < 11; k++) {
-    sacc[k] = __builtin_amdgcn_readfirstlane((int)acc[k]);
-    if (sacc[k] < sadBest) { sadBest = sacc[k]; bk = k; }
-  }
+  const unsigned kmin = row_min_u32(sub < 11 ? ((mine << 4) | (unsigned)sub) : 0xFFFFFFFFu);
+  const int bk = (int)(kmin & 15u);
+  const int sadBest = (int)(kmin >> 4);
   const int bestincR = bk - L;
-  if (bestincR == -L || bestincR == L) return;
-  int i1 = 0, i2 = 0, i3 = 0;
-#pragma unroll
-  for (int k = 1; k < 10; k++)
-    if (k == bk) { i1 = sacc[k - 1]; i2 = sacc[k]; i3 = sacc[k + 1]; }
-  if (lane != 0) return;
+  // the neighbours of the minimum, from the lanes that hold them (for bk = 0 / 10 the lane read is outside 0..10: no match anyway)
+  const int rowbase = lane & ~(SM_G - 1);
+  const int i1 = __builtin_amdgcn_ds_bpermute((rowbase + ((bk + 15) & 15)) << 2, (int)mine);
+  const int i3 = __builtin_amdgcn_ds_bpermute((rowbase + ((bk + 1) & 15)) << 2, (int)mine);
+  const int i2 = sadBest;
+  if (!act || sub != 0 || bestincR == -L || bestincR == L) return;
   const float dist1 = (float)i1, dist2 = (float)i2, dist3 = (float)i3;
   const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
   if (deltaR < -1 || deltaR > 1) return;
-  float bestuR = P.scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+  float bestuR = lv.scale * ((float)scaleduR0 + (float)bestincR + deltaR);
   float disparity = (uL - bestuR);
   if (disparity >= minD && disparity < maxD) {
     if (disparity <= 0) {
@@ -1621,7 +1658,7 @@ void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {
     });
   }
   hipLaunchKernelGGL(stereo_bucket_kernel, dim3(n_pairs), dim3(256), bucket_lds, s, p);
-  dim3 grid((p.cap + 3) / 4, n_pairs);
+  dim3 grid((p.cap + SM_KPB - 1) / SM_KPB, n_pairs);
   hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, p);
   hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, p);
 }

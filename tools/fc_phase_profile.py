@@ -45,20 +45,3 @@ ex.sync()
 L.orbfe_debug_oct_profile(out64,0)
 print("octree: level, cycles per workgroup, loop iterations per workgroup")
 for l in range(8): print(f"  level {l}: {out64[l]/(R*B):9.0f} cycles  {out64[32+l]/(R*B):5.1f} iterations")
-# ---- stereo_match_kernel
-from refactored_orb_slam2_amd.matcher import Matcher
-pairs=synth.sequence(W,H,8,seq=5,stereo=True)
-Lt=torch.from_numpy(np.stack([pairs[i%8][0] for i in range(B)])).cuda(); Rt=torch.from_numpy(np.stack([pairs[i%8][1] for i in range(B)])).cuda()
-exR=ORBextractor(NF,device=0); mt=Matcher(0)
-kr=torch.zeros_like(k); dr=torch.zeros_like(de); nr=torch.zeros_like(n)
-ur=torch.zeros(B,cap,dtype=torch.float32,device='cuda'); dp=torch.zeros_like(ur); ns=torch.zeros_like(n)
-ex.extract_batch_device(Lt,k,de,n); exR.extract_batch_device(Rt,kr,dr,nr); ex.sync(); exR.sync()
-out=(C.c_ulonglong*8)()
-mt.stereo_match(ex,exR,k,de,n,kr,dr,nr,386.1448,386.1448/718.856,ur,dp,ns); torch.cuda.synchronize()
-L.orbfe_debug_sm_profile(out,1)
-for _ in range(R): mt.stereo_match(ex,exR,k,de,n,kr,dr,nr,386.1448,386.1448/718.856,ur,dp,ns)
-torch.cuda.synchronize()
-L.orbfe_debug_sm_profile(out,0)
-v=list(out); waves=v[6]; tot=sum(v[:6])
-print("stereo_match: waves recorded",waves/R,"cycles/wave",tot/max(waves,1))
-for nme,x in zip(["own record+range","bucket+Hamming","min reduction","window loads->LDS","SAD+reductions","-"],v[:6]): print(f"{nme:20s} {x/max(waves,1):9.0f} cycles/wave  {100*x/max(tot,1):5.1f}%")
