@@ -236,15 +236,31 @@ def per_frame_latency(cfg, n_frames: int):
                 _write_png_gray(os.path.join(seq, "image_0", f"{i:06d}.png"), L)
                 _write_png_gray(os.path.join(seq, "image_1", f"{i:06d}.png"), R)
                 f.write(f"{i * 0.1:e}\n")
-        r = subprocess.run([exe, seq, "--features", str(cfg["nfeat"]), "--bf", str(cfg["bf"]), "--fx", str(cfg["fx"]), "--fy", str(cfg["fy"]),
-                            "--cx", str(cfg["cx"]), "--cy", str(cfg["cy"]), "--th", str(cfg["th"])], capture_output=True, text=True, timeout=600)
+        base = [exe, seq, "--features", str(cfg["nfeat"]), "--bf", str(cfg["bf"]), "--fx", str(cfg["fx"]), "--fy", str(cfg["fy"]),
+                "--cx", str(cfg["cx"]), "--cy", str(cfg["cy"]), "--th", str(cfg["th"])]
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(16, usable - 3))   # the tracking thread and the two extractor threads keep a core each
+        r = subprocess.run(base + ["--decode-threads", str(threads), "--prefetch", "32"], capture_output=True, text=True, timeout=600)
+        r0 = subprocess.run(base + ["--decode-threads", "0"], capture_output=True, text=True, timeout=600)   # load, then track
     if r.returncode != 0:
         return {"error": f"stereo_kitti exited with {r.returncode}: " + (r.stderr or r.stdout)[-300:]}
     med = re.search(r"median tracking time: ([0-9.eE+-]+)", r.stdout)
     mean = re.search(r"mean tracking time: ([0-9.eE+-]+)", r.stdout)
+    tail = {k: re.search(k + r" tracking time: ([0-9.eE+-]+)", r.stdout) for k in ("p95", "p99", "max")}
     stats = re.search(r"keypoints/left image: ([0-9.]+), stereo matches/frame: ([0-9.]+), tracked/frame: ([0-9.]+)", r.stdout)
     ph = re.search(r"two threads\) ([0-9.]+), ComputeStereoMatches ([0-9.]+), SearchByProjection\(cur,last\) ([0-9.]+)", r.stdout)
-    return {"median_ms": round(float(med.group(1)) * 1e3, 4), "mean_ms": round(float(mean.group(1)) * 1e3, 4), "frames": n_frames,
+    seq_re = r"sequence: (\d+) frames in ([0-9.]+) s = ([0-9.]+) frames/s end to end \(decode threads (\d+), prefetch (\d+); decode ([0-9.]+) s of CPU time = ([0-9.]+) ms per pair; tracking thread waited ([0-9.]+) s"
+    sq, sq0 = re.search(seq_re, r.stdout), (re.search(seq_re, r0.stdout) if r0.returncode == 0 else None)
+    prep = re.search(r"front end prepared for \d+x\d+ in ([0-9.]+) ms", r.stdout)
+    sequence = None
+    if sq:
+        sequence = {"frames_per_s": float(sq.group(3)), "decode_threads": int(sq.group(4)), "prefetch_pairs": int(sq.group(5)),
+                    "decode_ms_per_pair_cpu": float(sq.group(7)), "tracking_thread_waited_s": float(sq.group(8)),
+                    "frames_per_s_load_then_track": float(sq0.group(3)) if sq0 else None,
+                    "input": "synthetic KITTI-layout sequence written as 8-bit grey PNGs (zlib level 1, filter 0), decoded by orbfe_png_read_gray"}
+    return {"median_ms": round(float(med.group(1)) * 1e3, 4), "mean_ms": round(float(mean.group(1)) * 1e3, 4),
+            **{k + "_ms": (round(float(m.group(1)) * 1e3, 4) if m else None) for k, m in tail.items()},
+            "prepare_ms": float(prep.group(1)) if prep else None, "sequence": sequence, "frames": n_frames,
             "keypoints_per_left_image": float(stats.group(1)), "stereo_matches_per_frame": float(stats.group(2)),
             "tracked_per_frame": float(stats.group(3)),
             "median_ms_by_phase": ({"extract_x2": float(ph.group(1)), "stereo": float(ph.group(2)), "search_by_projection": float(ph.group(3))} if ph else None),
@@ -287,7 +303,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="kitti_stereo")
     ap.add_argument("--cpu-sample", type=int, default=160, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--e2e-steps", type=int, default=12, help="steps of the PCIe-inclusive measurement (0 = skip)")
-    ap.add_argument("--per-frame", type=int, default=24, help="stereo pairs pushed one at a time through the C++ drop-in classes for per_frame_ms (0 = skip)")
+    ap.add_argument("--per-frame", type=int, default=192, help="stereo pairs pushed one at a time through the C++ drop-in classes for per_frame_ms (0 = skip)")
     ap.add_argument("--gather", choices=("all", "root"), default="all",
                     help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),

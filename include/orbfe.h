@@ -32,7 +32,8 @@ enum {
   ORBFE_ERR_CAPACITY = -2,   /* an output buffer or an internal fixed-size table is too small */
   ORBFE_ERR_NO_DEVICE = -3,  /* no usable HIP device / HIP runtime failure at start-up */
   ORBFE_ERR_HIP = -4,        /* a HIP call failed; orbfe_last_error() has the text */
-  ORBFE_ERR_EMPTY = -5       /* empty input image: outputs untouched (L/src/ORBextractor.cc:981-982) */
+  ORBFE_ERR_EMPTY = -5,      /* empty input image: outputs untouched (L/src/ORBextractor.cc:981-982) */
+  ORBFE_ERR_ALLOC = -6       /* a host memory allocation failed */
 };
 
 #define ORBFE_MAX_LEVELS 16
@@ -71,12 +72,20 @@ int orbfe_device_count(int* count);   /* number of visible HIP devices */
  *                       one FAST cell per level the caller wants keypoints from (a level narrower or lower than 2 x 16 + 30
  *                       pixels yields none, where the reference divides by zero, L/src/ORBextractor.cc:753-754)
  *   pyramid             n_levels <= ORBFE_MAX_LEVELS (16); FAST cells <= 66 x 66 pixels
- *   descriptor sets     fewer than 65 536 descriptors per frame / per set (orbfe_hamming_bf_device, orbfe_stereo_match*,
- *                       the projection searches: indices travel as 16-bit fields next to the distance)
+ *   descriptor sets     fewer than 65 536 descriptors per frame / per set (orbfe_hamming_bf_device, orbfe_stereo_match*:
+ *                       indices travel as 16-bit fields next to the distance)
+ *   projection searches at most 9 500 keypoints per frame (orbfe_search_by_projection_*, orbfe_search_local_points*,
+ *                       orbfe_proj_match_batch_device, orbfe_kf_search in its LOOP / RELOC modes: the ordered resolver keeps
+ *                       nine bytes per keypoint in LDS); orbfe_proj_candidates / orbfe_proj_best alone take 65 535
+ *   stereo matching     (image rows / 8, rounded up) x n_levels <= 8 192 row-bucket keys, rows <= 4 095
  *   inv_level_sigma2    orbfe_proj_best / orbfe_kf_search read n_levels floats (the caller states n_levels)
  * Threads: a handle serialises its own calls (internal mutex); different handles may be used from different threads at the same
  * time (Frame.cc:91-94 runs the two extractors on two threads).  The library holds no other mutable global state and reads no
- * environment variables. */
+ * environment variables.  The matcher entry points that take no handle (orbfe_search_*, orbfe_stereo_match, orbfe_kf_search,
+ * ...) work on a handle the library creates per calling thread -- one HIP stream, scratch HBM and pinned staging that grow to
+ * the largest call -- and keeps until the process ends: three for ORB-SLAM2's Tracking / LocalMapping / LoopClosing threads.
+ * A thread that is about to end gives its handle back with orbfe_thread_release(). */
+int orbfe_thread_release(void);   /* destroys the calling thread's implicit matcher handle, if it has one */
 
 /* ------------------------------------------------------------------------------------- ORBextractor */
 /* ORBextractor::ORBextractor (L/src/ORBextractor.cc:407-464).  device < 0 selects the current device. */
@@ -504,12 +513,59 @@ int orbfe_compute_bow(orbfe_vocabulary* v, const uint8_t* desc, int n, int level
                       int32_t* node_id, double* weight, int32_t* bow_ids, double* bow_vals, int* n_bow,
                       orbfe_featvec_node* fv_nodes, int32_t* fv_idx, int* n_fv_nodes);
 
+/* ------------------------------------------------------------------------------- batched-sequence mode: record gather */
+/* Independent frames shard over the GPUs of a node in contiguous chunks of the frame range (the reference
+ * walks a sequence one frame at a time in one process, Source/Examples/Stereo/stereo_kitti.cc:88-106): one host thread or
+ * process per GPU with its own extractor / matcher handles, no collective inside the step.  The only exchange is the gather
+ * of the fixed-size padded records {n[frames]; keypoints[frames][cap]; descriptors[frames][cap][32]} over RCCL (librccl is
+ * loaded on first use; ORBFE_ERR_NO_DEVICE without it):
+ *   ORBFE_GATHER_ALL   ncclAllGather: every rank receives every rank's records, in rank order = frame order
+ *   ORBFE_GATHER_ROOT  grouped ncclSend / ncclRecv: rank 0 alone receives them (the *_all pointers of other ranks may be NULL)
+ * `frames` and `cap` are equal on every rank (orbfe_shard_range gives the chunk sizes; pad the short ones).  DEVICE pointers;
+ * the collective is enqueued on `stream` (NULL: the handle's own stream, orbfe_gather_sync waits for it) and returns at once.
+ * A handle belongs to one device; world = 1 is a valid communicator (the collective degenerates to a copy). */
+typedef struct orbfe_gather orbfe_gather;
+#define ORBFE_GATHER_ID_BYTES 128
+enum { ORBFE_GATHER_ALL = 0, ORBFE_GATHER_ROOT = 1 };
+/* [begin, end) of the frames rank `rank` owns: contiguous chunks whose sizes differ by at most one */
+int orbfe_shard_range(int n_frames, int rank, int world, int* begin, int* end);
+/* one process per GPU: rank 0 makes the id (ncclGetUniqueId) and hands it to the others out of band (MPI, a file, a socket) */
+int orbfe_gather_unique_id(uint8_t id[ORBFE_GATHER_ID_BYTES]);
+int orbfe_gather_create(const uint8_t* id, int rank, int world, int device, orbfe_gather** out);
+/* one process, one host thread per GPU: n_devices handles at once (ncclCommInitAll); devices = NULL: 0 .. n_devices - 1 */
+int orbfe_gather_create_all(int n_devices, const int* devices, orbfe_gather** out);
+int orbfe_gather_destroy(orbfe_gather* g);
+int orbfe_gather_rank(const orbfe_gather* g, int* rank, int* world);
+int orbfe_gather_records(orbfe_gather* g, const int32_t* d_n, const orbfe_keypoint* d_kps, const uint8_t* d_desc, int frames,
+                         int cap, int mode, int32_t* d_n_all, orbfe_keypoint* d_kps_all, uint8_t* d_desc_all, void* stream);
+int orbfe_gather_sync(orbfe_gather* g);
+
+/* ------------------------------------------------------------------------------------------------- warm-up */
+/* The first call for an image size builds the plan and its device tables, allocates the work space and the pinned staging
+ * buffers, loads the code objects; the third one- or two-image call captures the launch graph.  The reference constructs its
+ * extractors once (L/src/Tracking.cc:112-127) and its first Track() already counts (initialisation): do that work when the
+ * size is known instead of inside the first frames.  orbfe_extractor_prepare runs the host-API extraction of `n_images`
+ * synthetic w x h images four times on handle e (n_images = 1 for ORBextractor::operator(), 2 for a stereo pair through
+ * orbfe_extract_batch).  orbfe_frontend_prepare does that for both eyes (right may be NULL: monocular) and, ON THE CALLING
+ * THREAD (the handle-less matcher entry points work on a per-thread handle), one stereo pair through orbfe_stereo_match and
+ * the two SearchByProjection forms with max_queries queries (<= 0: one per keypoint).  Without them everything still happens
+ * on first use.  HOST work only besides the calls themselves; synchronous. */
+int orbfe_extractor_prepare(orbfe_extractor* e, int w, int h, int n_images);
+int orbfe_frontend_prepare(orbfe_extractor* left, orbfe_extractor* right, int w, int h, int max_queries);
+
 /* --------------------------------------------------------------------------------------- sequence driver helpers */
 /* Dependency-free PNG input for the dataset drivers (the reference reads with cv::imread(..., IMREAD_UNCHANGED),
- * Source/Examples/Stereo/stereo_kitti.cc:88-89, and converts colour frames in Tracking::GrabImage*, L/src/Tracking.cc:
- * 164-178): 8-bit greyscale, or 8-bit RGB(A) converted with cvtColor's RGB2GRAY weights; non-interlaced.  zlib only. */
+ * Source/Examples/Stereo/stereo_kitti.cc:88-89, Source/Examples/RGB-D/rgbd_tum.cc, and converts colour frames in
+ * Tracking::GrabImage*, L/src/Tracking.cc:164-178): 8-bit greyscale (+ alpha), or 8-bit RGB(A) converted with cvtColor's
+ * RGB2GRAY weights; 16-bit greyscale (TUM depth maps) through orbfe_png_read_gray16; non-interlaced only; zlib only.
+ * Images larger than 4095 x 4095 are refused (ORBFE_ERR_INVALID) before anything is allocated; no exception leaves these
+ * functions (ORBFE_ERR_ALLOC when the decoder cannot get its memory).  Thread-safe: any number of calls may run at once. */
 int orbfe_png_info(const char* path, int* w, int* h);
+/* ... with the bit depth (8 / 16) and channel count (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA); any output may be NULL */
+int orbfe_png_info2(const char* path, int* w, int* h, int* depth, int* channels);
 int orbfe_png_read_gray(const char* path, uint8_t* dst, int stride, int cap_rows, int* w, int* h);
+/* 16-bit greyscale: h rows of w uint16 samples (host byte order), `stride_elems` ELEMENTS apart */
+int orbfe_png_read_gray16(const char* path, uint16_t* dst, int stride_elems, int cap_rows, int* w, int* h);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,9 @@ class FrameView(C.Structure):
 
 # every symbol include/orbfe.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "orbfe_last_error", "orbfe_device_count", "orbfe_extractor_create", "orbfe_extractor_destroy",
+    "orbfe_last_error", "orbfe_device_count", "orbfe_thread_release", "orbfe_extractor_prepare", "orbfe_frontend_prepare",
+    "orbfe_shard_range", "orbfe_gather_unique_id", "orbfe_gather_create", "orbfe_gather_create_all", "orbfe_gather_destroy",
+    "orbfe_gather_rank", "orbfe_gather_records", "orbfe_gather_sync", "orbfe_extractor_create", "orbfe_extractor_destroy",
     "orbfe_extractor_levels", "orbfe_extractor_scale_factors", "orbfe_extractor_inv_scale_factors",
     "orbfe_extractor_sigma2", "orbfe_extractor_inv_sigma2", "orbfe_extractor_features_per_level",
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_pyramid_level", "orbfe_pyramid_level_size", "orbfe_pyramid_levels",
@@ -98,7 +100,7 @@ EXPORTS = [
     "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_kf_search", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
     "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
-    "orbfe_bow_transform_device", "orbfe_compute_bow", "orbfe_png_info", "orbfe_png_read_gray",
+    "orbfe_bow_transform_device", "orbfe_compute_bow", "orbfe_png_info", "orbfe_png_info2", "orbfe_png_read_gray", "orbfe_png_read_gray16",
 ]
 
 

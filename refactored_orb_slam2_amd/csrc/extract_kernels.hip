@@ -414,20 +414,24 @@ __device__ __forceinline__ int arc9_maxmin_pk(const uint32_t (&P)[8], uint32_t V
 // workgroup-wide kernel every phase boundary is a barrier at which most waves idle.  Here every wave owns a run of <= 4
 // horizontally adjacent cells and walks them one at a time entirely inside its own LDS slice (~5.4 KB: 28 waves per CU): all
 // synchronisation is the in-order execution of one wave's LDS operations and a compute unit holds independent waves in
-// different phases.  72 VGPRs = 7 waves per SIMD, which is also what the LDS slices allow; holding the NEXT cell's tile in
-// registers while the current one is processed (FC_PREFETCH) costs 15 registers = one wave per SIMD and measured slower.
+// different phases.  63 VGPRs; 7 waves per SIMD is what the LDS slices allow; holding the NEXT cell's tile in registers while
+// the current one is processed costs 15 registers = one wave per SIMD and measured slower (DESIGN lessons 13, 18).
 //   stage   cell ROI (<= 66 x 66) as bytes, shifted one column when that makes the tested region start on an even column (the
 //           shift happens in registers: v_alignbyte over one extra aligned dword; LDS stores stay 16-byte aligned)
 //   A1      SWAR quick test, two pixels per lane in 16-bit fields: the 16-bit pairs are cut out of aligned dwords with
 //           v_perm_b32 (selectors per lane: the pair starts at byte 0 or 2), ten dwords per pair in five ds_read2_b32; packed
 //           min / max over the four antipodal pairs, one biased subtract / add per polarity (see below).  Lanes = (row in a
 //           band of RI rows, pixel pair): rows are 64 bytes apart, so the lanes of a 32-lane LDS group hit distinct banks.
-//           Survivors -> 384-entry list with their polarity, scored (A2) and emptied whenever more than 256 are waiting
+//           Two tiers: the antipodal pairs (0, 8), (4, 12) first, the other two only if some lane of the wave passes.
+//           Survivors -> 384-entry list with their polarity, scored (A2) and emptied whenever more than 256 are waiting.
+//           The whole pass runs at iniThFAST first and is repeated at minThFAST (from the tile that is still staged) only for a
+//           cell that kept nothing: the reference's own order (L/src/ORBextractor.cc:773-780)
 //   A2      exact cornerScore of the surviving polarity: ring held as eight packed pairs, one 9-arc max-min network of packed
-//           16-bit min / max for either polarity (arc9_maxmin_pk) -> score plane (tested region + 1-pixel zero frame) and a
-//           bitmap of scored pixels
-//   B + C   each lane takes the bitmap words w = lane, lane + 64: strict 3x3 NMS inside the cell, the two-threshold rule and the
-//           row-major emission run from registers (two packed wave scans give the output offsets)
+//           16-bit min / max for either polarity (arc9_maxmin_pk) -> score plane (tested region + 1-pixel zero frame)
+//   B       strict 3x3 NMS inside the cell with lane = survivor (the list still holds every scored pixel; nine LDS reads in flight
+//           per lane); kept pixels set bits, one 32-bit word per tested row.  Cells whose list was recycled (> 256 survivors)
+//           walk the bitmap instead (lane = word)
+//   C       row-major emission from the bitmap, one packed wave scan for the output offsets
 #define FC_LIST_CAP 384
 #ifndef FC_TIMING
 #define FC_TIMING 0
@@ -1172,8 +1176,8 @@ __device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {
   return (((uint32_t)(y >> 3) * (uint32_t)(pitch >> 4) + (uint32_t)(x >> 4)) << 7) + (uint32_t)((y & 7) * 16 + (x & 15));
 }
 // 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps [18,34,48,56,48,34,18], exact 16.16 accumulation,
-// round half up.  One 64x32 output tile per workgroup, separable through LDS.  Interior tiles stage the
-// (64+8)x(32+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
+// round half up.  One 64 x BT_H (58) output tile per workgroup, separable through LDS.  Interior tiles stage the
+// (64+8) x (58+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
 // REFLECT_101 indexing.  Both passes produce 4 adjacent pixels per work item (dword LDS/global accesses).
 #define BT_W 64
 #define BT_H ORBFE_BLUR_TILE_H   // 58: (58 + 6) / 2 = 32 row pairs x 16 groups = exactly two full 256-thread passes
@@ -1299,6 +1303,179 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     }
     }
   }
+}
+
+// ---- the same blur on the matrix cores.  A 7-tap pass over a row is Out = In x Band, a band (Toeplitz) matrix of the taps; with
+// pixels as i8 (x ^ 0x80 = x - 128) and taps <= 56 (folded REFLECT_101 taps <= 96) v_mfma_i32_16x16x64_i8 computes it exactly.
+// One wave owns a strip of 48 output columns and walks down the level:
+//   horizontal: A = 16 rows x 64 pixels, ONE aligned 16-byte load per lane straight into the operand layout (lane (q, r): row r,
+//     pixels 16q .. 16q + 15 of the segment [48c - 16, 48c + 48)); the columns that have all seven taps inside the segment, on
+//     4-pixel boundaries, are the strip: [48c - 12, 48c + 36).  B = the strip's three band matrices (64 x 16, from
+//     the plan's table, in registers for the whole walk); C = 128.  D: lane (q, c) holds H - 32768 + 128 of rows 4q .. 4q + 3 of
+//     column c -- a signed 16-bit number whose bytes (high, low ^ 0x80) are the i8 digits of H - 32768 = 256 a + b;
+//   vertical: those bytes, packed four rows to a dword, ARE the operand of the second product: a lane's 16 bytes are the rows
+//     16 ww + 4q + i (ww = 0..3 <-> dword, i <-> byte) of a 64-row window -- the K order of a matrix product is free as long as
+//     both operands agree, and the other operand (the vertical band matrix, one pair for every window: rows outside the level are
+//     loaded from their REFLECT_101 source) is written in that order.  With the
+//     data as A and the band matrix as B the result comes out transposed: lane (q, r) holds columns 4q .. 4q + 3 of output row r,
+//     one dword of the 16 x 8-tiled blurred plane.  V = 256 (T a) + (T b) + 256 * 32768, pixel = (V + 32768) >> 16 = byte 2.
+// A window of four 16-row blocks yields the two middle ones; the walk advances by two blocks.  No LDS, no barrier.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
+  const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x05010400u);   // [d0.b0, d1.b0, d0.b1, d1.b1]
+  const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x05010400u);
+  lo = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+  hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+}
+#ifndef BLUR_RING
+#define BLUR_RING 2         // passes of source rows in flight per wave (LDS-DMA ring: 2 KB per pass and wave)
+#endif
+#ifndef BLUR_MIN_BLOCKS
+#define BLUR_MIN_BLOCKS 4   // workgroups per CU the register allocation must leave room for
+#endif
+// One 1 KB piece (16 rows x 64 bytes) global -> LDS without passing registers: lane l's 16 bytes land at lds_dst + 16 l.  M0
+// (the destination) is the compiler's register: saved and restored inside the statement.  The compiler does not count this
+// load: every wait for it is the explicit BLUR_WAIT_ROWS below.
+#define BLUR_DMA(gsrc, lds_dst) do { \
+    unsigned keep_m0; \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_m0) : "v"(gsrc), "s"(lds_dst) : "memory"); \
+  } while (0)
+// vector-memory operations a wave issues AFTER the two pieces of pass p and before it reads them (at the end of pass p - 1):
+// per pass in between two pieces and six stores (every lane stores in every pass): (BLUR_RING - 1) * 6 + (BLUR_RING - 2) * 2
+#if BLUR_RING == 2
+#define BLUR_WAIT_ROWS() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#elif BLUR_RING == 3
+#define BLUR_WAIT_ROWS() asm volatile("s_waitcnt vmcnt(14)" ::: "memory")
+#elif BLUR_RING == 4
+#define BLUR_WAIT_ROWS() asm volatile("s_waitcnt vmcnt(22)" ::: "memory")
+#else
+#error "BLUR_RING must be 2, 3 or 4"
+#endif
+__global__ __launch_bounds__(256, BLUR_MIN_BLOCKS) void gauss_blur7_mfma_kernel(PyrView src, PyrView dst, BlurMfmaParams P) {
+  const int lane = threadIdx.x & 63;
+  const int sid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ v4i ring[4][BLUR_RING][2][64];
+  if (sid >= P.n_strips) return;
+  const BlurStrip st = P.strips[sid];
+  const int lvl = __builtin_amdgcn_readfirstlane((int)st.level), ch = __builtin_amdgcn_readfirstlane((int)st.chunk);
+  const int w = src.w[lvl], h = src.h[lvl], sp = src.pitch[lvl], dp = dst.pitch[lvl];
+  const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
+  uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
+  const int q = lane >> 4, r = lane & 15;
+  const v4i* bt = reinterpret_cast<const v4i*>(P.tab + P.b_off[lvl]) + (size_t)(ch * 3) * 64 + lane;
+  const v4i B0 = bt[0], B1 = bt[64], B2 = bt[128];
+  const v4i* tt = reinterpret_cast<const v4i*>(P.tab + P.t_off) + lane;
+  const v4i T1 = tt[0], T2 = tt[64];
+  // Load role: lane l fetches row l >> 2, 16-byte piece lc of the 64-byte segment -- four lanes read 64 contiguous bytes; a lane
+  // loading its own operand bytes (16 rows per 16 consecutive lanes) costs four times the cache-line requests -- into LDS slot l.
+  // The operand of lane (q, r), row r piece q, is then slot 4r + (q ^ (r >> 2 & 3)): the xor on the SOURCE piece spreads the
+  // sixteen rows one b128 read serves over all banks.  A segment that would start left of the image or end right of the pitch
+  // is moved inside: the band matrices hold zeros for every pixel outside [0, w).
+  const int lrow = lane >> 2, lc = (lane & 3) ^ ((lane >> 4) & 3);
+  const int xo = min(max(ORBFE_BLUR_CHUNK * ch - 16 + 16 * lc, 0), sp - 16);
+  const int rslot = 4 * r + (q ^ ((r >> 2) & 3));
+  const uint8_t* scol = S + xo;
+  v4i* const wring = &ring[threadIdx.x >> 6][0][0][0];
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) v4i*)wring);
+  const v4i c128 = {128, 128, 128, 128}, zero = {0, 0, 0, 0};
+  const v4i cfin = {8388608 + 32768, 8388608 + 32768, 8388608 + 32768, 8388608 + 32768};
+  // The two pieces of pass p: rows [32 p + 16, 32 p + 32) and [32 p + 32, 32 p + 48), into ring stage `stage`.  Rows outside
+  // the level are fetched from their REFLECT_101 source row (one reflection, then clamped: only rows within three of the level
+  // matter, and h >= 8), so the vertical band matrix is the plain Toeplitz one in every window.
+#define BLUR_ROW(y) min(max((y) < 0 ? -(y) : ((y) >= h ? 2 * (h - 1) - (y) : (y)), 0), h - 1)
+#define BLUR_REQUEST(p, stage) do { \
+    const uint8_t* g0 = scol + (size_t)BLUR_ROW(32 * (p) + 16 + lrow) * sp; \
+    const uint8_t* g1 = scol + (size_t)BLUR_ROW(32 * (p) + 32 + lrow) * sp; \
+    BLUR_DMA(g0, lds0 + (uint32_t)(stage) * 2048u); \
+    BLUR_DMA(g1, lds0 + (uint32_t)(stage) * 2048u + 1024u); \
+  } while (0)
+#define BLUR_HBLOCK(a, slot) do { \
+    const v4i ax = (a) ^ (int)0x80808080; \
+    const v4i d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ax, B0, c128, 0, 0, 0); \
+    const v4i d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ax, B1, c128, 0, 0, 0); \
+    const v4i d2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ax, B2, c128, 0, 0, 0); \
+    int ph, pl; \
+    blur_pack(d0, ph, pl); Xh[0].slot = ph; Xl[0].slot = pl; \
+    blur_pack(d1, ph, pl); Xh[1].slot = ph; Xl[1].slot = pl; \
+    blur_pack(d2, ph, pl); Xh[2].slot = ph; Xl[2].slot = pl; \
+  } while (0)
+  v4i Xh[3] = {zero, zero, zero}, Xl[3] = {zero, zero, zero};   // window blocks 0..3 <-> .x .y .z .w, per column group
+  const int n_win = (h + ORBFE_BLUR_WINDOW - 1) / ORBFE_BLUR_WINDOW;
+  // Pass s of the walk: first product for rows [32 s + 16, 32 s + 48) -- blocks 2 and 3 of window s --, second product for the
+  // two middle blocks of the window, then the window moves down by two blocks.  Pass -1 only fills blocks 0 and 1 (rows -16 .. 15).  The rows of pass p are requested BLUR_RING passes ahead into stage
+  // (p + 1) mod BLUR_RING.  Memory operations retire in issue order; inside a pass the order is: products; the next pass's rows
+  // LDS -> operands (behind a counted wait: its pieces are older than exactly BLUR_YOUNGER operations); the request for the
+  // pass whose stage this pass just vacated; this pass's stores.
+  int st_cur = 0;   // stage of pass s
+#pragma unroll
+  for (int p = -1; p < BLUR_RING - 1; p++) BLUR_REQUEST(p, p + 1);
+  const int dtile = dp >> 4;
+  uint32_t xoff[3], rowoff[2];
+  bool okx[3];
+  const uint32_t trash = (uint32_t)dst.img_stride[lvl] - 256u + 4u * (uint32_t)lane;   // extractor.cpp: every plane ends in 256 spare bytes
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const int x = ORBFE_BLUR_CHUNK * ch - 12 + 16 * g + 4 * q;   // a multiple of 4: the dword lies in one tile row
+    okx[g] = x >= 0 && x < w;
+    xoff[g] = ((uint32_t)(x >> 4) << 7) + (uint32_t)(x & 15);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; b++) {   // output row of pass -1: 16 b + r - 32 (never stored); the offset is taken modulo 2^32
+    const int o = 16 * b + r;
+    rowoff[b] = (((uint32_t)(o >> 3) * (uint32_t)dtile) << 7) + (uint32_t)((o & 7) * 16) - ((uint32_t)dtile << 9);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first pieces (and this wave's tables) have landed
+  v4i A2 = wring[rslot], A3 = wring[64 + rslot];
+  for (int s = -1; s < n_win; s++) {
+    BLUR_HBLOCK(A2, z);
+    BLUR_HBLOCK(A3, w);
+    uint32_t out[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+    if (s >= 0) {
+#pragma unroll
+      for (int g = 0; g < 3; g++) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const v4i T = b ? T2 : T1;
+          const v4i vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(Xh[g], T, zero, 0, 0, 0);
+          const v4i vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(Xl[g], T, cfin, 0, 0, 0);
+          const uint32_t r0 = ((uint32_t)vh.x << 8) + (uint32_t)vl.x, r1 = ((uint32_t)vh.y << 8) + (uint32_t)vl.y;
+          const uint32_t r2 = ((uint32_t)vh.z << 8) + (uint32_t)vl.z, r3 = ((uint32_t)vh.w << 8) + (uint32_t)vl.w;
+          out[g][b] = __builtin_amdgcn_perm(r1, r0, 0x0c0c0602u) | __builtin_amdgcn_perm(r3, r2, 0x06020c0cu);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      Xh[g].x = Xh[g].z; Xh[g].y = Xh[g].w;
+      Xl[g].x = Xl[g].z; Xl[g].y = Xl[g].w;
+    }
+    // rows of pass s + 1: LDS -> operands
+    const int st_next = st_cur + 1 == BLUR_RING ? 0 : st_cur + 1;
+    BLUR_WAIT_ROWS();
+    A2 = wring[st_next * 128 + rslot];
+    A3 = wring[st_next * 128 + 64 + rslot];
+    BLUR_REQUEST(s + BLUR_RING, st_cur);   // the stage of pass s was read a pass ago
+    st_cur = st_next;
+    // this pass's stores: the tiled offset of (x, o) splits into a column part (fixed for the strip) and a row part that
+    // advances by four tile rows per pass.  Every lane stores in every pass -- a store under a condition is a branch to the
+    // compiler, and BLUR_WAIT_ROWS counts on six stores per pass: a dword outside the level goes to the lane's own slot
+    // in the 256 spare bytes behind the plane
+    {
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const bool oky = s >= 0 && ORBFE_BLUR_WINDOW * s + 16 * b + r < h;
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+          *reinterpret_cast<uint32_t*>(D + ((oky && okx[g]) ? rowoff[b] + xoff[g] : trash)) = out[g][b];
+        rowoff[b] += (uint32_t)dtile << 9;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pieces requested past the last pass must not land in LDS after the wave has gone
+#undef BLUR_REQUEST
+#undef BLUR_ROW
+#undef BLUR_HBLOCK
 }
 
 // ------------------------------------------------------------------------------------------------ describe
@@ -1674,8 +1851,20 @@ void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hip
   hipLaunchKernelGGL(octree_select_kernel, grid, block, lds_bytes, s, p);
 }
 
-void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
-                       hipStream_t s) {
+// Which blur runs: measured on 256 KITTI images (profiles/r04_blur_mfma.md, DESIGN lesson 31) the matrix-core kernel does the
+// arithmetic of the LDS kernel in a third of the vector instructions and is bit-exact, but the stage moves 0.74 GB per launch
+// and both kernels take 0.29-0.32 ms for it; the LDS kernel is a few per cent ahead and stays the default.
+#ifndef ORBFE_BLUR_MFMA
+#define ORBFE_BLUR_MFMA 0
+#endif
+void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const BlurMfmaParams& mf,
+                       int n_images, hipStream_t s) {
+#if ORBFE_BLUR_MFMA
+  if (mf.n_strips > 0) {
+    hipLaunchKernelGGL(gauss_blur7_mfma_kernel, dim3((mf.n_strips + 3) / 4, n_images), dim3(256), 0, s, src, dst, mf);
+    return;
+  }
+#endif
   dim3 block(256), grid(n_tiles, n_images);
   hipLaunchKernelGGL(gauss_blur7_kernel, grid, block, 0, s, src, dst, tiles, n_tiles);
 }

@@ -83,7 +83,7 @@ struct orbfe_extractor {
   struct LaunchGraph {
     hipGraphExec_t exec = nullptr;
     int w = 0, h = 0, cap = 0, warm = 0;
-    unsigned long long epoch = 0;
+    unsigned long long buffers = 0;   // buffer_signature() at capture time
   } graphs[2];
   // level 0 of the last device batch when the caller's images could be used in place (16-byte aligned rows): no pitched copy
   const uint8_t* ext0 = nullptr;
@@ -94,6 +94,10 @@ struct orbfe_extractor {
   std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
   int fc_rows = 0, fc_span = 0, fc_sc = 0, fc_bits = 0;   // wave-per-cell FAST: largest cell ROI rows, (x0 & 15) + 1 + cols, score plane bytes
   std::vector<BlurTile> tiles;
+  std::vector<BlurStrip> strips;       // gauss_blur7_mfma: one wave per (level, 48-column chunk)
+  std::vector<uint8_t> blur_tab;       // its band matrices as MFMA operands (1 KB each)
+  uint32_t blur_b_off[ORBFE_MAX_LEVELS]{}, blur_t_off = 0;
+  bool blur_mfma = false;              // every coefficient fits int8, no level under eight pixels wide or high
   OctLevel oct[ORBFE_MAX_LEVELS]{};
   int total_cells = 0;
   size_t slots_per_image = 0, gkeys_per_image = 0;
@@ -101,6 +105,7 @@ struct orbfe_extractor {
   int max_nodes = 0, lds_keys = 0;
   size_t oct_lds = 0;
   // device tables
+  DevBuf d_strips, d_blur_tab;
   DevBuf d_cells, d_groups, d_groups1, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];   // d_groups1: one cell per run (small batches)
   int resize_mode[ORBFE_MAX_LEVELS]{};  // 0: direct gathers; 1: every 256x16 destination tile's source window fits the LDS stage;
                                          // 2: and every aligned group of four destination pixels reads at most 8 adjacent source bytes
@@ -124,11 +129,8 @@ struct orbfe_extractor {
   std::mutex mu;
 };
 
-// bumped whenever any buffer of any handle is (re)allocated: captured launch graphs hold raw pointers and are re-captured then
-static std::atomic<unsigned long long> g_alloc_epoch{1};
 static int dev_alloc(DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes && b.p) return ORBFE_OK;
-  g_alloc_epoch.fetch_add(1);
   if (b.p) HIPCHK(hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
@@ -139,7 +141,6 @@ static int dev_alloc(DevBuf& b, size_t bytes) {
 }
 static int pinned_alloc(void*& p, size_t& have, size_t bytes) {
   if (p && bytes <= have) return ORBFE_OK;
-  g_alloc_epoch.fetch_add(1);
   if (p) HIPCHK(hipHostFree(p));
   p = nullptr;
   have = 0;
@@ -191,7 +192,67 @@ static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
   return ORBFE_OK;
 }
 
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+static int reflect101_host(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+  return p;
+}
+// Coefficient of input sample `in` in output sample `out` of the 7-tap pass over a line of `len` samples: the taps whose
+// REFLECT_101 source is `in` added up (L/src/ORBextractor.cc:1019, SURVEY P3: [18,34,48,56,48,34,18], folded taps <= 96 < 128)
+static int blur_coef(int in, int out, int len) {
+  static const int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+  if (out < 0 || out >= len || in < 0 || in >= len) return 0;
+  int c = 0;
+  for (int t = -3; t <= 3; t++)
+    if (reflect101_host(out + t, len) == in) c += taps[t + 3];
+  return c;   // two taps fold onto one sample at an edge (<= 96); on lines of two or three samples more do, and the sum leaves int8
+}
+// Band matrices of gauss_blur7_mfma_kernel (extract_kernels.hip) as v_mfma_i32_16x16x64_i8 operands: lane (q = lane >> 4,
+// n = lane & 15) holds 16 bytes.  Horizontal, strip chunk c, column group g: byte j <-> input column 48c - 16 + 16q + j, output
+// column 48c - 12 + 16g + n (strip c = output columns [48c - 12, 48c + 36): every tap inside the 64-byte segment); the level's
+// left and right REFLECT_101 borders are folded into the first and last chunks' matrices.  Vertical, row group b of a window:
+// byte j = 4ww + i <-> window row 16ww + 4q + i (the order the kernel's packed first-pass results come in), output window row
+// 16 + 16b + n; plain Toeplitz -- the kernel fetches rows outside the level from their reflection.
+// Returns false when a coefficient does not fit int8 or the kernel's single row reflection would not do (a level fewer than
+// eight pixels wide or high): the plan then keeps the LDS kernel (gauss_blur7_kernel) for its blur.
+static bool build_blur_tables(orbfe_extractor* e) {
+  static const int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+  e->strips.clear();
+  e->blur_tab.clear();
+  bool fits = true;
+  auto put = [&fits](int8_t& dst, int c) { fits = fits && c <= 127; dst = (int8_t)c; };
+  e->blur_t_off = 0;
+  e->blur_tab.resize(2 * 1024);
+  {
+    int8_t* tt = reinterpret_cast<int8_t*>(e->blur_tab.data());
+    for (int b = 0; b < 2; b++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 16; j++) {
+          const int d = (16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)) - (16 + 16 * b + (lane & 15));
+          tt[((size_t)b * 64 + lane) * 16 + j] = (int8_t)(d >= -3 && d <= 3 ? taps[d + 3] : 0);
+        }
+  }
+  for (int l = 0; l < e->prm.n_levels; l++) {
+    const LevelGeom& g = e->lg[l];
+    fits = fits && g.w >= 8 && g.h >= 8;
+    const int nch = (g.w + 12 + ORBFE_BLUR_CHUNK - 1) / ORBFE_BLUR_CHUNK;
+    for (int c = 0; c < nch; c++) e->strips.push_back(BlurStrip{(int16_t)l, (int16_t)c});
+    e->blur_b_off[l] = (uint32_t)e->blur_tab.size();
+    e->blur_tab.resize(e->blur_tab.size() + (size_t)nch * 3 * 1024);
+    int8_t* bt = reinterpret_cast<int8_t*>(e->blur_tab.data() + e->blur_b_off[l]);
+    for (int c = 0; c < nch; c++)
+      for (int gg = 0; gg < 3; gg++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int j = 0; j < 16; j++)
+            put(bt[(((size_t)c * 3 + gg) * 64 + lane) * 16 + j],
+                blur_coef(ORBFE_BLUR_CHUNK * c - 16 + 16 * (lane >> 4) + j, ORBFE_BLUR_CHUNK * c - 12 + 16 * gg + (lane & 15), g.w));
+  }
+  return fits;
+}
+
 // Builds everything that depends on the image size.
+
 static int build_plan(orbfe_extractor* e, int w, int h) {
   if (e->plan_w == w && e->plan_h == h) return ORBFE_OK;
   if (w < 1 || h < 1 || w > 4095 || h > 4095) {
@@ -210,7 +271,9 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
       return ORBFE_ERR_INVALID;
     }
     g.pitch = (g.w + 63) & ~63;
-    g.plane = ((size_t)g.pitch * ((g.h + 7) & ~7) + 255) & ~(size_t)255;   // rows padded to 8: the blurred planes are stored in 16 x 8 tiles
+    // rows padded to 8: the blurred planes are stored in 16 x 8 tiles; 256 spare bytes behind them: where gauss_blur7_mfma's
+    // lanes outside the level put their dword (extract_kernels.hip)
+    g.plane = ((size_t)g.pitch * ((g.h + 7) & ~7) + 256 + 255) & ~(size_t)255;
     g.off = off;  // per-image offsets; the buffer is level-major: level block = plane * cap_images
     off += g.plane;
   }
@@ -312,6 +375,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     for (int ty = 0; ty < (g.h + ORBFE_BLUR_TILE_H - 1) / ORBFE_BLUR_TILE_H; ty++)
       for (int tx = 0; tx < (g.w + 63) / 64; tx++) e->tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
   }
+  e->blur_mfma = build_blur_tables(e);
   e->total_cells = (int)e->cells.size();
   e->slots_per_image = slot_off;
   e->gkeys_per_image = key_off;
@@ -358,6 +422,8 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     HIPCHK(hipStreamSynchronize(e->stream));   // g1 goes out of scope
   }
   if ((rc = upload(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(BlurTile), e->stream))) return rc;
+  if ((rc = upload(e->d_strips, e->strips.data(), e->strips.size() * sizeof(BlurStrip), e->stream))) return rc;
+  if ((rc = upload(e->d_blur_tab, e->blur_tab.data(), e->blur_tab.size(), e->stream))) return rc;
   for (int l = 1; l < nl; l++) {
     std::vector<ResizeTap> xt, yt;
     build_taps(e->lg[l - 1].w, e->lg[l].w, true, xt);
@@ -493,7 +559,22 @@ static void drain_events(orbfe_extractor* e) {
   e->ev_pending.clear();
 }
 
-// Enqueues the whole extractor pipeline for n_images whose level-0 planes are already in d_pyr.
+// A captured launch graph holds raw pointers into this handle's buffers (and into nobody else's): it stays valid exactly as long
+// as none of them has been reallocated.  FNV-1a over the pointers; a process-wide allocation counter made two handles that warm
+// up side by side (left and right extractor) throw each other's graphs away.
+static unsigned long long buffer_signature(const orbfe_extractor* e) {
+  const void* ptrs[] = {e->d_strips.p, e->d_blur_tab.p, e->d_cells.p, e->d_groups.p, e->d_groups1.p, e->d_tiles.p, e->d_pyr.p, e->d_blur.p,
+                        e->d_cell_cnt.p, e->d_cell_off.p, e->d_slots.p, e->d_gkeys.p, e->d_lvl_kp.p, e->d_lvl_n.p, e->d_err.p,
+                        e->d_out_kps.p, e->d_out_desc.p, e->d_out_n.p, e->d_in_stage.p, e->h_in, e->h_out};
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](unsigned long long v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+  for (const void* q : ptrs) mix((unsigned long long)(uintptr_t)q);
+  for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { mix((unsigned long long)(uintptr_t)e->d_xt[l].p); mix((unsigned long long)(uintptr_t)e->d_yt[l].p); }
+  return h | 1ull;
+}
+
+// Enqueues the whole extractor pipeline for n_images whose level-0 planes are already in d_pyr.  No host-side state changes in
+// here: a captured graph replays the launches without running this function.
 static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_kps, uint8_t* d_desc, int cap,
                             int32_t* d_n_out, hipStream_t s) {
   const int nl = e->prm.n_levels;
@@ -539,7 +620,13 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_BLUR);
-    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), n_images, s);
+    BlurMfmaParams mf;
+    mf.strips = (const BlurStrip*)e->d_strips.p;
+    mf.n_strips = e->blur_mfma ? (int)e->strips.size() : 0;   // 0: the LDS kernel
+    mf.tab = (const uint8_t*)e->d_blur_tab.p;
+    memcpy(mf.b_off, e->blur_b_off, sizeof(mf.b_off));
+    mf.t_off = e->blur_t_off;
+    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), mf, n_images, s);
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_DESCRIBE);
@@ -568,7 +655,6 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     orbfe_set_error("kernel launch failed: %s", hipGetErrorString(le));
     return ORBFE_ERR_HIP;
   }
-  e->last_images = n_images;
   return ORBFE_OK;
 }
 
@@ -645,7 +731,7 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (auto& g : e->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  DevBuf* bufs[] = {&e->d_cells, &e->d_groups, &e->d_groups1, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
+  DevBuf* bufs[] = {&e->d_strips, &e->d_blur_tab, &e->d_cells, &e->d_groups, &e->d_groups1, &e->d_tiles, &e->d_pyr, &e->d_blur, &e->d_cell_cnt, &e->d_cell_off, &e->d_slots,
                     &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
   for (auto b : bufs) dev_free(*b);
   dev_free(e->d_in_stage);
@@ -754,7 +840,9 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
                          n_images, s);
     }
   }
-  return enqueue_pipeline(e, n_images, d_kps, d_desc, cap, d_n_out, s);
+  if ((rc = enqueue_pipeline(e, n_images, d_kps, d_desc, cap, d_n_out, s))) return rc;
+  e->last_images = n_images;
+  return ORBFE_OK;
 }
 
 extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* imgs, int n_images, int w, int h,
@@ -815,11 +903,11 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     // captured once per (geometry, capacity) into a hipGraph and replayed: one submission instead of thirteen dependent ones.
     // The first calls launch directly (module loading and attribute calls stay outside the capture); any allocation re-captures.
     orbfe_extractor::LaunchGraph& g = e->graphs[n_images - 1];
-    const unsigned long long epoch = g_alloc_epoch.load();
-    const bool same = g.w == w && g.h == h && g.cap == cap && g.epoch == epoch;
+    const unsigned long long sig = buffer_signature(e);
+    const bool same = g.w == w && g.h == h && g.cap == cap && g.buffers == sig;
     if (!same) {
       if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-      g.w = w; g.h = h; g.cap = cap; g.epoch = epoch; g.warm = 0;
+      g.w = w; g.h = h; g.cap = cap; g.buffers = sig; g.warm = 0;
     }
     bool launched = false;
     if (!e->profile && g.warm >= 2) {
@@ -859,6 +947,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     HIPCHK(hipMemcpyAsync(ho + hdr_bytes, e->d_out_kps.p, kp_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(ho + hdr_bytes + kp_bytes, e->d_out_desc.p, desc_bytes, hipMemcpyDeviceToHost, s));
   }
+  e->last_images = n_images;   // host state of the pipeline: set here, not inside the (replayable) launches
   HIPCHK(hipStreamSynchronize(s));
   if (e->profile) drain_events(e);
   const int32_t* hn = (const int32_t*)ho;

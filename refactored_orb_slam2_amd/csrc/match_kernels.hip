@@ -11,6 +11,7 @@
 //
 // Compiled with -ffp-contract=off: every float expression is evaluated un-fused, as the reference does.
 #include <string.h>
+#include <atomic>
 #include <mutex>
 
 #include "match_internal.h"
@@ -1582,6 +1583,17 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(StereoParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// hipFuncSetAttribute applies to the device that is current when it is called: a process with matchers on several devices
+// (orbfe_matcher_create takes a device) must raise a kernel's dynamic-LDS limit once on EACH of them.  One bit per device
+// ordinal; two threads racing on the same device both set the same value.
+static void raise_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
 void orbfe_launch_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* out, hipStream_t s) {
   if (nA < 1 || nB < 1) return;
   dim3 grid((nB + 255) / 256, (nA + 63) / 64);
@@ -1597,11 +1609,8 @@ void orbfe_launch_grid_build(const FrameBatch& f, int n_frames, hipStream_t s) {
     hipLaunchKernelGGL(grid_build_global_kernel, dim3(n_frames), dim3(GB_THREADS), 0, s, f);
     return;
   }
-  static std::once_flag raised;
-  std::call_once(raised, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              6 * GB_LDS_CAP + 16);
-  });
+  static std::atomic<unsigned long long> raised{0};
+  raise_dynamic_lds(reinterpret_cast<const void*>(grid_build_kernel), 6 * GB_LDS_CAP + 16, raised);
   hipLaunchKernelGGL(grid_build_kernel, dim3(n_frames), dim3(GB_THREADS), (size_t)6 * (size_t)f.cap + 16, s, f);
 }
 void orbfe_launch_proj_candidates(const FrameBatch& f, const QueryBatch& q, orbfe_cand* cand, int32_t* n_cand,
@@ -1616,12 +1625,9 @@ void orbfe_launch_proj_resolve(const FrameBatch& f, const QueryBatch& q, const o
                                int32_t* assigned, int32_t* n_matches, int32_t* push_idx, uint8_t* push_bin, int n_frames,
                                hipStream_t s) {
   const size_t dyn = (size_t)(((f.cap + 15) & ~15) + 8 * (size_t)f.cap);
-  // this kernel's static LDS alone is ~69 KiB: the limit is raised once per process, whichever thread launches first
-  static std::once_flag raised;
-  std::call_once(raised, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              88 * 1024);
-  });
+  // this kernel's static LDS alone is ~69 KiB: the limit is raised once per device, whichever thread launches first
+  static std::atomic<unsigned long long> raised{0};
+  raise_dynamic_lds(reinterpret_cast<const void*>(proj_resolve_kernel), 88 * 1024, raised);
   hipLaunchKernelGGL(proj_resolve_kernel, dim3(n_frames), dim3(RC_THREADS), dyn, s, f, q, cand, n_cand, max_cand, mode, th_high,
                      nnratio, check_ori, blocked, assigned, n_matches, push_idx, push_bin);
 }
@@ -1651,11 +1657,8 @@ void orbfe_launch_init_resolve(const FrameBatch& f, const QueryBatch& q, const o
 void orbfe_launch_stereo(const StereoParams& p, int n_pairs, hipStream_t s) {
   const size_t bucket_lds = sizeof(int) * (size_t)(2 * p.n_keys + 1);
   if (bucket_lds > 48 * 1024) {   // tall images with many levels only (KITTI: 3 KB)
-    static std::once_flag raised;
-    std::call_once(raised, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(int) * (2 * STEREO_MAX_KEYS + 1)));
-    });
+    static std::atomic<unsigned long long> raised{0};
+    raise_dynamic_lds(reinterpret_cast<const void*>(stereo_bucket_kernel), (int)(sizeof(int) * (2 * STEREO_MAX_KEYS + 1)), raised);
   }
   hipLaunchKernelGGL(stereo_bucket_kernel, dim3(n_pairs), dim3(256), bucket_lds, s, p);
   dim3 grid((p.cap + SM_KPB - 1) / SM_KPB, n_pairs);

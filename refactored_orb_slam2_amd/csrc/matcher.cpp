@@ -237,20 +237,29 @@ extern "C" int orbfe_proj_match_batch_device(orbfe_matcher* m, int n_frames, con
                       nnratio, check_orientation, d_blocked, d_assigned, d_n_matches, true, s);
 }
 
-// thread-local handle behind the handle-less host entry points
-// (not destroyed at thread exit: the HIP runtime may already be gone when thread_local destructors of the
-// main thread run; the leak is bounded by the number of threads that ever called the matcher)
+// Thread-local handle behind the handle-less host entry points (one HIP stream + scratch HBM + pinned staging per calling
+// thread).  Not destroyed at thread exit: the HIP runtime may already be gone when thread_local destructors of the main thread
+// run.  ORB-SLAM2's three long-lived threads (Tracking, LocalMapping, LoopClosing) hold three of them for the life of the
+// process; a caller with transient threads gives the handle back with orbfe_thread_release() before the thread ends.
 struct TlsMatcher {
   orbfe_matcher* m = nullptr;
 };
+static thread_local TlsMatcher t_tls_matcher;
 static int tls_matcher(orbfe_matcher** out) {
-  static thread_local TlsMatcher t;
+  TlsMatcher& t = t_tls_matcher;
   if (!t.m) {
     int rc = orbfe_matcher_create(-1, &t.m);
     if (rc) return rc;
   }
   *out = t.m;
   return ORBFE_OK;
+}
+extern "C" int orbfe_thread_release(void) {
+  TlsMatcher& t = t_tls_matcher;
+  if (!t.m) return ORBFE_OK;
+  orbfe_matcher* m = t.m;
+  t.m = nullptr;
+  return orbfe_matcher_destroy(m);
 }
 
 // uploads one host frame + queries; returns device pointers inside the handle's staging buffers

@@ -100,6 +100,22 @@ struct BlurTile {
   int16_t pad;
 };
 
+// gauss_blur7_mfma_kernel: one wave blurs a strip of 48 output columns over the whole height of a level.  The 7-tap passes are
+// band-matrix products on the matrix cores; the band matrices (REFLECT_101 folded into the edge ones) are precomputed per level
+// as MFMA operands, 1 KB each (64 lanes x 16 bytes).
+#define ORBFE_BLUR_CHUNK 48      // output columns per strip: three 16-column MFMA tiles from one 64-byte row segment
+#define ORBFE_BLUR_WINDOW 32     // output rows per step: two 16-row MFMA tiles from a 64-row window
+struct BlurStrip {
+  int16_t level, chunk;
+};
+struct BlurMfmaParams {
+  const BlurStrip* strips;
+  int n_strips;
+  const uint8_t* tab;
+  uint32_t b_off[ORBFE_MAX_LEVELS];   // horizontal matrices of a level: entry (chunk * 3 + column group)
+  uint32_t t_off;                     // the two vertical matrices (row groups 0, 1 of a window)
+};
+
 // launchers (extract_kernels.hip)
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, int mode, hipStream_t s);   // mode: 0 direct gathers, 1 LDS-staged, 2 LDS-staged + 8-byte windows
@@ -107,7 +123,7 @@ void orbfe_launch_fast_cells(const PyrView& pyr, const CellDesc* cells, const Fa
                              int cell_rows, int cell_span, int sc_max, int bits_max, int32_t* cell_cnt, uint32_t* slots,
                              unsigned long long slots_per_image, int ini_th, int min_th, int n_images, hipStream_t s);
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
-void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, int n_images,
-                       hipStream_t s);
+void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const BlurMfmaParams& mf,
+                       int n_images, hipStream_t s);
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s);
 size_t orbfe_octree_lds_bytes(int max_nodes, int lds_keys);

@@ -123,7 +123,10 @@ def test_batch_equals_single_and_is_idempotent():
 def test_aligned_device_images_are_level0_in_place():
     """Device images whose rows start on 16-byte boundaries (pitch 1280 for a 1241-pixel row) are used as pyramid level 0 without
     the pitched copy: results, the level-0 plane seen through orbfe_device_pyramid / debug_pyramid, and a stereo match on the
-    in-place pyramids must equal the copied path (tightly packed rows) and the oracle."""
+    in-place pyramids must equal the copied path (tightly packed rows) and the oracle.  The caller's pad columns hold random
+    bytes (the copy path replicates the last pixel there, the in-place kernels see whatever the caller left: no result may
+    depend on them), and the tightest legal layout -- pitch = ceil16(w) = 1248, the buffer ending with the last row of the last
+    image -- is run as well."""
     import torch
     from refactored_orb_slam2_amd._lib import KP_DTYPE
     from refactored_orb_slam2_amd.matcher import Matcher
@@ -131,13 +134,15 @@ def test_aligned_device_images_are_level0_in_place():
     pairs = synth.sequence(w, h, B, seq=31, stereo=True)
     cap = None
     outs = {}
-    for name, pitch in (("packed", w), ("in_place", 1280)):
+    pad_rng = np.random.default_rng(77)
+    for name, pitch in (("packed", w), ("in_place", 1280), ("tight", 1248)):
         exL, exR, mt = ORBextractor(nf), ORBextractor(nf), Matcher(0)
         cap = exL.max_keypoints(w, h)
         bufs = []
         for side in (0, 1):
-            full = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
-            full[:, :, :w] = torch.from_numpy(np.stack([p[side] for p in pairs])).cuda()
+            host = pad_rng.integers(0, 256, (B, h, pitch), dtype=np.uint8)
+            host[:, :, :w] = np.stack([p[side] for p in pairs])
+            full = torch.from_numpy(host).cuda()
             bufs.append(full)
         z = lambda *s, dt=torch.uint8: torch.zeros(s, dtype=dt, device="cuda")
         kl, dl, nl, kr, dr, nr = z(B, cap, 28), z(B, cap, 32), z(B, dt=torch.int32), z(B, cap, 28), z(B, cap, 32), z(B, dt=torch.int32)
@@ -154,8 +159,9 @@ def test_aligned_device_images_are_level0_in_place():
         outs[name] = [t.cpu().numpy() for t in (kl, dl, nl, ur, dp, ns)]
         for hnd in (exL, exR, mt):
             hnd.close()
-    for a, b in zip(outs["packed"], outs["in_place"]):
-        np.testing.assert_array_equal(a, b)
+    for other in ("in_place", "tight"):
+        for a, b in zip(outs["packed"], outs[other]):
+            np.testing.assert_array_equal(a, b)
     orc = ol.OracleExtractor(nf)
     ok, od = orc(pairs[0][0])
     n0 = int(outs["in_place"][2][0])

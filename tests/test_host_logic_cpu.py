@@ -190,3 +190,47 @@ def test_png_reader_decodes_all_filters_and_rgb(tmp_path):
     assert L.orbfe_png_info(str(tmp_path / "junk.png").encode(), C.byref(w), C.byref(h)) != 0
     small = np.empty((10, 10), np.uint8)
     assert L.orbfe_png_read_gray(str(tmp_path / "pil.png").encode(), small.ctypes.data_as(C.c_void_p), 10, 10, C.byref(w), C.byref(h)) == _lib.ERR_CAPACITY if hasattr(_lib, "ERR_CAPACITY") else True
+
+
+def test_png_reader_16bit_depth_maps_and_hostile_headers(tmp_path):
+    """16-bit greyscale PNGs (TUM RGB-D depth maps, Source/Examples/RGB-D/rgbd_tum.cc reads them with IMREAD_UNCHANGED) decode
+    to uint16 in host byte order; an IHDR that announces a huge image is refused with a code before anything is allocated
+    (no exception crosses the C ABI), and the 8-bit entry point names the 16-bit one instead of mis-decoding."""
+    import ctypes as C
+    import struct
+    import zlib
+    from PIL import Image
+    from refactored_orb_slam2_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    depth = rng.integers(0, 65536, (61, 83)).astype(np.uint16)
+    depth[10:30, 5:60] = np.arange(55, dtype=np.uint16) * 700          # ramps: sub / paeth filters on 2-byte pixels
+    Image.fromarray(depth).save(tmp_path / "d16.png")
+    w, h, dp, ch = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    assert L.orbfe_png_info2(str(tmp_path / "d16.png").encode(), C.byref(w), C.byref(h), C.byref(dp), C.byref(ch)) == 0
+    assert (w.value, h.value, dp.value, ch.value) == (83, 61, 16, 1)
+    out = np.zeros((61, 96), np.uint16)
+    assert L.orbfe_png_read_gray16(str(tmp_path / "d16.png").encode(), out.ctypes.data_as(C.c_void_p), 96, 61, C.byref(w), C.byref(h)) == 0
+    np.testing.assert_array_equal(out[:, :83], depth)
+    buf8 = np.zeros((61, 96), np.uint8)
+    assert L.orbfe_png_read_gray(str(tmp_path / "d16.png").encode(), buf8.ctypes.data_as(C.c_void_p), 96, 61, C.byref(w), C.byref(h)) == -1
+    assert b"orbfe_png_read_gray16" in L.orbfe_last_error()
+    # a grey + alpha file takes the grey channel
+    ga = np.stack([rng.integers(0, 256, (20, 30)).astype(np.uint8), np.full((20, 30), 255, np.uint8)], axis=-1)
+    Image.fromarray(ga, mode="LA").save(tmp_path / "ga.png")
+    o8 = np.zeros((20, 30), np.uint8)
+    assert L.orbfe_png_read_gray(str(tmp_path / "ga.png").encode(), o8.ctypes.data_as(C.c_void_p), 30, 20, C.byref(w), C.byref(h)) == 0
+    np.testing.assert_array_equal(o8, ga[..., 0])
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    for (ww, hh) in ((0x7fffffff, 0x7fffffff), (4096, 10), (10, 70000), (0, 5)):
+        ihdr = struct.pack(">IIBBBBB", ww, hh, 8, 0, 0, 0, 0)
+        (tmp_path / "evil.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""))
+        dst = np.zeros((16, 16), np.uint8)
+        assert L.orbfe_png_info(str(tmp_path / "evil.png").encode(), C.byref(w), C.byref(h)) == -1
+        assert L.orbfe_png_read_gray(str(tmp_path / "evil.png").encode(), dst.ctypes.data_as(C.c_void_p), 16, 16, C.byref(w), C.byref(h)) == -1
+    # truncated IDAT stream: a code
+    ihdr = struct.pack(">IIBBBBB", 8, 8, 8, 0, 0, 0, 0)
+    (tmp_path / "short.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 20)) + chunk(b"IEND", b""))
+    assert L.orbfe_png_read_gray(str(tmp_path / "short.png").encode(), dst.ctypes.data_as(C.c_void_p), 16, 16, C.byref(w), C.byref(h)) == -1

@@ -20,5 +20,5 @@ for o in _obj/*.o; do
     objs="$objs $o"
   fi
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o _ab/liborbfe_$name.so $objs -lz
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o _ab/liborbfe_$name.so $objs -lz -ldl
 echo "built _ab/liborbfe_$name.so"
