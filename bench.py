@@ -251,7 +251,7 @@ def per_frame_latency(cfg, n_frames: int):
     ph = re.search(r"two threads\) ([0-9.]+), ComputeStereoMatches ([0-9.]+), SearchByProjection\(cur,last\) ([0-9.]+)", r.stdout)
     seq_re = r"sequence: (\d+) frames in ([0-9.]+) s = ([0-9.]+) frames/s end to end \(decode threads (\d+), prefetch (\d+); decode ([0-9.]+) s of CPU time = ([0-9.]+) ms per pair; tracking thread waited ([0-9.]+) s"
     sq, sq0 = re.search(seq_re, r.stdout), (re.search(seq_re, r0.stdout) if r0.returncode == 0 else None)
-    prep = re.search(r"front end prepared for \d+x\d+ in ([0-9.]+) ms", r.stdout)
+    prep = re.search(r"front end prepared in ([0-9.]+) ms", r.stdout)
     sequence = None
     if sq:
         sequence = {"frames_per_s": float(sq.group(3)), "decode_threads": int(sq.group(4)), "prefetch_pairs": int(sq.group(5)),
@@ -304,6 +304,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--e2e-steps", type=int, default=12, help="steps of the PCIe-inclusive measurement (0 = skip)")
     ap.add_argument("--per-frame", type=int, default=192, help="stereo pairs pushed one at a time through the C++ drop-in classes for per_frame_ms (0 = skip)")
+    ap.add_argument("--content-steps", type=int, default=30, help="steps per image content of the content-sensitivity key (0 = skip)")
     ap.add_argument("--gather", choices=("all", "root"), default="all",
                     help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
@@ -549,6 +550,79 @@ def main():
         e2e_run(args.e2e_steps)
         e2e = F * args.e2e_steps / (time.perf_counter() - t1)
 
+    # ---- content sensitivity (N = 1, outside the timed region): the same step on other image content.  The headline runs on the
+    #      synthetic generator of SURVEY.md 8(d); FAST's cost drivers (fallback cells, quick-test early-outs) differ 2-3 x between
+    #      it and real texture (DESIGN lesson 18), dense noise sends the quadtree's keys to HBM, a flat frame has no corner at all.
+    content = None
+    if world == 1 and args.content_steps > 0 and STEREO and cfg["match"] == "projection":
+        def content_images(kind):
+            rng = np.random.default_rng(1234)
+            L = np.zeros((F, H, PITCH), np.uint8)
+            if kind == "real_texture":      # the four DBoW2 demo images of the reference checkout (tests/golden/real_demo.npz), tiled
+                demo = np.load(os.path.join(ROOT, "tests", "golden", "real_demo.npz"))["images"][:4]
+                reps = (H + demo.shape[1] - 1) // demo.shape[1] + 1, (W + 64 + demo.shape[2] - 1) // demo.shape[2] + 1
+                big = [np.tile(d, reps) for d in demo]
+                for f in range(F):
+                    oy, ox = (37 * f) % demo.shape[1], (53 * f) % demo.shape[2]
+                    L[f, :, :W] = big[f % 4][oy:oy + H, ox:ox + W]
+            elif kind == "uniform_noise":
+                base = rng.integers(0, 256, (8, H, W + 64), dtype=np.uint8)
+                for f in range(F):
+                    L[f, :, :W] = base[f % 8][:, (f // 8) % 32:(f // 8) % 32 + W]
+            elif kind == "flat":
+                L[:, :, :W] = 128
+            R = np.zeros_like(L)
+            R[:, :, :W - 10] = L[:, :, 10:W]     # the right eye sees the scene 10 pixels further left
+            R[:, :, W - 10:W] = L[:, :, W - 10:W]
+            return torch.from_numpy(L), torch.from_numpy(R)
+
+        content = {}
+        for kind in ("real_texture", "uniform_noise", "flat"):
+            try:
+                tl, tr = content_images(kind)
+                B0.dL_full.copy_(tl); B0.dR_full.copy_(tr)
+                for e in extractors:
+                    e.profile(True); e.stage_times(reset=True)
+                for _ in range(3):
+                    step()
+                barrier()
+                for e in extractors:
+                    e.device_status()
+                st = {k: round(v[0] / max(v[1] // 2 if k == "pyramid" else v[1], 1), 4) for k, v in stage_sums().items()}
+                for e in extractors:
+                    e.profile(False)
+                barrier()
+                tc = time.perf_counter()
+                for _ in range(args.content_steps):
+                    step()
+                barrier()
+                dtc = time.perf_counter() - tc
+                content[kind] = {"frames_per_s": round(F * args.content_steps / dtc, 1), "ms_per_step": round(dtc / args.content_steps * 1e3, 4),
+                                 "stage_ms_per_batch": st, "keypoints_per_image": round((int(B0.nl.sum().item()) + int(B0.nr.sum().item())) / (2 * F), 1),
+                                 "stereo_matches_per_frame": round(int(B0.n_stereo.sum().item()) / F, 1),
+                                 "tracked_per_frame": round(int(B0.n_track.sum().item()) / F, 1)}
+            except Exception as ex:   # a content the library refuses must not cost the headline line
+                content[kind] = {"error": str(ex)[:200]}
+        # packed input for comparison with earlier rounds: tightly packed rows (W bytes apart) cost one pitched copy per image first
+        try:
+            pk_l = torch.from_numpy(np.stack([p[0] for p in data])).to(dev); pk_r = torch.from_numpy(np.stack([p[1] for p in data])).to(dev)
+            keepL, keepR = B0.dL, B0.dR
+            B0.dL, B0.dR = pk_l, pk_r
+            for _ in range(3):
+                step()
+            barrier()
+            tc = time.perf_counter()
+            for _ in range(args.content_steps):
+                step()
+            barrier()
+            content["synthetic_packed_rows"] = {"frames_per_s": round(F * args.content_steps / (time.perf_counter() - tc), 1),
+                                                "note": f"the headline's images in tightly packed rows ({W} bytes apart): level 0 is a pitched copy"}
+            B0.dL, B0.dR = keepL, keepR
+        except Exception as ex:
+            content["synthetic_packed_rows"] = {"error": str(ex)[:200]}
+        B0.dL_full.copy_(hL); B0.dR_full.copy_(hR)
+        step(); barrier()
+
     if rank == 0:
         px = [exL.level_size(l, W, H) for l in range(NLEVELS)]
         sumP = sum(w * h for w, h in px)
@@ -600,6 +674,10 @@ def main():
         if e2e is not None:
             out["e2e_frames_per_s"] = round(e2e, 1)
             out["e2e_note"] = "pinned host images -> H2D -> step -> D2H of keypoints, descriptors, counts, matches (and mvuRight / mvDepth), double-buffered"
+        if content is not None:
+            out["content"] = content
+            out["content_note"] = (f"the same step ({args.content_steps} steps each, outside the timed region) on other content: the DBoW2 demo images tiled "
+                                   f"to {W}x{H}, uniform noise (HBM-spill quadtree), a flat frame; `value` is the synthetic sequence of SURVEY.md 8(d)")
         if world == 1 and args.per_frame > 0 and STEREO:
             pf = per_frame_latency(cfg, args.per_frame)
             out["per_frame_ms"] = pf.get("median_ms")

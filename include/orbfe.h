@@ -66,6 +66,14 @@ typedef struct orbfe_extractor orbfe_extractor;
 
 const char* orbfe_last_error(void);   /* thread-local text of the last failure on this thread */
 int orbfe_device_count(int* count);   /* number of visible HIP devices */
+/* For hosts that do not link the HIP runtime themselves: the calling thread's current device (handles created with device = -1,
+ * the per-thread matcher handle and the C++ drop-in classes use it), and plain device memory with synchronous copies (a C / C++
+ * caller of the batched mode keeps its per-frame records in HBM for orbfe_gather_records). */
+int orbfe_set_device(int device);
+int orbfe_device_malloc(size_t bytes, void** out);
+int orbfe_device_free(void* p);
+int orbfe_device_upload(void* d_dst, const void* h_src, size_t bytes);
+int orbfe_device_download(void* h_dst, const void* d_src, size_t bytes);
 
 /* Hard limits (checked, ORBFE_ERR_INVALID beyond them):
  *   images              at most 4095 x 4095 pixels (keypoint coordinates travel between kernels as 12-bit fields) and at least

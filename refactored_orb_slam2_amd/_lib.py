@@ -85,7 +85,8 @@ class FrameView(C.Structure):
 
 # every symbol include/orbfe.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "orbfe_last_error", "orbfe_device_count", "orbfe_thread_release", "orbfe_extractor_prepare", "orbfe_frontend_prepare",
+    "orbfe_last_error", "orbfe_device_count", "orbfe_set_device", "orbfe_device_malloc", "orbfe_device_free", "orbfe_device_upload",
+    "orbfe_device_download", "orbfe_thread_release", "orbfe_extractor_prepare", "orbfe_frontend_prepare",
     "orbfe_shard_range", "orbfe_gather_unique_id", "orbfe_gather_create", "orbfe_gather_create_all", "orbfe_gather_destroy",
     "orbfe_gather_rank", "orbfe_gather_records", "orbfe_gather_sync", "orbfe_extractor_create", "orbfe_extractor_destroy",
     "orbfe_extractor_levels", "orbfe_extractor_scale_factors", "orbfe_extractor_inv_scale_factors",

@@ -58,6 +58,36 @@ extern "C" int orbfe_device_count(int* count) {
   return ORBFE_OK;
 }
 
+// Device selection and plain device memory for hosts that do not link the HIP runtime themselves (a C or C++ caller of the
+// batched mode keeps its records in HBM for the gather): thin wrappers, synchronous.
+extern "C" int orbfe_set_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { orbfe_set_error("no HIP device available"); return ORBFE_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) return ORBFE_ERR_INVALID;
+  HIPCHK(hipSetDevice(device));
+  return ORBFE_OK;
+}
+extern "C" int orbfe_device_malloc(size_t bytes, void** out) {
+  if (!out) return ORBFE_ERR_INVALID;
+  *out = nullptr;
+  HIPCHK(hipMalloc(out, bytes ? bytes : 256));
+  return ORBFE_OK;
+}
+extern "C" int orbfe_device_free(void* p) {
+  if (p) HIPCHK(hipFree(p));
+  return ORBFE_OK;
+}
+extern "C" int orbfe_device_upload(void* d_dst, const void* h_src, size_t bytes) {
+  if ((!d_dst || !h_src) && bytes) return ORBFE_ERR_INVALID;
+  if (bytes) HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return ORBFE_OK;
+}
+extern "C" int orbfe_device_download(void* h_dst, const void* d_src, size_t bytes) {
+  if ((!h_dst || !d_src) && bytes) return ORBFE_ERR_INVALID;
+  if (bytes) HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return ORBFE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ handle
 struct LevelGeom {
   int w, h, pitch;

@@ -73,6 +73,10 @@ class ORBextractor:
         _lib.check(self._L.orbfe_extractor_max_keypoints(self._h, w, h, C.byref(cap)), "orbfe_extractor_max_keypoints")
         return cap.value
 
+    def prepare(self, w: int, h: int, n_images: int = 1):
+        """orbfe_extractor_prepare: plan, work space, code objects and launch graph for w x h images, before the first frame."""
+        _lib.check(self._L.orbfe_extractor_prepare(self._h, w, h, n_images), "orbfe_extractor_prepare")
+
     # ---- operator()
     def __call__(self, image: np.ndarray, mask=None):
         """ORBextractor::operator() on one host image (mask ignored, as in the reference)."""

@@ -19,6 +19,69 @@ def shard_range(n_frames: int, rank: int, world: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def shard_range_c(n_frames: int, rank: int, world: int) -> tuple[int, int]:
+    """The same split through the C ABI (orbfe_shard_range): what a C++ host uses."""
+    import ctypes as C
+    from . import _lib
+    b, e = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().orbfe_shard_range(n_frames, rank, world, C.byref(b), C.byref(e)), "orbfe_shard_range")
+    return b.value, e.value
+
+
+class RcclGather:
+    """ctypes mirror of the C ABI's record gather (include/orbfe.h: orbfe_gather_*): RCCL called by liborbfe itself, no
+    torch.distributed in the data path.  `unique_id()` on rank 0, hand the 128 bytes to the other ranks (any side channel:
+    here usually a torch.distributed broadcast of the control-plane group), then RcclGather(id, rank, world, device)."""
+    ALL, ROOT = 0, 1
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int = -1):
+        import ctypes as C
+        from . import _lib
+        self._L = _lib.lib()
+        self._h = C.c_void_p(None)
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _lib.check(self._L.orbfe_gather_create(buf, rank, world, device, C.byref(self._h)), "orbfe_gather_create")
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().orbfe_gather_unique_id(buf), "orbfe_gather_unique_id")
+        return bytes(buf)
+
+    def gather(self, n, kps, desc, mode: str = "all", stream=None):
+        """n: int32 (F,), kps: uint8 (F, cap, 28), desc: uint8 (F, cap, 32) device tensors.  Returns the gathered tensors
+        (world * F leading dimension) on the ranks that receive, None elsewhere.  Asynchronous on `stream`."""
+        import torch
+        from . import _lib
+        if mode not in ("all", "root"):
+            raise ValueError("mode must be 'all' or 'root'")
+        recv = mode == "all" or self.rank == 0
+        out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in (n, kps, desc)] if recv else None
+        ptrs = [_lib.ptr(t) for t in out] if recv else [None, None, None]
+        _lib.check(self._L.orbfe_gather_records(self._h, _lib.ptr(n), _lib.ptr(kps), _lib.ptr(desc), n.shape[0], kps.shape[1],
+                                                self.ALL if mode == "all" else self.ROOT, ptrs[0], ptrs[1], ptrs[2],
+                                                _lib.stream_handle(stream)), "orbfe_gather_records")
+        return tuple(out) if recv else None
+
+    def sync(self):
+        from . import _lib
+        _lib.check(self._L.orbfe_gather_sync(self._h), "orbfe_gather_sync")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbfe_gather_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def padded_chunk(n_frames: int, world: int) -> int:
     """Frames per rank after padding the last chunks, so every rank contributes equally sized records."""
     return (n_frames + world - 1) // world

@@ -178,3 +178,21 @@ def test_cpp_sequence_driver_on_kitti_layout(tmp_path):
         np.testing.assert_array_equal(a, assigned, err_msg=f"tracked assignment of frame {i}")
     assert off == len(raw)
     assert exp[2][4] > 500 and (exp[1][3] > 0).sum() > 800
+    # the report: every frame counts (the front end was prepared before frame 0), tail latencies, the end-to-end rate
+    for key in ("mean tracking time", "p95 tracking time", "p99 tracking time", "max tracking time", "frames/s end to end", "front end prepared in"):
+        assert key in r.stdout, key
+    # the batched mode's exchange through the C ABI (orbfe_gather_create_all + orbfe_gather_records; one GPU here: world 1), both
+    # forms, and the reference's load-then-track loop (no decode pool, no warm-up): the same records
+    for extra in (["--gather", "all"], ["--gather", "root", "--decode-threads", "0", "--prepare", "0"]):
+        gd = str(tmp_path / "gather.bin")
+        r2 = subprocess.run([exe, str(seq), "--gather-dump", gd] + extra, capture_output=True, text=True, timeout=600)
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        assert "RCCL through the C ABI" in r2.stdout and "0 frame(s) differ" in r2.stdout, r2.stdout
+        graw = open(gd, "rb").read()
+        goff = 0
+        for i, (kL, dL, *_rest) in enumerate(exp):
+            n = int(np.frombuffer(graw, np.int32, 1, goff)[0]); goff += 4
+            assert n == len(kL)
+            np.testing.assert_array_equal(np.frombuffer(graw, KP_DTYPE, n, goff), kL, err_msg=f"gathered keypoints of frame {i}"); goff += 28 * n
+            np.testing.assert_array_equal(np.frombuffer(graw, np.uint8, 32 * n, goff).reshape(n, 32), dL); goff += 32 * n
+        assert goff == len(graw)

@@ -333,6 +333,95 @@ def test_rccl_gather_self_check_world1():
     ex.close()
 
 
+def test_c_abi_record_gather_world1_and_comm_init_all():
+    """The batched-sequence exchange behind the C ABI (include/orbfe.h: orbfe_gather_*; RCCL called by liborbfe, no
+    torch.distributed in the data path): pack the per-frame records of a device batch, gather them at world size 1 --
+    ncclAllGather, then the rank-0 form (grouped send / recv; rank 0's own records are a stream-ordered copy) --, unpack,
+    compare with the unsharded extraction.  Both ways of making the communicator: unique id + orbfe_gather_create (one process
+    per GPU) and orbfe_gather_create_all (one process, one thread per GPU: ncclCommInitAll)."""
+    import ctypes as C
+    import torch
+    from refactored_orb_slam2_amd import _lib, sharding
+    w, h, nf, F = 640, 480, 1000, 5
+    imgs = synth.sequence(w, h, F, seq=4)
+    ex = ORBextractor(nf)
+    single = ex.extract_batch(imgs)
+    cap = ex.max_keypoints(w, h)
+    dimg = torch.from_numpy(np.stack(imgs)).cuda()
+    kps = torch.zeros((F, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(F, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ex.extract_batch_device(dimg, kps, desc, n, stream=st)
+
+    def check(res):
+        torch.cuda.synchronize()
+        frames = sharding.unpack_records(*res, F)
+        for (k, d), (k0, d0) in zip(frames, single):
+            np.testing.assert_array_equal(k, k0)
+            np.testing.assert_array_equal(d, d0)
+
+    g = sharding.RcclGather(sharding.RcclGather.unique_id(), 0, 1, 0)
+    for mode in ("all", "root"):
+        check(g.gather(n, kps, desc, mode=mode, stream=st))      # same stream as the extraction: ordered behind it
+    st.synchronize()
+    check(g.gather(n, kps, desc, mode="all"))                    # the handle's own stream + orbfe_gather_sync
+    g.sync()
+    g.close()
+    L = _lib.lib()
+    hs = (C.c_void_p * 1)()
+    assert L.orbfe_gather_create_all(1, None, hs) == 0, L.orbfe_last_error()
+    rank, world = C.c_int(-1), C.c_int(-1)
+    assert L.orbfe_gather_rank(C.c_void_p(hs[0]), C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+    out = [torch.empty_like(t) for t in (n, kps, desc)]
+    assert L.orbfe_gather_records(C.c_void_p(hs[0]), _lib.ptr(n), _lib.ptr(kps), _lib.ptr(desc), F, cap, 1, _lib.ptr(out[0]),
+                                  _lib.ptr(out[1]), _lib.ptr(out[2]), None) == 0, L.orbfe_last_error()
+    assert L.orbfe_gather_sync(C.c_void_p(hs[0])) == 0
+    check(out)
+    # argument errors are codes
+    assert L.orbfe_gather_records(C.c_void_p(hs[0]), _lib.ptr(n), _lib.ptr(kps), _lib.ptr(desc), F, cap, 7, None, None, None, None) == -1
+    assert L.orbfe_gather_records(C.c_void_p(hs[0]), _lib.ptr(n), _lib.ptr(kps), _lib.ptr(desc), F, cap, 0, None, None, None, None) == -1
+    assert L.orbfe_gather_destroy(C.c_void_p(hs[0])) == 0
+    ex.close()
+
+
+def test_prepare_moves_the_first_call_cost_out_of_the_first_frame():
+    """orbfe_extractor_prepare / orbfe_frontend_prepare (include/orbfe.h, warm-up): the plan, the work space, the code objects and
+    the launch graph exist before the first frame.  Results after a prepare are the results without one (the synthetic warm-up
+    frames leave no state behind), and the first real call costs what a later one costs -- not the ~30 ms of a cold handle."""
+    import ctypes as C
+    import time
+    from refactored_orb_slam2_amd import _lib
+    w, h, nf = 1241, 376, 2000
+    img = synth.sequence(w, h, 2, seq=12)
+    cold = ORBextractor(nf)
+    k0, d0 = cold(img[0])
+    warm = ORBextractor(nf)
+    warm.prepare(w, h, 1)
+    t = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        k1, d1 = warm(img[0])
+        t.append(time.perf_counter() - t0)
+    np.testing.assert_array_equal(k1, k0)
+    np.testing.assert_array_equal(d1, d0)
+    assert t[0] < 3 * sorted(t)[len(t) // 2] + 1e-3, t          # no first-call spike left
+    # both eyes + the calling thread's matcher handle; then a stereo match and a search on real frames equal the oracle's
+    L = _lib.lib()
+    exL, exR = ORBextractor(nf), ORBextractor(nf)
+    assert L.orbfe_frontend_prepare(exL._h, exR._h, w, h, 0) == 0, L.orbfe_last_error()
+    assert L.orbfe_frontend_prepare(exL._h, None, w, h, 500) == 0, L.orbfe_last_error()      # monocular form
+    pair = synth.sequence(w, h, 1, seq=13, stereo=True)[0]
+    kl, dl = exL(pair[0]); kr, dr = exR(pair[1])
+    orc = ol.OracleExtractor(nf)
+    okl, odl = orc(pair[0])
+    np.testing.assert_array_equal(kl, okl); np.testing.assert_array_equal(dl, odl)
+    for e in (cold, warm, exL, exR):
+        e.close()
+    assert L.orbfe_extractor_prepare(None, w, h, 1) == -1 and L.orbfe_extractor_prepare(cold._h, 0, h, 1) == -1
+
+
 def test_bench_spawns_its_ranks_and_checks_the_gather():
     """`bench.py --gpus 2` started without a launcher must produce two ranks by itself (one process each; on this one-GPU box
     both share the device and the gather runs over gloo, because RCCL refuses two ranks per device) and print n_gpus = 2.  Every

@@ -155,6 +155,23 @@ def test_gather_records_identity_without_group():
     assert out[0] is n and out[1] is k and out[2] is d
 
 
+def test_c_abi_shard_range_equals_the_python_split():
+    """orbfe_shard_range (what a C++ host of the batched mode calls) == sharding.shard_range: contiguous, exhaustive, sizes
+    differing by at most one; bad arguments are codes."""
+    import ctypes as C
+    from refactored_orb_slam2_amd import _lib
+    L = _lib.lib()
+    for n_frames in (0, 1, 7, 8, 4541):
+        for world in (1, 2, 3, 8):
+            got = [sharding.shard_range_c(n_frames, r, world) for r in range(world)]
+            assert got == [sharding.shard_range(n_frames, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n_frames and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    b, e = C.c_int(), C.c_int()
+    assert L.orbfe_shard_range(10, 3, 3, C.byref(b), C.byref(e)) == -1
+    assert L.orbfe_shard_range(10, 0, 0, C.byref(b), C.byref(e)) == -1
+    assert L.orbfe_shard_range(-1, 0, 1, C.byref(b), C.byref(e)) == -1
+
+
 def test_png_reader_decodes_all_filters_and_rgb(tmp_path):
     """liborbfe's zlib PNG reader (sequence driver input): 8-bit grey with every filter type, RGB converted with cvtColor's
     fixed-point RGB2GRAY weights; files written by PIL (adaptive filters) and by the driver test's minimal writer."""

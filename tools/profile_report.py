@@ -46,7 +46,7 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
         head = "bench line not parsed"
     with open(out_prefix + "_kernel_stats.md", "w") as f:
         f.write(f"# {os.path.basename(out_prefix)}: rocprofv3 kernel stats of the bench step\n\n"
-                "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0` "
+                "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0` "
                 f"(tools/profile_round.sh), times in microseconds per launch of 256 images; {head}.\n\n")
         f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
         for r in rows:
@@ -61,7 +61,7 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
     cs = counters(tag_dir)
     with open(out_prefix + "_pmc_counters.md", "w") as f:
         f.write(f"# {os.path.basename(out_prefix)}: PMC counters per kernel launch (256 KITTI images / stereo frames per launch)\n\n"
-                "Separate `rocprofv3 --kernel-trace --pmc <set>` passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0` "
+                "Separate `rocprofv3 --kernel-trace --pmc <set>` passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0` "
                 "(tools/profile_round.sh: two SQ sets, FETCH_SIZE, WRITE_SIZE, TCC hit/miss, GRBM_GUI_ACTIVE), averaged over the later launches of "
                 "each kernel; durations from the `--stats` pass of the same build.  FETCH / WRITE are KB as rocprofv3 reports them; FETCH is doubled "
                 "(x2) for kernels whose bulk reads are coalesced 16-byte-per-lane loads, which gfx950 tallies at half their bytes "
@@ -95,7 +95,7 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
     json.dump({"stage": st, "config": config, "kernel": dom, "images_per_launch": 256, "fetch_kb": cs[dom].get("FETCH_SIZE", 0),
                "fetch_correction": 2.0 if wide else 1.0, "write_kb": cs[dom].get("WRITE_SIZE", 0), "avg_us_stats_pass": avg_us[dom],
                "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                         "--warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0; FETCH_SIZE x 2 for 16-byte-per-lane coalesced loads on gfx950 (MI355X_MICROARCH.md, HBM section)"},
+                         "--warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0; FETCH_SIZE x 2 for 16-byte-per-lane coalesced loads on gfx950 (MI355X_MICROARCH.md, HBM section)"},
               open(out_prefix + "_pmc_dominant.json", "w"), indent=1)
     print("dominant:", dom, avg_us[dom])
 

@@ -5,13 +5,13 @@
 #   the markdown / json files committed under profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; shift; mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 "$@" > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
 tail -1 $OUT/stats.log | cut -c1-200
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 "$@" > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
   echo "pass $i done"
 done
