@@ -640,14 +640,16 @@ def main():
         per_launch_ms[dom] = st_dom[0] / max(cnt, 1)              # the dominant kernel: live, over the timed region
         achieved = alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9
         # HBM-side traffic of the dominant kernel: FETCH_SIZE (x2 for 16-byte-per-lane streams on gfx950) + WRITE_SIZE from the
-        # committed PMC pass of THIS kernel build (profiles/r03_pmc_dominant.json), scaled to this launch's image count;
+        # committed PMC pass of THIS kernel build (profiles/rNN_pmc_dominant.json, latest round), scaled to this launch's image count;
         # null when the pass covers another kernel or configuration
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_dominant.json")))
+            import glob
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_dominant.json")))[-1]   # the latest round's pass
+            pmc = json.load(open(pmc_path))
             if pmc["stage"] == dom and pmc["config"] == args.config:
                 traffic = int((pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
-                traffic_src = f"committed rocprofv3 --pmc pass ({pmc['kernel']}), not measured in this run"
+                traffic_src = f"committed rocprofv3 --pmc pass ({pmc['kernel']}, {os.path.basename(pmc_path)}), not measured in this run"
         except Exception:
             pass
         value = world * F * args.steps / dt

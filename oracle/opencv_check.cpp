@@ -83,6 +83,71 @@ static void check_scalars() {
     }
 }
 
+// Cases the whole-image runs cannot reach (each primitive called directly, small crafted inputs)
+static void check_edge_cases() {
+  // P2: one resize step at each of the seven KITTI level sizes, incl. the right-border columns where sx + 1 >= sw clamps
+  // (xmax) and the bottom rows where the source row clamps
+  const int lw[8] = {1241, 1034, 862, 718, 598, 499, 416, 346}, lh[8] = {376, 313, 261, 218, 181, 151, 126, 105};
+  for (int l = 1; l < 8; l++) {
+    cv::Mat src = synth_image(lw[l - 1], lh[l - 1], 0xC0FFEE + (uint32_t)l), dst;
+    for (int y = 0; y < src.rows; y++) { src.at<uchar>(y, src.cols - 1) = (uchar)(y * 7); src.at<uchar>(y, src.cols - 2) = (uchar)(255 - y); }
+    cv::resize(src, dst, cv::Size(lw[l], lh[l]), 0, 0, cv::INTER_LINEAR);
+    std::vector<uint8_t> od((size_t)lw[l] * lh[l]);
+    oo_resize_linear_u8(src.data, src.cols, src.rows, (int)src.step, od.data(), lw[l], lh[l], lw[l]);
+    int bad = 0, bad_edge = 0;
+    for (int y = 0; y < lh[l]; y++)
+      for (int x = 0; x < lw[l]; x++) {
+        const bool d = dst.at<uchar>(y, x) != od[(size_t)y * lw[l] + x];
+        bad += d;
+        bad_edge += d && (x >= lw[l] - 2 || y >= lh[l] - 2);
+      }
+    CHECK(bad == 0, "P2 resize %dx%d -> %dx%d: %d pixels differ (%d of them in the last two columns / rows)", lw[l - 1], lh[l - 1], lw[l],
+          lh[l], bad, bad_edge);
+  }
+  // P3: GaussianBlur on degenerate widths (1 and 7 pixels wide, 1 and 7 pixels high): REFLECT_101 folds several taps onto one
+  // sample; and on a saturated image (every sum at its maximum: the rounding constant shows)
+  const int dims[][2] = {{1, 40}, {7, 40}, {40, 1}, {40, 7}, {2, 2}, {3, 5}, {64, 64}};
+  for (auto& d : dims) {
+    cv::Mat m(d[1], d[0], CV_8UC1), b;
+    for (int y = 0; y < m.rows; y++)
+      for (int x = 0; x < m.cols; x++) m.at<uchar>(y, x) = (d[0] == 64) ? 255 : (uchar)(rnd() & 0xff);
+    cv::GaussianBlur(m, b, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+    std::vector<uint8_t> og((size_t)m.cols * m.rows);
+    oo_gaussian_blur7_u8(m.data, m.cols, m.rows, (int)m.step, og.data(), m.cols);
+    int bad = 0;
+    for (int y = 0; y < m.rows; y++)
+      for (int x = 0; x < m.cols; x++) bad += b.at<uchar>(y, x) != og[(size_t)y * m.cols + x];
+    CHECK(bad == 0, "P3 GaussianBlur %dx%d: %d pixels differ", d[0], d[1], bad);
+  }
+  // P4: FAST on plateau corners -- equal scores on adjacent pixels (strict > in the non-maximum suppression: both go), a corner
+  // whose arc is exactly nine long, thresholds at which the arc's weakest pixel is exactly v +- t (strict comparison), a 7 x 7
+  // ROI (one tested pixel) and a ROI too small to test anything
+  {
+    cv::Mat m(40, 40, CV_8UC1, cv::Scalar(100));
+    cv::rectangle(m, cv::Rect(10, 10, 12, 12), cv::Scalar(160), cv::FILLED);          // four corners with 2 x 2 plateaus nearby
+    cv::rectangle(m, cv::Rect(28, 5, 2, 2), cv::Scalar(121), cv::FILLED);             // differences of exactly 21 and 20
+    m.at<uchar>(30, 20) = 120; m.at<uchar>(30, 21) = 120;                             // twin maxima
+    for (int th : {7, 19, 20, 21, 59, 60}) {
+      for (auto roi : {cv::Rect(0, 0, 40, 40), cv::Rect(7, 7, 20, 20), cv::Rect(17, 17, 7, 7), cv::Rect(0, 0, 6, 6)}) {
+        std::vector<cv::KeyPoint> k;
+        cv::FAST(m(roi), k, th, true);
+        std::vector<int> fx(roi.area() + 1), fy(roi.area() + 1), fs(roi.area() + 1);
+        const int n = oo_fast9_16(m.data + (size_t)roi.y * m.step + roi.x, (int)m.step, roi.width, roi.height, th, 1, roi.area(), fx.data(), fy.data(), fs.data());
+        CHECK(n == (int)k.size(), "P4 FAST plateau th %d roi %dx%d: %d keypoints, oracle %d", th, roi.width, roi.height, (int)k.size(), n);
+        for (int t = 0; t < n && t < (int)k.size(); t++)
+          CHECK((int)k[t].pt.x == fx[t] && (int)k[t].pt.y == fy[t] && (int)k[t].response == fs[t], "P4 FAST plateau th %d kp %d differs", th, t);
+      }
+    }
+  }
+  // P5: fastAtan2 on the axes, the diagonals, zero and tiny / huge magnitudes
+  const float vals[] = {0.f, -0.f, 1.f, -1.f, 1e-30f, -1e-30f, 3e6f, -3e6f, 749.f * 255.f * 15.f, 5e-7f};
+  for (float y : vals)
+    for (float x : vals) {
+      const float a = cv::fastAtan2(y, x), b = oo_fast_atan2(y, x);
+      CHECK(a == b, "fastAtan2(%g, %g) = %.9g, oracle %.9g", y, x, a, b);
+    }
+}
+
 static void check_image(const cv::Mat& image, int nfeatures, const char* name) {
   const int nlevels = 8;
   const float scaleFactor = 1.2f;
@@ -192,6 +257,7 @@ static void check_image(const cv::Mat& image, int nfeatures, const char* name) {
 
 int main(int argc, char** argv) {
   check_scalars();
+  check_edge_cases();
   if (argc > 1) {
     for (int i = 1; i < argc; i++) {
       cv::Mat im = cv::imread(argv[i], cv::IMREAD_GRAYSCALE);

@@ -1565,9 +1565,11 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 // instructions of a wave-per-keypoint kernel, each of them computing ONE value on 64 lanes).  Here a wave takes eight consecutive
 // keypoint slots: phase 1 stages each raw 31 x 31 patch and leaves the keypoint's moments in lane k; phase 2 evaluates
 // fastAtan2 / sinf / cosf once, lane k for keypoint k; phase 3 stages each blurred 37 x 37 patch and samples the pattern with
-// (a, b) read from lane k.  The moments use v_dot4_u32_u8: a lane owns four (row, 4-column) items of the disc, the per-item
-// weights (u + 15, v + 15 and 1 inside the disc, 0 outside; a host-filled table) stay in registers for all eight keypoints, and
-// m10 = sum (u+15) I - 15 sum I, m01 = sum (v+15) I - 15 sum I -- integer, hence the same moments as the reference's loops.
+// (a, b) read from lane k.  The moments use v_dot4_i32_i8: a lane owns four (row, 4-column) items of the disc, the per-item
+// weights (u and v as signed bytes, 0 outside the disc; a host-filled table) stay in registers for all eight keypoints, and the
+// pixels enter as I - 128 (one xor per dword).  The disc is symmetric, sum u = sum v = 0, so sum u (I - 128) = sum u I = m10
+// exactly -- integer, hence the same moments as the reference's loops -- and no sum of I is needed: two wave reductions per
+// keypoint instead of three.
 #ifndef OD_K
 #define OD_K 8
 #endif
@@ -1583,7 +1585,7 @@ extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
-__device__ __attribute__((aligned(16))) uint32_t g_ic_w[256 * 3];   // [item][u-weights | v-weights | inside], item = row * 8 + 4-column group
+__device__ __attribute__((aligned(16))) uint32_t g_ic_w[256 * 2];   // [item][u-weights | v-weights] (int8 x 4), item = row * 8 + 4-column group
 __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1614,11 +1616,12 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
   float4 pk[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
-  uint32_t wu[4], wv[4], w1[4];
+  uint32_t wu[4], wv[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int it = lane + WAVE * j;   // items >= 248 carry zero weights
-    wu[j] = g_ic_w[it * 3]; wv[j] = g_ic_w[it * 3 + 1]; w1[j] = g_ic_w[it * 3 + 2];
+    const uint2 w2 = reinterpret_cast<const uint2*>(g_ic_w)[it];
+    wu[j] = w2.x; wv[j] = w2.y;
   }
   uint8_t* ori = &patch[wv_id][0];
   uint8_t* dsc = ori + ORI_BYTES;
@@ -1704,21 +1707,20 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      uint32_t A = 0, B = 0, S = 0;
+      int A = 0, B = 0;
       const uint32_t sh = (uint32_t)(m & 3);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int it = lane + WAVE * j;
         const int r = it >> 3, c = it & 7;
         const uint32_t* q = reinterpret_cast<const uint32_t*>(ori + (r < 31 ? r : 30) * ORI_PITCH + ((m + 4 * c) & ~3));
-        const uint32_t px = __builtin_amdgcn_alignbyte(q[1], q[0], sh);   // the four pixels u = -15 + 4c .. -12 + 4c of row v = r - 15
-        A = __builtin_amdgcn_udot4(px, wu[j], A, false);
-        B = __builtin_amdgcn_udot4(px, wv[j], B, false);
-        S = __builtin_amdgcn_udot4(px, w1[j], S, false);
+        // the four pixels u = -15 + 4c .. -12 + 4c of row v = r - 15, as I - 128
+        const int px = (int)(__builtin_amdgcn_alignbyte(q[1], q[0], sh) ^ 0x80808080u);
+        A = __builtin_amdgcn_sdot4(px, (int)wu[j], A, false);
+        B = __builtin_amdgcn_sdot4(px, (int)wv[j], B, false);
       }
-      const int At = __builtin_amdgcn_readlane(wave_incl_scan((int)A), 63), Bt = __builtin_amdgcn_readlane(wave_incl_scan((int)B), 63),
-                St = __builtin_amdgcn_readlane(wave_incl_scan((int)S), 63);
-      if (lane == k) { m10v = At - 15 * St; m01v = Bt - 15 * St; }
+      const int At = __builtin_amdgcn_readlane(wave_incl_scan(A), 63), Bt = __builtin_amdgcn_readlane(wave_incl_scan(B), 63);
+      if (lane == k) { m10v = At; m01v = Bt; }
       __builtin_amdgcn_wave_barrier();   // every lane has read the patch before the next keypoint overwrites it
       FC_T(2);   // moments
     }
@@ -1874,7 +1876,12 @@ void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s)
   pp.xcd_images = 1;
   const int per_block = 4 * OD_K;
   dim3 block(256), grid((p.kp_per_image + per_block - 1) / per_block > 0 ? (p.kp_per_image + per_block - 1) / per_block : 1, n_images);
-  hipLaunchKernelGGL(orient_describe8_kernel, grid, block, 0, s, pp);
+  // 63 VGPRs would let eight waves per SIMD run; the gather of 2 000 patches per image is L2-miss bound and an eighth wave
+  // measured slower (0.352 against 0.341 ms per 256 images): unused dynamic LDS keeps a CU at seven workgroups
+#ifndef OD_LDS_PAD
+#define OD_LDS_PAD 10240
+#endif
+  hipLaunchKernelGGL(orient_describe8_kernel, grid, block, OD_LDS_PAD, s, pp);
 }
 
 int orbfe_upload_pattern_floats() {
@@ -1885,7 +1892,7 @@ int orbfe_upload_pattern_floats() {
   if (e != hipSuccess) return (int)e;
   // weights of the moment sums: item = row * 8 + group, row v = r - 15, columns u = -15 + 4 * group + t
   static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-  uint32_t wtab[256 * 3];
+  uint32_t wtab[256 * 2];
   memset(wtab, 0, sizeof(wtab));
   for (int it = 0; it < 248; it++) {
     const int v = (it >> 3) - 15;
@@ -1893,9 +1900,8 @@ int orbfe_upload_pattern_floats() {
       const int u = -15 + 4 * (it & 7) + t;
       const bool inside = u <= 15 && abs(u) <= umax[abs(v)];
       if (!inside) continue;
-      wtab[it * 3] |= (uint32_t)(u + 15) << (8 * t);
-      wtab[it * 3 + 1] |= (uint32_t)(v + 15) << (8 * t);
-      wtab[it * 3 + 2] |= 1u << (8 * t);
+      wtab[it * 2] |= (uint32_t)(uint8_t)(int8_t)u << (8 * t);
+      wtab[it * 2 + 1] |= (uint32_t)(uint8_t)(int8_t)v << (8 * t);
     }
   }
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ic_w), wtab, sizeof(wtab));
