@@ -124,4 +124,11 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
   }
 }
 
+bool ORBextractor::Prepare(int width, int height) {
+  if (!mpImpl) return false;
+  const int rc = orbfe_extractor_prepare(mpImpl, width, height, 1);
+  if (rc != ORBFE_OK) fprintf(stderr, "ORBextractor: orbfe_extractor_prepare failed (%d): %s\n", rc, orbfe_last_error());
+  return rc == ORBFE_OK;
+}
+
 }  // namespace ORB_SLAM2

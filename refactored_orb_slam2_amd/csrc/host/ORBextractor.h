@@ -58,6 +58,9 @@ class ORBextractor {
 
   // ---- additions (not in the reference)
   void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+  // Warm-up for images of this size (plan, work space, code objects, launch graph: orbfe_extractor_prepare) -- e.g. from
+  // Tracking::Tracking once Camera.width / Camera.height are read.  Optional: the first operator() does the same work otherwise.
+  bool Prepare(int width, int height);
   orbfe_extractor* Handle() const { return mpImpl; }
 
  protected:
