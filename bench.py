@@ -569,6 +569,9 @@ def main():
                 base = rng.integers(0, 256, (8, H, W + 64), dtype=np.uint8)
                 for f in range(F):
                     L[f, :, :W] = base[f % 8][:, (f // 8) % 32:(f // 8) % 32 + W]
+            elif kind == "sensor_noise":    # the synthetic sequence with +-8 grey levels of per-pixel noise: 4.5 k FAST candidates at level 0
+                for f in range(F):          # instead of 1.4 k -- more than the quadtree's LDS holds (1 750 keys per level)
+                    L[f, :, :W] = np.clip(hL[f, :, :W].numpy().astype(np.int16) + rng.integers(-8, 9, (H, W)), 0, 255).astype(np.uint8)
             elif kind == "flat":
                 L[:, :, :W] = 128
             R = np.zeros_like(L)
@@ -577,7 +580,7 @@ def main():
             return torch.from_numpy(L), torch.from_numpy(R)
 
         content = {}
-        for kind in ("real_texture", "uniform_noise", "flat"):
+        for kind in ("real_texture", "sensor_noise", "uniform_noise", "flat"):
             try:
                 tl, tr = content_images(kind)
                 B0.dL_full.copy_(tl); B0.dR_full.copy_(tr)
@@ -679,7 +682,8 @@ def main():
         if content is not None:
             out["content"] = content
             out["content_note"] = (f"the same step ({args.content_steps} steps each, outside the timed region) on other content: the DBoW2 demo images tiled "
-                                   f"to {W}x{H}, uniform noise (HBM-spill quadtree), a flat frame; `value` is the synthetic sequence of SURVEY.md 8(d)")
+                                   f"to {W}x{H}, the synthetic sequence with +-8 grey levels of pixel noise (the quadtree's keys of level 0 leave LDS), "
+                                   f"uniform noise (every level's keys in HBM), a flat frame; `value` is the synthetic sequence of SURVEY.md 8(d)")
         if world == 1 and args.per_frame > 0 and STEREO:
             pf = per_frame_latency(cfg, args.per_frame)
             out["per_frame_ms"] = pf.get("median_ms")
