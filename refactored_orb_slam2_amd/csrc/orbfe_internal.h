@@ -7,7 +7,9 @@
 
 #define ORBFE_EDGE 16            // minBorder = EDGE_THRESHOLD - 3 (L/src/ORBextractor.cc:740)
 #define ORBFE_CELL_MAX 66        // largest FAST cell ROI side the cell kernel stages in LDS
-#define ORBFE_BLUR_TILE_H 58      // rows of a blur tile (64 wide); must be even
+#ifndef ORBFE_BLUR_TILE_H
+#define ORBFE_BLUR_TILE_H 56      // rows of a blur tile (64 wide); a multiple of 8: its row blocks are the 16 x 8 storage tiles
+#endif
 #define ORBFE_MAX_INI 256        // largest nIni (root nodes of DistributeOctTree) supported
 #ifndef ORBFE_OCT_THREADS
 #define ORBFE_OCT_THREADS 256
