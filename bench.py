@@ -304,6 +304,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--e2e-steps", type=int, default=12, help="steps of the PCIe-inclusive measurement (0 = skip)")
     ap.add_argument("--per-frame", type=int, default=192, help="stereo pairs pushed one at a time through the C++ drop-in classes for per_frame_ms (0 = skip)")
+    ap.add_argument("--c-abi-gather", type=int, default=0, help="N > 1: after the line, run the record gather through the C ABI (orbfe_gather_*, RCCL inside "
+                                                                "liborbfe) in both modes, compare with the local records, report on stderr (default off: "
+                                                                "the path has never run with peers and must not be able to cost the line)")
     ap.add_argument("--content-steps", type=int, default=30, help="steps per image content of the content-sensitivity key (0 = skip)")
     ap.add_argument("--gather", choices=("all", "root"), default="all",
                     help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
@@ -700,6 +703,27 @@ def main():
             ok = bool((n_all[mine].to(B0.nl.device) == B0.nl).all()) and bool((d_all[mine].to(B0.dl.device) == B0.dl).all())
             if not ok:
                 raise SystemExit(f"rank {rank}: gathered records differ from the local ones")
+        if args.c_abi_gather and backend == "nccl":
+            # the same exchange through the C ABI: unique id from rank 0 over the control-plane group, one communicator per rank
+            from refactored_orb_slam2_amd.sharding import RcclGather
+            uid = [RcclGather.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            cg = RcclGather(uid[0], rank, world, local)
+            report = {}
+            for mode in ("all", "root"):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(sM):
+                    e0.record(sM)
+                    got = cg.gather(B0.nl, B0.kl, B0.dl, mode=mode, stream=sM)
+                    e1.record(sM)
+                torch.cuda.synchronize()
+                good = True
+                if got is not None:
+                    mine = slice(rank * F, (rank + 1) * F)
+                    good = bool((got[0][mine] == B0.nl).all()) and bool((got[2][mine] == B0.dl).all())
+                report[mode] = {"ms": round(e0.elapsed_time(e1), 4), "own_slot_equal": good}
+            cg.close()
+            print(json.dumps({"c_abi_gather": report, "rank": rank, "world": world}), file=sys.stderr, flush=True)
         dist.barrier()
         dist.destroy_process_group()
 
