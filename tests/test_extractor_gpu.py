@@ -422,6 +422,37 @@ def test_prepare_moves_the_first_call_cost_out_of_the_first_frame():
     assert L.orbfe_extractor_prepare(None, w, h, 1) == -1 and L.orbfe_extractor_prepare(cold._h, 0, h, 1) == -1
 
 
+def test_replayed_launch_graph_keeps_the_host_state_current():
+    """A one-image host call is replayed from a captured hipGraph from its third use on (extractor.cpp): the launches' host-side
+    bookkeeping does not run then.  The number of images of the last call guards orbfe_debug_* / orbfe_pyramid_level / the stereo
+    entry points: after a five-image device batch a REPLAYED one-image call must leave it at 1 (image 1 is refused, image 0 is
+    the new image), and the results of the replayed call are those of a fresh handle."""
+    import torch
+    w, h, nf = 640, 480, 1000
+    imgs = synth.sequence(w, h, 6, seq=17)
+    ex = ORBextractor(nf)
+    for _ in range(4):                       # direct, direct, capture + replay, replay
+        k_warm, d_warm = ex(imgs[5])
+    cap = ex.max_keypoints(w, h)
+    dimg = torch.from_numpy(np.stack(imgs[:5])).cuda()
+    kps = torch.zeros((5, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((5, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(5, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(dimg, kps, desc, n)
+    ex.sync()
+    np.testing.assert_array_equal(ex.debug_pyramid(4, 0), imgs[4])       # five images resident
+    k, d = ex(imgs[5])                                                   # replayed graph
+    np.testing.assert_array_equal(k, k_warm); np.testing.assert_array_equal(d, d_warm)
+    np.testing.assert_array_equal(ex.debug_pyramid(0, 0), imgs[5])
+    with pytest.raises(Exception):
+        ex.debug_pyramid(1, 0)                                           # slot 1 belongs to the earlier batch: refused
+    fresh = ORBextractor(nf)
+    k0, d0 = fresh(imgs[5])
+    np.testing.assert_array_equal(k, k0); np.testing.assert_array_equal(d, d0)
+    ex.close(); fresh.close()
+
+
 def test_bench_spawns_its_ranks_and_checks_the_gather():
     """`bench.py --gpus 2` started without a launcher must produce two ranks by itself (one process each; on this one-GPU box
     both share the device and the gather runs over gloo, because RCCL refuses two ranks per device) and print n_gpus = 2.  Every
