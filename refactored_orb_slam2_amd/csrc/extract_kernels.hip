@@ -1856,18 +1856,18 @@ void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hip
 
 // Which blur runs: measured on 256 KITTI images (profiles/r04_blur_mfma.md, DESIGN lesson 31) the matrix-core kernel does the
 // arithmetic of the LDS kernel in a third of the vector instructions and is bit-exact, but the stage moves 0.74 GB per launch
-// and both kernels take 0.29-0.32 ms for it; the LDS kernel is a few per cent ahead and stays the default.
+// and both kernels take 0.29-0.32 ms for it; the LDS kernel is a few per cent ahead and is what a handle uses unless
+// orbfe_debug_blur_kernel() selects the other one (the parity test of the matrix-core kernel does; -DORBFE_BLUR_MFMA=1 makes it
+// the default of an A/B build).
 #ifndef ORBFE_BLUR_MFMA
 #define ORBFE_BLUR_MFMA 0
 #endif
 void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const BlurMfmaParams& mf,
                        int n_images, hipStream_t s) {
-#if ORBFE_BLUR_MFMA
-  if (mf.n_strips > 0) {
+  if ((ORBFE_BLUR_MFMA || mf.use) && mf.n_strips > 0) {
     hipLaunchKernelGGL(gauss_blur7_mfma_kernel, dim3((mf.n_strips + 3) / 4, n_images), dim3(256), 0, s, src, dst, mf);
     return;
   }
-#endif
   dim3 block(256), grid(n_tiles, n_images);
   hipLaunchKernelGGL(gauss_blur7_kernel, grid, block, 0, s, src, dst, tiles, n_tiles);
 }

@@ -128,6 +128,7 @@ struct orbfe_extractor {
   std::vector<uint8_t> blur_tab;       // its band matrices as MFMA operands (1 KB each)
   uint32_t blur_b_off[ORBFE_MAX_LEVELS]{}, blur_t_off = 0;
   bool blur_mfma = false;              // every coefficient fits int8, no level under eight pixels wide or high
+  int blur_kind = 0;                   // 0: gauss_blur7_kernel (LDS), 1: gauss_blur7_mfma_kernel (orbfe_debug_blur_kernel)
   OctLevel oct[ORBFE_MAX_LEVELS]{};
   int total_cells = 0;
   size_t slots_per_image = 0, gkeys_per_image = 0;
@@ -656,6 +657,7 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     mf.tab = (const uint8_t*)e->d_blur_tab.p;
     memcpy(mf.b_off, e->blur_b_off, sizeof(mf.b_off));
     mf.t_off = e->blur_t_off;
+    mf.use = e->blur_kind;
     orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), mf, n_images, s);
   }
   {
@@ -1116,6 +1118,20 @@ extern "C" int orbfe_debug_candidates(orbfe_extractor* e, int image, int level, 
   }
   *n = total;
   return total > cap ? ORBFE_ERR_CAPACITY : ORBFE_OK;
+}
+
+// 0: the LDS blur kernel (default), 1: the matrix-core one (DESIGN lesson 31) -- same bytes, for the parity test and A/B timing.
+// A captured launch graph bakes the choice in: it is dropped here.
+extern "C" int orbfe_debug_blur_kernel(orbfe_extractor* e, int kind) {
+  if (!e || (kind != 0 && kind != 1)) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (kind != e->blur_kind)
+    for (auto& g : e->graphs) {
+      if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+      g.warm = 0; g.buffers = 0;
+    }
+  e->blur_kind = kind;
+  return ORBFE_OK;
 }
 
 extern "C" int orbfe_debug_blurred(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride) {

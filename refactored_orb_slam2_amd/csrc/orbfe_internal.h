@@ -116,6 +116,7 @@ struct BlurMfmaParams {
   const uint8_t* tab;
   uint32_t b_off[ORBFE_MAX_LEVELS];   // horizontal matrices of a level: entry (chunk * 3 + column group)
   uint32_t t_off;                     // the two vertical matrices (row groups 0, 1 of a window)
+  int use;                            // the handle asked for this kernel (orbfe_debug_blur_kernel)
 };
 
 // launchers (extract_kernels.hip)

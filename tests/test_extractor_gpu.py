@@ -422,6 +422,42 @@ def test_prepare_moves_the_first_call_cost_out_of_the_first_frame():
     assert L.orbfe_extractor_prepare(None, w, h, 1) == -1 and L.orbfe_extractor_prepare(cold._h, 0, h, 1) == -1
 
 
+@pytest.mark.parametrize("geom", ["kitti", "tum", "odd"])
+def test_blur_on_the_matrix_cores_is_byte_equal(geom):
+    """gauss_blur7_mfma_kernel (the 7-tap passes as v_mfma_i32_16x16x64_i8 band-matrix products, REFLECT_101 folded into the edge
+    matrices / the row fetch; DESIGN lesson 31) against the LDS kernel and the oracle: every blurred plane, every keypoint and
+    descriptor.  `odd`: a size whose levels end inside a strip / a window and whose smallest level is 8 pixels high."""
+    w, h, nf, nl = {"kitti": (1241, 376, 2000, 8), "tum": (640, 480, 1000, 8), "odd": (333, 67, 300, 12)}[geom]
+    imgs = synth.sequence(w, h, 2, seq=23)
+    a = ORBextractor(nf, 1.2, nl, 20, 7)
+    b = ORBextractor(nf, 1.2, nl, 20, 7)
+    assert b._L.orbfe_debug_blur_kernel(b._h, 1) == 0
+    ra, rb = a.extract_batch(imgs), b.extract_batch(imgs)
+    for (ka, da), (kb, db) in zip(ra, rb):
+        np.testing.assert_array_equal(ka, kb)
+        np.testing.assert_array_equal(da, db)
+    orc = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+    ok, od = orc(imgs[1])
+    np.testing.assert_array_equal(rb[1][0], ok); np.testing.assert_array_equal(rb[1][1], od)
+    for lvl in range(nl):
+        lw, lh = b.level_size(lvl, w, h)
+        if lw < 8 or lh < 8:
+            continue
+        np.testing.assert_array_equal(b.debug_blurred(1, lvl), a.debug_blurred(1, lvl), err_msg=f"blurred level {lvl}")
+        ob = orc.level_blurred(lvl)          # None: the reference skips the blur of a level without keypoints
+        if ob is not None:
+            np.testing.assert_array_equal(b.debug_blurred(1, lvl), ob, err_msg=f"blurred level {lvl} vs oracle")
+    # the one-image latency path (captured launch graph) with the other kernel, and back
+    for _ in range(4):
+        k1, d1 = b(imgs[0])
+    np.testing.assert_array_equal(k1, ra[0][0]); np.testing.assert_array_equal(d1, ra[0][1])
+    assert b._L.orbfe_debug_blur_kernel(b._h, 0) == 0
+    k2, d2 = b(imgs[0])
+    np.testing.assert_array_equal(k2, ra[0][0]); np.testing.assert_array_equal(d2, ra[0][1])
+    assert b._L.orbfe_debug_blur_kernel(b._h, 2) == -1
+    a.close(); b.close()
+
+
 def test_replayed_launch_graph_keeps_the_host_state_current():
     """A one-image host call is replayed from a captured hipGraph from its third use on (extractor.cpp): the launches' host-side
     bookkeeping does not run then.  The number of images of the last call guards orbfe_debug_* / orbfe_pyramid_level / the stereo
