@@ -12,7 +12,10 @@ import json
 import os
 import sys
 
-WIDE = ("copy_level0", "pyr_resize", "fast_cells", "fast_groups", "orient_describe")   # 16-byte-per-lane streaming reads
+# 16-byte-per-lane STREAMING reads (a wave's load = whole 128-byte lines).  orient_describe also loads 16 bytes per lane, but as a
+# gather of 48- / 64-byte row pieces: its requests are 64 bytes and FETCH_SIZE counts them as such (TCC_MISS x 128 B = 0.91 GB per
+# launch agrees with the uncorrected 0.78 GB, not with twice that)
+WIDE = ("copy_level0", "pyr_resize", "fast_cells", "fast_groups")
 ALG_KB = {  # algorithmic KB per 256-image launch at KITTI geometry
     "copy_level0": 2 * 466616 * 256 / 1024,
     "pyr_resize": ((1444097 - 36330) + (1444097 - 466616)) * 256 / 1024 / 7,
