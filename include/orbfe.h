@@ -156,8 +156,9 @@ int orbfe_device_status(orbfe_extractor* e);
 int orbfe_debug_candidates(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y, int32_t* score,
                            int cap, int* n);
 int orbfe_debug_blurred(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride);
-/* Which kernel blurs the levels from the next call on: 0 = the LDS kernel (default), 1 = the matrix-core kernel
- * (v_mfma_i32_16x16x64_i8 band products; same bytes, measured no faster: DESIGN.md lesson 31).  For parity tests and A/B timing. */
+/* How pyramid and blur run from the next call on: 0 = the fused level chain (default: launch l blurs level l and writes level
+ * l + 1 from the same staged windows), 1 = resize chain + the matrix-core blur (v_mfma_i32_16x16x64_i8 band products; DESIGN.md
+ * lesson 31), 2 = resize chain + one LDS blur launch over all levels (rounds 1-4).  Same bytes; for parity tests and A/B timing. */
 int orbfe_debug_blur_kernel(orbfe_extractor* e, int kind);
 int orbfe_debug_pyramid(orbfe_extractor* e, int image, int level, uint8_t* dst, int dst_stride);
 int orbfe_debug_level_keypoints(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y,

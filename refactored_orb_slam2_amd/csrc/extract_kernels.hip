@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       }
       const int nsc = ((th + 2) * SCP + 15) >> 4;
       for (int i = lane; i < nsc; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
-      for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
+      // (the bitmap is cleared where a cell first needs it: when its list is recycled)
     }
     FC_T(1);   // LDS staging + clears
 
@@ -650,6 +650,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
     // (wave-uniform) repeats them at min_th from the tile that is still staged.
     uint32_t keep[2] = {0u, 0u};
     int total = 0;
+    bool was_flushed = false;
     for (int pass = 0; pass < 2; pass++) {
       const int th_cur = pass ? min_th : ini_th;
       const uint32_t C = (uint32_t)(0x8000 - th_cur - 1) * 0x00010001u;
@@ -713,16 +714,20 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
           const uint32_t dark = AD - lo, brt = hi + AB;
           const uint32_t G = act ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
           const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
+          // the list stays in row-major order (lanes ascend along a row, then down the rows; a lane's two pixels are neighbours):
+          // the NMS below emits straight from it
           const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
-          const int n0 = __popcll(m0);
-          const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
-          const int i1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)(wcnt + n0)));
+          const int c0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
+          const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)c0));
+          const int i1 = i0 + (has0 ? 1 : 0);
           const uint32_t e = a0 + ec;
           if (has0) list[i0] = (uint16_t)((G & 0xC000u) | e);
           if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (e + 1));
-          wcnt += n0 + __popcll(m1);
+          wcnt += __popcll(m0) + __popcll(m1);
           if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
             FC_T(2);
+            if (!flushed)
+              for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
             flushed = true;
             score_list(wcnt, true, th_cur);
             FC_T(3);
@@ -736,26 +741,29 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
 
       // ---- B: strict 3x3 NMS inside the cell.
       if (!flushed) {
-        // lane = survivor: the list still holds every scored pixel of the cell.  Nine reads in flight together; the kept
-        // pixels are collected in the (so far empty) bitmap so that the emission below can walk them in row-major order
-        for (int i = lane; i < wcnt; i += WAVE) {
+        // lane = survivor: the list still holds every scored pixel of the cell, in row-major order -- the order the reference's
+        // keypoints of a cell come in -- so a kept pixel goes straight to its output slot: rank = kept pixels in front of it.
+        // Nine reads in flight together.  (Pass 0 of a cell that keeps nothing writes nothing.)
+        uint32_t* slot = slots + (size_t)img * slots_per_image + cd.slot_off;
+        int emitted = 0;
+        for (int base = 0; base < wcnt; base += WAVE) {
+          const int i = min(base + lane, wcnt - 1);
           const uint32_t en = list[i];
           const int e = (int)(en & 0x3fffu);
           const int y = PB == 64 ? (e >> 6) : (int)((e + 0.5f) * (1.0f / PB));
           const int x = e - y * PB;
-          if (x >= c_hi) continue;
           const int ty = y - 3, tx = x - c_lo;
-          const uint8_t* s = sc + (ty + 1) * SCP + tx + 1;
+          const uint8_t* s = sc + (ty + 1) * SCP + min(tx, tw - 1) + 1;
           const int v = s[0];
           const int n0 = s[-SCP - 1], n1 = s[-SCP], n2 = s[-SCP + 1], n3 = s[-1], n4 = s[1], n5 = s[SCP - 1], n6 = s[SCP], n7 = s[SCP + 1];
-          const bool kp = (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);   // v = 0: not scored
-          if (kp) {
-            const int p = (ty << bsh) + tx;
-            atomicOr(&scb[p >> 5], 1u << (p & 31));
-          }
+          const bool kp = (base + lane < wcnt) & (x < c_hi) & (v > n0) & (v > n1) & (v > n2) & (v > n3) & (v > n4) & (v > n5) & (v > n6) & (v > n7);   // v = 0: not scored
+          const unsigned long long mk = __ballot(kp);
+          const int off = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, (uint32_t)emitted));
+          const uint32_t rx = (uint32_t)(tx + 3 + cd.x0 - ORBFE_EDGE), ry = (uint32_t)(ty + 3 + cd.y0 - ORBFE_EDGE);
+          if (kp && off < cd.slot_cap) slot[off] = rx | (ry << 12) | ((uint32_t)v << 24);
+          emitted += __popcll(mk);
         }
-#pragma unroll
-        for (int h = 0; h < 2; h++) keep[h] = (lane + WAVE * h) < nbw ? scb[lane + WAVE * h] : 0u;
+        total = emitted;
       } else {
         // the list was recycled (more than 256 quick-test survivors in one cell): lane l walks the bits of words l and l + 64
         // of the bitmap of scored pixels
@@ -777,20 +785,24 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
             if (kp) keep[h] |= 1u << b;
           }
         }
+        total = __popcll(__ballot(keep[0] != 0u || keep[1] != 0u));   // > 0 <=> the cell keeps a pixel
       }
-      FC_T(4);   // NMS
-      total = __popcll(__ballot(keep[0] != 0u || keep[1] != 0u));   // > 0 <=> the cell keeps a pixel
+      was_flushed = flushed;
+      FC_T(4);   // NMS (and, for a cell whose list was never recycled, emission)
       if (total != 0 || pass == 1) break;
-      // nothing at ini_th: start over at min_th (score plane and bitmap may hold pass 0's plateau pixels)
+      // nothing at ini_th: start over at min_th (the score plane may hold pass 0's plateau pixels; a recycled list's bitmap is
+      // cleared again when pass 1 recycles)
       {
         const int nsc = ((th + 2) * SCP + 15) >> 4;
         for (int i = lane; i < nsc; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
-        for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
       }
     }
 
-    // ---- C: row-major emission from registers (one wave scan per bitmap half gives the output offsets)
-    {
+    // ---- C: (recycled lists only) row-major emission from registers (one wave scan per bitmap half gives the output offsets)
+    if (!was_flushed) {
+      if (lane == 0) cell_cnt[(size_t)img * total_cells + g.first_cell + k] = total < cd.slot_cap ? total : cd.slot_cap;
+      FC_T(5);
+    } else {
       const int pk = __popc(keep[0]) | (__popc(keep[1]) << 16);   // both halves in one packed wave scan
       const int in = wave_incl_scan(pk);
       const int tot = __builtin_amdgcn_readlane(in, WAVE - 1);
@@ -1184,7 +1196,17 @@ __device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {
                                 // (58 filled both passes exactly; 56 measured 2-3 % faster: its rows end on storage-tile boundaries)
 #define BT_INP 80   // LDS pitch (bytes) of the input window: column j <-> level x = ox - 4 + j
 #define BT_HP 68    // LDS pitch (dwords) of one row PAIR of the horizontal-pass result (two u16 rows interleaved)
-__global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles) {
+// RESIZE: the tile also produces its part of level + 1 (cv::resize INTER_LINEAR, the arithmetic of pyr_resize_dot_kernel) from
+// the window it has staged for the blur: the pyramid chain and the blur then read every level ONCE, and the seven resize
+// launches of a pyramid disappear (launch l = blur of level l + resize l -> l + 1; the last level's launch only blurs).  A
+// destination dword (four pixels) belongs to the tile that holds the first source column of its first pixel, a destination row
+// to the tile that holds its upper source row (BlurTile::j0 .. r1, from the plan): every tap of an owned dword-row then lies
+// inside the window -- staged one dword wider (19 instead of 18) than the blur alone needs --, nothing is computed twice and no
+// halo is added.  Thread = (dword column, three consecutive destination rows); its taps are requested before the window's
+// pixels, so they have arrived when the barrier behind the staging opens.
+template <bool RESIZE>
+__global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
+                                                         LevelResize rz) {
   __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
   __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
   const int tid = threadIdx.x;
@@ -1197,17 +1219,28 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
   const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
+  // the resize taps of this thread: dword column J (pixels 4J .. 4J + 3), rows Y0 .. Y0 + 2
+  const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1)), Y0 = t.r0 + (tid >> 4) * ORBFE_FUSE_ROWS;
+  uint2 txr[4], tyr[ORBFE_FUSE_ROWS];
+  if constexpr (RESIZE) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) txr[i] = reinterpret_cast<const uint2*>(rz.xt)[min(4 * J + i, rz.dw - 1)];
+#pragma unroll
+    for (int k = 0; k < ORBFE_FUSE_ROWS; k++) tyr[k] = reinterpret_cast<const uint2*>(rz.yt)[min(Y0 + k, rz.dh - 1)];
+  }
   {
-    // (BT_H+6) rows x 18 dwords (x = ox-4 .. ox+67).  Thread -> dword column c = tid % 18 and rows r0 + 14 k (one division;
-    // 252 of 256 threads), all loads issued before the first LDS store.  Interior tiles (the common case, wave-uniform) load
-    // plain aligned dwords; on edge tiles a dword that straddles the image border (left edge, the partial dword at the right
-    // edge, columns beyond it) is assembled from bytes with REFLECT_101 indexing, and rows reflect as a whole.
+    // (BT_H+6) rows x NC dwords (x = ox-4 .. ox+67, or .. ox+71 with the resize).  Thread -> dword column c = tid % NC and rows
+    // r0 + RPP k (one division; 252 / 247 of 256 threads), all loads issued before the first LDS store.  Interior tiles (the
+    // common case, wave-uniform) load plain aligned dwords; on edge tiles a dword that straddles the image border (left edge, the
+    // partial dword at the right edge, columns beyond it) is assembled from bytes with REFLECT_101 indexing, and rows reflect as a
+    // whole.
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
-    constexpr int RPP = 14, NLD = (BT_H + 6 + RPP - 1) / RPP;
-    const int r0 = tid / 18, c = tid - r0 * 18;
+    constexpr int NC = RESIZE ? 19 : 18;
+    constexpr int RPP = 256 / NC, NLD = (BT_H + 6 + RPP - 1) / RPP;
+    const int r0 = tid / NC, c = tid - r0 * NC;
     const int x = ox - 4 + 4 * c;
     uint32_t v[NLD];
-    const bool interior = oy >= 3 && oy + BT_H + 3 <= h && ox >= 4 && ox + BT_W + 4 <= w;
+    const bool interior = oy >= 3 && oy + BT_H + 3 <= h && ox >= 4 && ox - 4 + 4 * NC <= w;
     if (r0 < RPP) {
       if (interior) {
         const uint8_t* p0 = S + (size_t)(oy - 3 + r0) * pitch + x;
@@ -1238,6 +1271,55 @@ __global__ __launch_bounds__(256) void gauss_blur7_kernel(PyrView src, PyrView d
     }
   }
   __syncthreads();
+  if constexpr (RESIZE) {
+    // level + 1: the destination dword J of rows Y0 .. Y0 + 2.  Per source row three aligned LDS dwords, two v_alignbyte to start
+    // the 8-byte window at the first pixel's source column, per pixel one v_perm (bytes s0, s0 + 1 into 16-bit fields) + one
+    // v_dot2_u32_u16 against (c0, c1); (b * (t >> 4)) >> 16 == mul_hi_u24(b << 12, t & ~15).  Rows differ between the lanes of a
+    // wave here, so the horizontal result of a source row is not carried over to the next destination row (a divergent test).
+    typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+    if (J < t.j1 && Y0 < t.r1) {
+      const int s00 = (int)(int16_t)(txr[0].x & 0xffff);
+      const int base = s00 - (ox - 4);   // >= 4: the dword's first source column lies in this tile column
+      const uint32_t sh = (uint32_t)base & 3u;
+      uint32_t sel[4], cp[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t o = (uint32_t)((int)(int16_t)(txr[i].x & 0xffff) - s00);   // 0 .. 6
+        sel[i] = o | 0x0c000c00u | ((o + 1) << 16);
+        cp[i] = txr[i].y;                                                         // c0 | c1 << 16
+      }
+      const uint32_t* trow = reinterpret_cast<const uint32_t*>(in + (base & ~3));
+      auto hrow = [&](int r, uint32_t (&hh)[4]) {
+        const uint32_t* p = trow + r * (BT_INP / 4);
+        const uint32_t* p2 = p + 2;
+        asm("" : "+v"(p2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow)
+        const uint32_t w0 = p[0], w1 = p[1], w2 = *p2;
+        const uint32_t W0 = __builtin_amdgcn_alignbyte(w1, w0, sh), W1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t u = __builtin_amdgcn_perm(W1, W0, sel[i]);
+          hh[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, u), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
+        }
+      };
+      uint8_t* N = rz.dst + (size_t)blockIdx.y * rz.dimg + 4 * J;
+#pragma unroll
+      for (int k = 0; k < ORBFE_FUSE_ROWS; k++) {
+        const int y = Y0 + k;
+        if (y < t.r1) {
+          const int ra = (int)(int16_t)(tyr[k].x & 0xffff) - (oy - 3), rb = (int)(int16_t)(tyr[k].x >> 16) - (oy - 3);
+          uint32_t h0[4], h1[4];
+          hrow(ra, h0);
+          hrow(rb, h1);
+          const uint32_t B0 = (tyr[k].y & 0xffffu) << 12, B1 = (tyr[k].y >> 16) << 12;
+          uint32_t sm[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) sm[i] = mulhi_u24(B0, h0[i]) + mulhi_u24(B1, h1[i]) + 2u;
+          const uint32_t P01 = (sm[0] | (sm[1] << 16)) >> 2, P23 = (sm[2] | (sm[3] << 16)) >> 2;   // values <= 255 in bytes 0 and 2
+          *reinterpret_cast<uint32_t*>(N + (size_t)y * rz.dpitch) = __builtin_amdgcn_perm(P23, P01, 0x06040200u);
+        }
+      }
+    }
+  }
   // horizontal pass: item = (row pair k, 4-pixel group g).  Output x = 4g+i needs window columns 4g+i+1 .. 4g+i+7:
   // two byte windows cut with v_alignbyte and two v_dot4_u32_u8 against the packed taps.  The two rows of a pair
   // are stored interleaved (even row in the low half) so the vertical pass can use v_dot2_u32_u16.
@@ -1868,8 +1950,15 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
     hipLaunchKernelGGL(gauss_blur7_mfma_kernel, dim3((mf.n_strips + 3) / 4, n_images), dim3(256), 0, s, src, dst, mf);
     return;
   }
+  orbfe_launch_blur_level(src, dst, tiles, n_tiles, nullptr, n_images, s);
+}
+
+void orbfe_launch_blur_level(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const LevelResize* rz,
+                             int n_images, hipStream_t s) {
+  if (n_tiles <= 0) return;
   dim3 block(256), grid(n_tiles, n_images);
-  hipLaunchKernelGGL(gauss_blur7_kernel, grid, block, 0, s, src, dst, tiles, n_tiles);
+  if (rz) hipLaunchKernelGGL(blur_level_kernel<true>, grid, block, 0, s, src, dst, tiles, n_tiles, *rz);
+  else hipLaunchKernelGGL(blur_level_kernel<false>, grid, block, 0, s, src, dst, tiles, n_tiles, LevelResize{});
 }
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {

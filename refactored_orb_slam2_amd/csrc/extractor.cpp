@@ -124,11 +124,15 @@ struct orbfe_extractor {
   std::vector<FastGroup> groups;   // runs of adjacent cells, one workgroup each
   int fc_rows = 0, fc_span = 0, fc_sc = 0, fc_bits = 0;   // wave-per-cell FAST: largest cell ROI rows, (x0 & 15) + 1 + cols, score plane bytes
   std::vector<BlurTile> tiles;
+  int tile_first[ORBFE_MAX_LEVELS]{}, tile_count[ORBFE_MAX_LEVELS]{};   // a level's tiles are consecutive in `tiles`
+  bool fuse_ok[ORBFE_MAX_LEVELS]{};    // [l]: the step l -> l + 1 can run inside level l's blur tiles (blur_level_kernel<true>)
   std::vector<BlurStrip> strips;       // gauss_blur7_mfma: one wave per (level, 48-column chunk)
   std::vector<uint8_t> blur_tab;       // its band matrices as MFMA operands (1 KB each)
   uint32_t blur_b_off[ORBFE_MAX_LEVELS]{}, blur_t_off = 0;
   bool blur_mfma = false;              // every coefficient fits int8, no level under eight pixels wide or high
-  int blur_kind = 0;                   // 0: gauss_blur7_kernel (LDS), 1: gauss_blur7_mfma_kernel (orbfe_debug_blur_kernel)
+  int blur_kind = 0;                   // orbfe_debug_blur_kernel: 0 = blur_level_kernel, level l's blur and the resize l -> l + 1 from one staged
+                                       // window, one launch per level; 1 = resize chain + gauss_blur7_mfma_kernel; 2 = resize chain + one
+                                       // blur_level_kernel<false> launch over all levels (the pipeline of rounds 1-4)
   OctLevel oct[ORBFE_MAX_LEVELS]{};
   int total_cells = 0;
   size_t slots_per_image = 0, gkeys_per_image = 0;
@@ -402,9 +406,82 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     o.key_off = key_off;
     o.key_cap = (int)std::min<size_t>(level_slots, 0xFFFFFF);
     key_off += level_slots;
-    // blur tiles
-    for (int ty = 0; ty < (g.h + ORBFE_BLUR_TILE_H - 1) / ORBFE_BLUR_TILE_H; ty++)
-      for (int tx = 0; tx < (g.w + 63) / 64; tx++) e->tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
+  }
+  // resize coefficient tables of every step l - 1 -> l, and which kernel can run it
+  std::vector<ResizeTap> hxt[ORBFE_MAX_LEVELS], hyt[ORBFE_MAX_LEVELS];
+  for (int l = 1; l < nl; l++) {
+    std::vector<ResizeTap>&xt = hxt[l], &yt = hyt[l];
+    build_taps(e->lg[l - 1].w, e->lg[l].w, true, xt);
+    build_taps(e->lg[l - 1].h, e->lg[l].h, false, yt);
+    // does the source window of every 256 x 16 destination tile fit the staged 34 rows x 560 bytes?
+    bool ok = true;
+    for (int x0 = 0; x0 < (int)xt.size() && ok; x0 += 256) {
+      const int xl = std::min<int>(x0 + 255, (int)xt.size() - 1);
+      const int sxa = xt[x0].s0 & ~15;
+      if ((((xt[xl].s1 - sxa) >> 4) + 1) * 16 > 560) ok = false;
+    }
+    for (int y0 = 0; y0 < (int)yt.size() && ok; y0 += 16) {  // 256 x 16 tiles of the 4-rows-per-thread kernel: 34 rows
+      const int yl = std::min<int>(y0 + 15, (int)yt.size() - 1);
+      if (yt[yl].s1 - yt[y0].s0 + 1 > 34) ok = false;
+    }
+    bool win8 = ok;
+    for (int y0 = 0; y0 < (int)yt.size() && win8; y0 += 32) {  // 256 x 32 tiles of pyr_resize_dot_kernel<32, 42>
+      const int yl = std::min<int>(y0 + 31, (int)yt.size() - 1);
+      if (yt[yl].s1 - yt[y0].s0 + 1 > 42) win8 = false;
+    }
+    for (int x4 = 0; x4 < (int)xt.size() && win8; x4 += 4) {
+      const int xe = std::min<int>(x4 + 3, (int)xt.size() - 1);
+      if (xt[xe].s0 + 1 - xt[x4].s0 > 7) win8 = false;
+      for (int i = x4; i <= xe; i++)
+        if (xt[i].c1 != 0 && xt[i].s1 != xt[i].s0 + 1) win8 = false;
+    }
+    e->resize_mode[l] = win8 ? 2 : ok ? 1 : 0;
+  }
+  // blur tiles, and the part of level l + 1 each tile of level l owns when the resize step is fused into the blur: destination
+  // dword j (pixels 4j .. 4j + 3) belongs to the tile column that holds the first source column of pixel 4j, destination row y
+  // to the tile row that holds its upper source row.  Source indices ascend with the destination index, so a tile owns a
+  // contiguous block; the step is fused only if every block fits the kernel's thread layout (16 dwords x 48 rows) and every tap
+  // of an owned dword lies inside the staged window (columns ox - 4 .. ox + 71, rows oy - 3 .. oy + 58).
+  for (int l = 0; l < nl; l++) {
+    const LevelGeom& g = e->lg[l];
+    const int tiles_x = (g.w + 63) / 64, tiles_y = (g.h + ORBFE_BLUR_TILE_H - 1) / ORBFE_BLUR_TILE_H;
+    std::vector<int> jx(tiles_x + 1, 0), ry(tiles_y + 1, 0);
+    bool fuse = l + 1 < nl && e->resize_mode[l + 1] == 2;
+    if (fuse) {
+      const std::vector<ResizeTap>&xt = hxt[l + 1], &yt = hyt[l + 1];
+      const int dw = (int)xt.size(), dh = (int)yt.size(), ndw = (dw + 3) / 4;
+      for (int tx = 0, j = 0; tx <= tiles_x; tx++) {
+        while (j < ndw && xt[4 * j].s0 < 64 * tx) j++;
+        jx[tx] = tx == tiles_x ? ndw : j;
+      }
+      for (int ty = 0, y = 0; ty <= tiles_y; ty++) {
+        while (y < dh && yt[y].s0 < ORBFE_BLUR_TILE_H * ty) y++;
+        ry[ty] = ty == tiles_y ? dh : y;
+      }
+      for (int tx = 0; tx < tiles_x && fuse; tx++) {
+        if (jx[tx + 1] - jx[tx] > ORBFE_FUSE_DWORDS) fuse = false;
+        for (int j = jx[tx]; j < jx[tx + 1] && fuse; j++) {
+          const int xe = std::min(4 * j + 3, dw - 1);
+          if (xt[4 * j].s0 < 64 * tx || xt[xe].s0 + 1 > 64 * tx + 71) fuse = false;
+        }
+      }
+      for (int ty = 0; ty < tiles_y && fuse; ty++) {
+        if (ry[ty + 1] - ry[ty] > 16 * ORBFE_FUSE_ROWS) fuse = false;
+        for (int y = ry[ty]; y < ry[ty + 1] && fuse; y++)
+          if (yt[y].s0 < ORBFE_BLUR_TILE_H * ty || yt[y].s1 > ORBFE_BLUR_TILE_H * ty + ORBFE_BLUR_TILE_H + 2) fuse = false;
+      }
+    }
+    e->fuse_ok[l] = fuse;
+    e->tile_first[l] = (int)e->tiles.size();
+    for (int ty = 0; ty < tiles_y; ty++)
+      for (int tx = 0; tx < tiles_x; tx++) {
+        BlurTile bt;
+        memset(&bt, 0, sizeof(bt));
+        bt.level = (int16_t)l; bt.tx = (int16_t)tx; bt.ty = (int16_t)ty;
+        if (fuse) { bt.j0 = (int16_t)jx[tx]; bt.j1 = (int16_t)jx[tx + 1]; bt.r0 = (int16_t)ry[ty]; bt.r1 = (int16_t)ry[ty + 1]; }
+        e->tiles.push_back(bt);
+      }
+    e->tile_count[l] = (int)e->tiles.size() - e->tile_first[l];
   }
   e->blur_mfma = build_blur_tables(e);
   e->total_cells = (int)e->cells.size();
@@ -456,35 +533,8 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
   if ((rc = upload(e->d_strips, e->strips.data(), e->strips.size() * sizeof(BlurStrip), e->stream))) return rc;
   if ((rc = upload(e->d_blur_tab, e->blur_tab.data(), e->blur_tab.size(), e->stream))) return rc;
   for (int l = 1; l < nl; l++) {
-    std::vector<ResizeTap> xt, yt;
-    build_taps(e->lg[l - 1].w, e->lg[l].w, true, xt);
-    build_taps(e->lg[l - 1].h, e->lg[l].h, false, yt);
-    // does the source window of every 256 x 16 destination tile fit the staged 34 rows x 560 bytes?
-    bool ok = true;
-    for (int x0 = 0; x0 < (int)xt.size() && ok; x0 += 256) {
-      const int xl = std::min<int>(x0 + 255, (int)xt.size() - 1);
-      const int sxa = xt[x0].s0 & ~15;
-      if ((((xt[xl].s1 - sxa) >> 4) + 1) * 16 > 560) ok = false;
-    }
-    for (int y0 = 0; y0 < (int)yt.size() && ok; y0 += 16) {  // 256 x 16 tiles of the 4-rows-per-thread kernel: 34 rows
-      const int yl = std::min<int>(y0 + 15, (int)yt.size() - 1);
-      if (yt[yl].s1 - yt[y0].s0 + 1 > 34) ok = false;
-    }
-    bool win8 = ok;
-    for (int y0 = 0; y0 < (int)yt.size() && win8; y0 += 32) {  // 256 x 32 tiles of pyr_resize_dot_kernel<32, 42>
-      const int yl = std::min<int>(y0 + 31, (int)yt.size() - 1);
-      if (yt[yl].s1 - yt[y0].s0 + 1 > 42) win8 = false;
-    }
-    for (int x4 = 0; x4 < (int)xt.size() && win8; x4 += 4) {
-      const int xe = std::min<int>(x4 + 3, (int)xt.size() - 1);
-      if (xt[xe].s0 + 1 - xt[x4].s0 > 7) win8 = false;
-      for (int i = x4; i <= xe; i++)
-        if (xt[i].c1 != 0 && xt[i].s1 != xt[i].s0 + 1) win8 = false;
-    }
-    e->resize_mode[l] = win8 ? 2 : ok ? 1 : 0;
-    if ((rc = upload(e->d_xt[l], xt.data(), xt.size() * sizeof(ResizeTap), e->stream))) return rc;
-    if ((rc = upload(e->d_yt[l], yt.data(), yt.size() * sizeof(ResizeTap), e->stream))) return rc;
-    HIPCHK(hipStreamSynchronize(e->stream));  // xt/yt go out of scope
+    if ((rc = upload(e->d_xt[l], hxt[l].data(), hxt[l].size() * sizeof(ResizeTap), e->stream))) return rc;
+    if ((rc = upload(e->d_yt[l], hyt[l].data(), hyt[l].size() * sizeof(ResizeTap), e->stream))) return rc;
   }
   HIPCHK(hipStreamSynchronize(e->stream));
   e->plan_w = w;
@@ -612,12 +662,35 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
   PyrView pv, bv;
   make_view(e, e->d_pyr, pv);
   make_view(e, e->d_blur, bv);
+  // Fused level chain (the default): launch l blurs level l and, from the same staged windows, writes level l + 1 -- every level
+  // is read once by the two stages together and the separate resize launches disappear; a step the fused kernel cannot run
+  // (scale factors outside its thread layout) falls back to resize + blur launches of its own.  orbfe_debug_blur_kernel(e, 1 | 2)
+  // keeps the old order: resize chain here, ONE blur launch over all levels behind the quadtree.
+  const bool fused = e->blur_kind == 0;
+  auto resize_step = [&](int l) {   // level l - 1 -> l
+    orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], pv.img_stride[l - 1], const_cast<uint8_t*>(pv.base[l]),
+                        pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
+                        (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_mode[l], s);
+  };
   {
     StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
-    for (int l = 1; l < nl; l++)
-      orbfe_launch_resize(pv.base[l - 1], pv.pitch[l - 1], pv.img_stride[l - 1], const_cast<uint8_t*>(pv.base[l]),
-                          pv.pitch[l], e->lg[l].plane, pv.w[l], pv.h[l], (const ResizeTap*)e->d_xt[l].p,
-                          (const ResizeTap*)e->d_yt[l].p, n_images, e->resize_mode[l], s);
+    for (int l = 0; l < nl; l++) {
+      const BlurTile* lt = (const BlurTile*)e->d_tiles.p + e->tile_first[l];
+      if (!fused) {
+        if (l + 1 < nl) resize_step(l + 1);
+      } else if (l + 1 < nl && e->fuse_ok[l]) {
+        LevelResize rz;
+        rz.dst = const_cast<uint8_t*>(pv.base[l + 1]);
+        rz.dimg = e->lg[l + 1].plane;
+        rz.dpitch = pv.pitch[l + 1]; rz.dw = pv.w[l + 1]; rz.dh = pv.h[l + 1];
+        rz.xt = (const ResizeTap*)e->d_xt[l + 1].p;
+        rz.yt = (const ResizeTap*)e->d_yt[l + 1].p;
+        orbfe_launch_blur_level(pv, bv, lt, e->tile_count[l], &rz, n_images, s);
+      } else {
+        if (l + 1 < nl) resize_step(l + 1);
+        orbfe_launch_blur_level(pv, bv, lt, e->tile_count[l], nullptr, n_images, s);
+      }
+    }
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_FAST);
@@ -650,15 +723,15 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
     orbfe_launch_octree(op, n_images, e->oct_lds, s);
   }
   {
-    StageTimer t(e, s, ORBFE_STAGE_BLUR);
+    StageTimer t(e, s, ORBFE_STAGE_BLUR);   // kept when the chain above has blurred already: the stage's event pairs stay one per batch
     BlurMfmaParams mf;
     mf.strips = (const BlurStrip*)e->d_strips.p;
     mf.n_strips = e->blur_mfma ? (int)e->strips.size() : 0;   // 0: the LDS kernel
     mf.tab = (const uint8_t*)e->d_blur_tab.p;
     memcpy(mf.b_off, e->blur_b_off, sizeof(mf.b_off));
     mf.t_off = e->blur_t_off;
-    mf.use = e->blur_kind;
-    orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), mf, n_images, s);
+    mf.use = e->blur_kind == 1;
+    if (!fused) orbfe_launch_blur(pv, bv, (const BlurTile*)e->d_tiles.p, (int)e->tiles.size(), mf, n_images, s);
   }
   {
     StageTimer t(e, s, ORBFE_STAGE_DESCRIBE);
@@ -1120,10 +1193,11 @@ extern "C" int orbfe_debug_candidates(orbfe_extractor* e, int image, int level, 
   return total > cap ? ORBFE_ERR_CAPACITY : ORBFE_OK;
 }
 
-// 0: the LDS blur kernel (default), 1: the matrix-core one (DESIGN lesson 31) -- same bytes, for the parity test and A/B timing.
+// 0: the fused level chain (default: blur of level l + resize l -> l + 1 per launch), 1: resize chain + the matrix-core blur (DESIGN
+// lesson 31), 2: resize chain + one LDS blur launch -- same bytes, for the parity tests and A/B timing.
 // A captured launch graph bakes the choice in: it is dropped here.
 extern "C" int orbfe_debug_blur_kernel(orbfe_extractor* e, int kind) {
-  if (!e || (kind != 0 && kind != 1)) return ORBFE_ERR_INVALID;
+  if (!e || kind < 0 || kind > 2) return ORBFE_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   if (kind != e->blur_kind)
     for (auto& g : e->graphs) {

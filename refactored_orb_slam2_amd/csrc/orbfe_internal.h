@@ -98,9 +98,23 @@ struct DescribeParams {
 };
 
 struct BlurTile {
-  int16_t level, tx, ty;  // tile origin = (tx*64, ty*32)
+  int16_t level, tx, ty;  // tile origin = (tx * 64, ty * ORBFE_BLUR_TILE_H)
+  // the part of level + 1 this tile produces when the resize step is fused into the blur (blur_level_kernel<true>): the
+  // destination dwords (four pixels) [j0, j1) whose first source column lies in this tile column, and the destination rows
+  // [r0, r1) whose upper source row lies in this tile row -- every destination dword-row has exactly one owner
+  int16_t j0, j1, r0, r1;
   int16_t pad;
 };
+// the level l -> l + 1 step of cv::resize as the blur tiles of level l see it
+struct LevelResize {
+  uint8_t* dst;               // level l + 1 of image 0
+  unsigned long long dimg;    // bytes between images
+  int dpitch, dw, dh;
+  const ResizeTap* xt;
+  const ResizeTap* yt;
+};
+#define ORBFE_FUSE_DWORDS 16     // destination dwords a tile may own per row (one lane each)
+#define ORBFE_FUSE_ROWS 3        // destination rows per thread: a tile may own 16 x 3 rows
 
 // gauss_blur7_mfma_kernel: one wave blurs a strip of 48 output columns over the whole height of a level.  The 7-tap passes are
 // band-matrix products on the matrix cores; the band matrices (REFLECT_101 folded into the edge ones) are precomputed per level
@@ -128,5 +142,8 @@ void orbfe_launch_fast_cells(const PyrView& pyr, const CellDesc* cells, const Fa
 void orbfe_launch_octree(const OctParams& p, int n_images, size_t lds_bytes, hipStream_t s);
 void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const BlurMfmaParams& mf,
                        int n_images, hipStream_t s);
+// blur of the levels the tiles name, plus -- rz != nullptr -- the resize step into the next level from the same staged windows
+void orbfe_launch_blur_level(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const LevelResize* rz,
+                             int n_images, hipStream_t s);
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s);
 size_t orbfe_octree_lds_bytes(int max_nodes, int lds_keys);

@@ -454,7 +454,43 @@ def test_blur_on_the_matrix_cores_is_byte_equal(geom):
     assert b._L.orbfe_debug_blur_kernel(b._h, 0) == 0
     k2, d2 = b(imgs[0])
     np.testing.assert_array_equal(k2, ra[0][0]); np.testing.assert_array_equal(d2, ra[0][1])
-    assert b._L.orbfe_debug_blur_kernel(b._h, 2) == -1
+    assert b._L.orbfe_debug_blur_kernel(b._h, 3) == -1
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("geom", ["kitti", "tum", "euroc", "odd", "sf15", "sf11", "tiny"])
+def test_fused_level_chain_equals_separate_launches(geom):
+    """blur_level_kernel<true> -- launch l blurs level l and writes level l + 1 from the same staged windows (cv::resize
+    INTER_LINEAR, L/src/ORBextractor.cc:1041-1065, and GaussianBlur, :1017-1019, reading each level once) -- against the
+    pipeline of rounds 1-4 (resize chain, then one blur launch: orbfe_debug_blur_kernel(e, 2)) and the oracle: every pyramid
+    plane, every blurred plane, keypoints and descriptors.  `sf11`: a scale factor whose tiles would own more destination rows
+    than the kernel's thread layout holds, so every step falls back to a resize and a blur launch of its own; `sf15`: a coarser
+    chain; `odd` / `tiny`: levels that end inside a tile, a smallest level of a few pixels."""
+    w, h, nf, sf, nl = {"kitti": (1241, 376, 2000, 1.2, 8), "tum": (640, 480, 1000, 1.2, 8), "euroc": (752, 480, 1200, 1.2, 8),
+                        "odd": (333, 67, 300, 1.2, 12), "sf15": (1241, 376, 1500, 1.5, 5), "sf11": (641, 377, 800, 1.1, 12),
+                        "tiny": (70, 61, 50, 1.2, 8)}[geom]
+    imgs = synth.sequence(w, h, 3, seq=29)
+    a = ORBextractor(nf, sf, nl, 20, 7)
+    b = ORBextractor(nf, sf, nl, 20, 7)
+    assert b._L.orbfe_debug_blur_kernel(b._h, 2) == 0
+    ra, rb = a.extract_batch(imgs), b.extract_batch(imgs)
+    for (ka, da), (kb, db) in zip(ra, rb):
+        np.testing.assert_array_equal(ka, kb)
+        np.testing.assert_array_equal(da, db)
+    orc = ol.OracleExtractor(nf, sf, nl, 20, 7)
+    ok, od = orc(imgs[2])
+    np.testing.assert_array_equal(ra[2][0], ok); np.testing.assert_array_equal(ra[2][1], od)
+    for lvl in range(nl):
+        np.testing.assert_array_equal(a.debug_pyramid(2, lvl), b.debug_pyramid(2, lvl), err_msg=f"pyramid level {lvl}")
+        np.testing.assert_array_equal(a.debug_pyramid(2, lvl), orc.level_pixels(lvl), err_msg=f"pyramid level {lvl} vs oracle")
+        np.testing.assert_array_equal(a.debug_blurred(2, lvl), b.debug_blurred(2, lvl), err_msg=f"blurred level {lvl}")
+        ob = orc.level_blurred(lvl)          # None: the reference skips the blur of a level without keypoints
+        if ob is not None:
+            np.testing.assert_array_equal(a.debug_blurred(2, lvl), ob, err_msg=f"blurred level {lvl} vs oracle")
+    # the one-image latency path (captured launch graph) runs the same chain
+    for _ in range(4):
+        k1, d1 = a(imgs[0])
+    np.testing.assert_array_equal(k1, rb[0][0]); np.testing.assert_array_equal(d1, rb[0][1])
     a.close(); b.close()
 
 

@@ -15,6 +15,8 @@ F = int(os.environ.get("F", "256")); W, H = 1241, 376
 dev = torch.device("cuda", 0)
 imgs = torch.from_numpy(np.stack([p for p in synth.sequence(W, H, F, seq=0)])).to(dev)
 ex = ORBextractor(2000, 1.2, 8, 20, 7, device=0)
+if os.environ.get("BLUR_KIND"):   # 0 fused level chain (default), 1 resize chain + matrix-core blur, 2 resize chain + one LDS blur launch
+    assert ex._L.orbfe_debug_blur_kernel(ex._h, int(os.environ["BLUR_KIND"])) == 0
 cap = ex.max_keypoints(W, H)
 k = torch.zeros((F, cap, 28), dtype=torch.uint8, device=dev); d = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev)
 n = torch.zeros(F, dtype=torch.int32, device=dev)
