@@ -651,6 +651,10 @@ static unsigned long long buffer_signature(const orbfe_extractor* e) {
   auto mix = [&h](unsigned long long v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
   for (const void* q : ptrs) mix((unsigned long long)(uintptr_t)q);
   for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { mix((unsigned long long)(uintptr_t)e->d_xt[l].p); mix((unsigned long long)(uintptr_t)e->d_yt[l].p); }
+  // a graph also bakes in the level-major layout (level l of image i at cap_images * off_l + i * plane_l) and the plan's geometry:
+  // buffers that come back at their old addresses after a reallocation must not revive it
+  mix((unsigned long long)e->cap_images); mix((unsigned long long)e->plan_w); mix((unsigned long long)e->plan_h);
+  mix((unsigned long long)e->blur_kind);
   return h | 1ull;
 }
 

@@ -61,14 +61,26 @@ class RcclGather:
         recv = mode == "all" or self.rank == 0
         out = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in (n, kps, desc)] if recv else None
         ptrs = [_lib.ptr(t) for t in out] if recv else [None, None, None]
+        # Ordering against torch: the collective runs on `stream`, or -- stream None -- on the handle's own non-blocking stream, which
+        # nothing orders behind the torch streams that produced n / kps / desc.  An explicit stream is the caller's to order (the
+        # tensors are marked as used on it, so the caching allocator does not hand them out while the collective is in flight); with
+        # the private stream the producers are waited for here and inputs and outputs are kept alive until sync().
+        if stream is None:
+            torch.cuda.current_stream(n.device).synchronize()
+            self._inflight = (n, kps, desc, out)
+        else:
+            for t in (n, kps, desc) + tuple(out or ()):
+                t.record_stream(stream)
         _lib.check(self._L.orbfe_gather_records(self._h, _lib.ptr(n), _lib.ptr(kps), _lib.ptr(desc), n.shape[0], kps.shape[1],
                                                 self.ALL if mode == "all" else self.ROOT, ptrs[0], ptrs[1], ptrs[2],
                                                 _lib.stream_handle(stream)), "orbfe_gather_records")
         return tuple(out) if recv else None
 
     def sync(self):
+        """Waits for the collectives issued on the handle's own stream (gather(..., stream=None)); call it before reading them."""
         from . import _lib
         _lib.check(self._L.orbfe_gather_sync(self._h), "orbfe_gather_sync")
+        self._inflight = None
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -184,16 +196,28 @@ def gather_records(n, kps, desc, group=None, mode: str = "all"):
     return tuple(out) if (mode == "all" or rank == 0) else None
 
 
-def unpack_records(n_all, kps_all, desc_all, n_frames: int):
-    """Drops the padding frames and returns per-frame (keypoints, descriptors) numpy views."""
+def unpack_records(n_all, kps_all, desc_all, n_frames: int, world: int = 1):
+    """Drops the padding frames and returns per-frame (keypoints, descriptors) numpy arrays in global frame order.
+
+    The gathered arrays hold `world` chunks of equal length (padded_chunk(n_frames, world) frames each, rank order); rank r's
+    chunk starts at row r * chunk and holds its shard_range(n_frames, r, world) frames followed by padding, so with
+    n_frames % world != 0 the rows behind the first short chunk are NOT at their global frame number."""
     import numpy as np
     from ._lib import KP_DTYPE
 
     n_np = n_all.cpu().numpy()
     k_np = kps_all.cpu().numpy()
     d_np = desc_all.cpu().numpy()
+    if world < 1 or n_np.shape[0] % world:
+        raise ValueError("the gathered arrays are not `world` equal chunks")
+    chunk = n_np.shape[0] // world
     res = []
-    for f in range(n_frames):
-        c = int(n_np[f])
-        res.append((k_np[f, :c].copy().view(KP_DTYPE).reshape(-1), d_np[f, :c].copy()))
+    for r in range(world):
+        b, e = shard_range(n_frames, r, world)
+        if e - b > chunk:
+            raise ValueError("chunk shorter than the rank's shard")
+        for f in range(b, e):
+            row = r * chunk + (f - b)
+            c = int(n_np[row])
+            res.append((k_np[row, :c].copy().view(KP_DTYPE).reshape(-1), d_np[row, :c].copy()))
     return res

@@ -323,7 +323,7 @@ def test_rccl_gather_self_check_world1():
             ag.launch(n, kps, desc)
             n_all, k_all, d_all = ag.result()
             torch.cuda.synchronize()
-            frames = sharding.unpack_records(n_all, k_all, d_all, F)
+            frames = sharding.unpack_records(n_all, k_all, d_all, F, 1)
             assert len(frames) == F
             for (k, d), (k0, d0) in zip(frames, single):
                 np.testing.assert_array_equal(k, k0)
@@ -357,7 +357,7 @@ def test_c_abi_record_gather_world1_and_comm_init_all():
 
     def check(res):
         torch.cuda.synchronize()
-        frames = sharding.unpack_records(*res, F)
+        frames = sharding.unpack_records(*res, F, 1)
         for (k, d), (k0, d0) in zip(frames, single):
             np.testing.assert_array_equal(k, k0)
             np.testing.assert_array_equal(d, d0)

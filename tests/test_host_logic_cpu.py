@@ -120,6 +120,12 @@ def _gather_worker(rank, world, port, n_frames, cap, tmp):
                 assert bool((k_all[g, :c] == f % 251).all()) and bool((d_all[g, :c] == (f * 3) % 253).all())
             for i in range(re_ - rb, chunk):
                 assert int(n_all[r * chunk + i]) == 0
+        # unpack_records walks the padded chunks: frame f's record whatever n_frames % world is
+        frames = sharding.unpack_records(n_all, k_all, d_all, n_frames, world)
+        assert len(frames) == n_frames
+        for f, (kk, dd) in enumerate(frames):
+            assert len(kk) == len(dd) == (f * 7) % cap
+            assert bool((kk.view(np.uint8) == f % 251).all()) and bool((dd == (f * 3) % 253).all())
         # gather to the root (ncclSend / Recv to rank 0): rank 0 holds the same records, the others nothing
         root = sharding.gather_records(n, kps, desc, mode="root")
         ag = sharding.AsyncGather(n, kps, desc, mode="root")
@@ -140,7 +146,7 @@ def _gather_worker(rank, world, port, n_frames, cap, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 9), (2, 8)])
+@pytest.mark.parametrize("world,n_frames", [(2, 9), (2, 8), (3, 10)])   # (3, 10): shards 4 + 3 + 3 in chunks of 4 -- rows shift behind the first short chunk
 def test_gather_records_gloo_world2(tmp_path, world, n_frames):
     port = _free_port()
     mp.spawn(_gather_worker, args=(world, port, n_frames, 40, str(tmp_path)), nprocs=world, join=True)
