@@ -310,6 +310,9 @@ def main():
     ap.add_argument("--content-steps", type=int, default=30, help="steps per image content of the content-sensitivity key (0 = skip)")
     ap.add_argument("--gather", choices=("all", "root"), default="all",
                     help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
+    ap.add_argument("--blur-kind", type=int, default=0, choices=(0, 1, 2),
+                    help="A/B of the level chain (orbfe_debug_blur_kernel): 0 fused level kernels (default), 1 resize chain + matrix-core blur, "
+                         "2 resize chain + one LDS blur launch (rounds 1-4)")
     ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
                     help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
     args = ap.parse_args()
@@ -366,6 +369,10 @@ def main():
     exL = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
     exR = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if STEREO else None
     extractors = [e for e in (exL, exR) if e is not None]
+    if args.blur_kind:
+        for e in extractors:
+            if e._L.orbfe_debug_blur_kernel(e._h, args.blur_kind) != 0:
+                raise SystemExit("orbfe_debug_blur_kernel refused the kind")
     mt = Matcher(local)
     import atexit
 
@@ -635,10 +642,11 @@ def main():
         P0, P7 = px[0][0] * px[0][1], px[-1][0] * px[-1][1]
         # algorithmic bytes per image and per kernel; one launch processes F images
         alg = {
-            "pyramid": (sumP - P7) + (sumP - P0),            # level chain (level 0 is the input itself)
+            # level chain: fused (launch l reads level l once, writes level l + 1 and the blurred level l), or the resize chain alone
+            "pyramid": (3 * sumP - P0) if args.blur_kind == 0 else (sumP - P7) + (sumP - P0),
             "fast": sumP + 8 * cand_per_img,
             "octree": 8 * cand_per_img + 4 * NFEAT,
-            "blur": 2 * sumP,
+            "blur": 0 if args.blur_kind == 0 else 2 * sumP,
             "describe": NFEAT * (749 + 512 + 60),
         }
         per_launch_ms = dict(stage_ms_all)   # untimed 3-step pass (every stage)

@@ -204,6 +204,11 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
   asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ uint32_t mulhi_u24_s(uint32_t a_uniform, uint32_t b) {   // first operand from a scalar register
+  uint32_t r;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b));
+  return r;
+}
 
 // Same tile, staging and arithmetic as pyr_resize_lds16_kernel, restated twice over:
 // (1) per-pixel work for the vector ALU:
@@ -221,15 +226,15 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
 struct ResizeGeom {
   int x0, y0, bz, sxa, ncols16, sy_first, nrows;
 };
-template <int TROWS, int SROWS>
+template <int TROWS, int SROWS, int COLS>   // COLS: bytes of a staged source row (RS_COLS for scale factors up to 2; 336 when every window fits 21 chunks)
 __global__ __launch_bounds__(256) void pyr_resize_dot_kernel(const uint8_t* __restrict__ src, int spitch,
                                                               unsigned long long simg, uint8_t* __restrict__ dst,
                                                               int dpitch, unsigned long long dimg, int dw, int dh,
                                                               const ResizeTap* __restrict__ xt,
                                                               const ResizeTap* __restrict__ yt, int tiles_x, int tiles_y,
                                                               int n_tiles) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[SROWS * RS_COLS + 16];
-  constexpr int NLD = (SROWS + 6) / 7;   // staging passes: at least 7 rows per pass (ncols16 <= 35)
+  __shared__ __attribute__((aligned(16))) uint8_t tile[SROWS * COLS + 16];
+  constexpr int NLD = (SROWS + 256 / (COLS / 16) - 1) / (256 / (COLS / 16));   // staging passes: at least 256 / (COLS / 16) rows per pass
   const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
   const int tid = wv * 64 + lane;
   auto geom = [&](int t) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void pyr_resize_dot_kernel(const uint8_t* __re
 #pragma unroll
       for (int k = 0; k < NLD; k++) {
         const int r = r0 + k * rpp;
-        if (r < g.nrows) *reinterpret_cast<uint4*>(tile + r * RS_COLS + 16 * c) = v[k];
+        if (r < g.nrows) *reinterpret_cast<uint4*>(tile + r * COLS + 16 * c) = v[k];
       }
     }
     __syncthreads();
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void pyr_resize_dot_kernel(const uint8_t* __re
       }
       const uint32_t* trow = reinterpret_cast<const uint32_t*>(tile + (base & ~3));
       auto hrow = [&](int r, uint32_t (&hh)[4]) {
-        const uint32_t* p = trow + r * (RS_COLS / 4);
+        const uint32_t* p = trow + r * (COLS / 4);
         const uint32_t* p2 = p + 2;
         asm("" : "+v"(p2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow)
         const uint32_t w0 = p[0], w1 = p[1], w2 = *p2;
@@ -1204,8 +1209,12 @@ __device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {
 // inside the window -- staged one dword wider (19 instead of 18) than the blur alone needs --, nothing is computed twice and no
 // halo is added.  Thread = (dword column, three consecutive destination rows); its taps are requested before the window's
 // pixels, so they have arrived when the barrier behind the staging opens.
+#ifndef BT_THREADS
+#define BT_THREADS 256   // threads per tile (128: eleven tiles per CU instead of eight, measured -6 % on the blur alone, +3 % fused)
+#endif
+#define BT_FUSE_ROWS (ORBFE_FUSE_ROWS * 256 / BT_THREADS)   // destination rows per thread of the fused resize (16 dword columns x BT_THREADS / 16 row groups)
 template <bool RESIZE>
-__global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
+__global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
                                                          LevelResize rz) {
   __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
   __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
@@ -1220,13 +1229,13 @@ __global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView ds
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
   // the resize taps of this thread: dword column J (pixels 4J .. 4J + 3), rows Y0 .. Y0 + 2
-  const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1)), Y0 = t.r0 + (tid >> 4) * ORBFE_FUSE_ROWS;
-  uint2 txr[4], tyr[ORBFE_FUSE_ROWS];
+  const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1)), Y0 = t.r0 + (tid >> 4) * BT_FUSE_ROWS;
+  uint2 txr[4], tyr[BT_FUSE_ROWS];
   if constexpr (RESIZE) {
 #pragma unroll
     for (int i = 0; i < 4; i++) txr[i] = reinterpret_cast<const uint2*>(rz.xt)[min(4 * J + i, rz.dw - 1)];
 #pragma unroll
-    for (int k = 0; k < ORBFE_FUSE_ROWS; k++) tyr[k] = reinterpret_cast<const uint2*>(rz.yt)[min(Y0 + k, rz.dh - 1)];
+    for (int k = 0; k < BT_FUSE_ROWS; k++) tyr[k] = reinterpret_cast<const uint2*>(rz.yt)[min(Y0 + k, rz.dh - 1)];
   }
   {
     // (BT_H+6) rows x NC dwords (x = ox-4 .. ox+67, or .. ox+71 with the resize).  Thread -> dword column c = tid % NC and rows
@@ -1236,7 +1245,7 @@ __global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView ds
     // whole.
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
     constexpr int NC = RESIZE ? 19 : 18;
-    constexpr int RPP = 256 / NC, NLD = (BT_H + 6 + RPP - 1) / RPP;
+    constexpr int RPP = BT_THREADS / NC, NLD = (BT_H + 6 + RPP - 1) / RPP;
     const int r0 = tid / NC, c = tid - r0 * NC;
     const int x = ox - 4 + 4 * c;
     uint32_t v[NLD];
@@ -1303,7 +1312,7 @@ __global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView ds
       };
       uint8_t* N = rz.dst + (size_t)blockIdx.y * rz.dimg + 4 * J;
 #pragma unroll
-      for (int k = 0; k < ORBFE_FUSE_ROWS; k++) {
+      for (int k = 0; k < BT_FUSE_ROWS; k++) {
         const int y = Y0 + k;
         if (y < t.r1) {
           const int ra = (int)(int16_t)(tyr[k].x & 0xffff) - (oy - 3), rb = (int)(int16_t)(tyr[k].x >> 16) - (oy - 3);
@@ -1323,7 +1332,7 @@ __global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView ds
   // horizontal pass: item = (row pair k, 4-pixel group g).  Output x = 4g+i needs window columns 4g+i+1 .. 4g+i+7:
   // two byte windows cut with v_alignbyte and two v_dot4_u32_u8 against the packed taps.  The two rows of a pair
   // are stored interleaved (even row in the low half) so the vertical pass can use v_dot2_u32_u16.
-  for (int it = tid; it < ((BT_H + 6) / 2) * 16; it += 256) {
+  for (int it = tid; it < ((BT_H + 6) / 2) * 16; it += BT_THREADS) {
     const int k = it >> 4, g = it & 15;
     uint32_t o[2][4];
 #pragma unroll
@@ -1353,7 +1362,7 @@ __global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView ds
   // vertical pass: thread = (4-pixel group g, row pair rp): output rows 2rp, 2rp+1 from the row pairs rp .. rp+3
   {
     typedef __attribute__((ext_vector_type(2))) unsigned short us2;
-    for (int it = tid; it < (BT_H / 2) * 16; it += 256) {
+    for (int it = tid; it < (BT_H / 2) * 16; it += BT_THREADS) {
     const int g = it & 15, rp = it >> 4;
     uint4 P[4];
 #pragma unroll
@@ -1381,8 +1390,16 @@ __global__ __launch_bounds__(256) void blur_level_kernel(PyrView src, PyrView ds
     const int gy = oy + 2 * rp, gx = ox + 4 * g;
     if (gx < w) {   // gx is a multiple of 4: the four pixels lie in one tile row; gy is even: row gy + 1 is the next row of the same tile
       uint8_t* o = D + blur_tiled_offset(gx, gy, dst.pitch[lvl]);
+#ifndef BT_NT_STORE
+#define BT_NT_STORE 1   // the blurred planes are next read by the descriptor gather, 0.5 GB of other traffic later: stored non-temporal
+#endif                  // they leave more of the raw levels in the Infinity Cache for FAST (+0.5 % on the step)
+#if BT_NT_STORE
+      if (gy < h) __builtin_nontemporal_store(outE, reinterpret_cast<uint32_t*>(o));
+      if (gy + 1 < h) __builtin_nontemporal_store(outO, reinterpret_cast<uint32_t*>(o + 16));
+#else
       if (gy < h) *reinterpret_cast<uint32_t*>(o) = outE;
       if (gy + 1 < h) *reinterpret_cast<uint32_t*>(o + 16) = outO;
+#endif
     }
     }
   }
@@ -1637,9 +1654,23 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 }
 
 // LDS staging of a keypoint's two patches: the raw 31 x 31 window of IC_Angle and the blurred 37 x 37 window of the pattern
+#ifndef ORI_PITCH
 #define ORI_PITCH 48   // 3 x 16 B: (cx - 15) & 15 <= 15, 15 + 31 <= 48
+#endif
+#ifndef DSC_PITCH
 #define DSC_PITCH 64   // 4 x 16 B: 15 + 37 <= 64
-#define ORI_BYTES (31 * ORI_PITCH)                        // 1116
+#endif
+// a patch row's 16-byte piece into LDS: one b128 store where the pitch keeps the pieces 16-byte aligned, four dwords otherwise
+template <int PITCH>
+__device__ __forceinline__ void patch_store16(uint8_t* base, int r, int c, const uint4& v) {
+  if constexpr (PITCH % 16 == 0) {
+    *reinterpret_cast<uint4*>(base + r * PITCH + 16 * c) = v;
+  } else {
+    uint32_t* q = reinterpret_cast<uint32_t*>(base + r * PITCH + 16 * c);
+    q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+  }
+}
+#define ORI_BYTES ((31 * ORI_PITCH + 15) & ~15)            // 1488
 #define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 2608
 
 // ---- orientation + description, eight keypoints per wave ------------------------------------------------------------------
@@ -1782,7 +1813,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       for (int j = 0; j < 2; j++) {
         const int i = lane + WAVE * j;
         const int r = i / 3, c = i - r * 3;
-        if (i < 31 * 3) reinterpret_cast<uint4*>(ori)[r * (ORI_PITCH / 16) + c] = vn[j];
+        if (i < 31 * 3) patch_store16<ORI_PITCH>(ori, r, c, vn[j]);
       }
       FC_T(1);   // wait for the raw patch + LDS store
       const int kn = next_valid(k);
@@ -1826,7 +1857,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int i = lane + WAVE * j;
-      if (i < 37 * 4) reinterpret_cast<uint4*>(dsc)[i] = wn[j];
+      if (i < 37 * 4) patch_store16<DSC_PITCH>(dsc, i >> 2, i & 3, wn[j]);
     }
     FC_T(4);   // wait for the blurred patch + LDS store
     const int kn = next_valid(k);
@@ -1890,13 +1921,20 @@ void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* d
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,
                          int dh, const ResizeTap* xt, const ResizeTap* yt, int n_images, int mode, hipStream_t s) {
   dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_images);
-  if (mode == 2) {   // scale <= 2 and taps within 8 source bytes: persistent workgroups, perm + dot2 interpolation
-    const int wgs = 6;   // workgroups per CU
+  if (mode >= 2) {   // scale <= 2 and taps within 8 source bytes: persistent workgroups, perm + dot2 interpolation
+#ifndef RS_WGS_NARROW
+#define RS_WGS_NARROW 7   // 6: 0.262, 7: 0.254, 8: 0.268 ms per pyramid of 256 images
+#endif
+    const int wgs = mode == 3 ? RS_WGS_NARROW : 6;   // workgroups per CU (mode 3: every window fits 21 chunks, 14 KB of LDS)
     const int tiles_x = (dw + 255) / 256, tiles_y = (dh + 31) / 32;
     const int n_tiles = tiles_x * tiles_y * n_images;
     const int nb = n_tiles < 256 * wgs ? n_tiles : 256 * wgs;
-    hipLaunchKernelGGL((pyr_resize_dot_kernel<32, 42>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg, dst,
-                       dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
+    if (mode == 3)
+      hipLaunchKernelGGL((pyr_resize_dot_kernel<32, 42, 336>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg, dst,
+                         dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
+    else
+      hipLaunchKernelGGL((pyr_resize_dot_kernel<32, 42, RS_COLS>), dim3(nb), block, 0, s, src, spitch, (unsigned long long)simg, dst,
+                         dpitch, (unsigned long long)dimg, dw, dh, xt, yt, tiles_x, tiles_y, n_tiles);
   }
   else if (mode >= 1)
     hipLaunchKernelGGL(pyr_resize_lds16_kernel, dim3((dw + 255) / 256, (dh + 15) / 16, n_images), block, 0, s, src, spitch,
@@ -1956,9 +1994,12 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
 void orbfe_launch_blur_level(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const LevelResize* rz,
                              int n_images, hipStream_t s) {
   if (n_tiles <= 0) return;
-  dim3 block(256), grid(n_tiles, n_images);
-  if (rz) hipLaunchKernelGGL(blur_level_kernel<true>, grid, block, 0, s, src, dst, tiles, n_tiles, *rz);
-  else hipLaunchKernelGGL(blur_level_kernel<false>, grid, block, 0, s, src, dst, tiles, n_tiles, LevelResize{});
+  dim3 block(BT_THREADS), grid(n_tiles, n_images);
+#ifndef BT_LDS_PAD
+#define BT_LDS_PAD 0   // unused dynamic LDS: an occupancy limiter for experiments
+#endif
+  if (rz) hipLaunchKernelGGL(blur_level_kernel<true>, grid, block, BT_LDS_PAD, s, src, dst, tiles, n_tiles, *rz);
+  else hipLaunchKernelGGL(blur_level_kernel<false>, grid, block, BT_LDS_PAD, s, src, dst, tiles, n_tiles, LevelResize{});
 }
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
@@ -1969,7 +2010,7 @@ void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s)
   // 63 VGPRs would let eight waves per SIMD run; the gather of 2 000 patches per image is L2-miss bound and an eighth wave
   // measured slower (0.352 against 0.341 ms per 256 images): unused dynamic LDS keeps a CU at seven workgroups
 #ifndef OD_LDS_PAD
-#define OD_LDS_PAD 10240
+#define OD_LDS_PAD (4 * PATCH_BYTES < 21504 ? 21504 - 4 * PATCH_BYTES : 0)   // 21 KB per workgroup: seven per CU
 #endif
   hipLaunchKernelGGL(orient_describe8_kernel, grid, block, OD_LDS_PAD, s, pp);
 }

@@ -143,7 +143,8 @@ struct orbfe_extractor {
   DevBuf d_strips, d_blur_tab;
   DevBuf d_cells, d_groups, d_groups1, d_tiles, d_xt[ORBFE_MAX_LEVELS], d_yt[ORBFE_MAX_LEVELS];   // d_groups1: one cell per run (small batches)
   int resize_mode[ORBFE_MAX_LEVELS]{};  // 0: direct gathers; 1: every 256x16 destination tile's source window fits the LDS stage;
-                                         // 2: and every aligned group of four destination pixels reads at most 8 adjacent source bytes
+                                         // 2: and every aligned group of four destination pixels reads at most 8 adjacent source bytes;
+                                         // 3: and every 256-pixel tile's window fits 21 chunks of 16 bytes (scale factors up to ~1.25)
   // work space for `cap_images`
   int cap_images = 0;
   DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_off, d_slots, d_gkeys, d_lvl_kp, d_lvl_n, d_err;
@@ -435,7 +436,12 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
       for (int i = x4; i <= xe; i++)
         if (xt[i].c1 != 0 && xt[i].s1 != xt[i].s0 + 1) win8 = false;
     }
-    e->resize_mode[l] = win8 ? 2 : ok ? 1 : 0;
+    bool narrow = win8;   // every 256-pixel tile's window within 21 chunks of 16 bytes: the kernel's 336-byte LDS rows (8 workgroups per CU)
+    for (int x0 = 0; x0 < (int)xt.size() && narrow; x0 += 256) {
+      const int xl = std::min<int>(x0 + 255, (int)xt.size() - 1);
+      if (((xt[xl].s1 - (xt[x0].s0 & ~15)) >> 4) + 1 > 21) narrow = false;
+    }
+    e->resize_mode[l] = narrow ? 3 : win8 ? 2 : ok ? 1 : 0;
   }
   // blur tiles, and the part of level l + 1 each tile of level l owns when the resize step is fused into the blur: destination
   // dword j (pixels 4j .. 4j + 3) belongs to the tile column that holds the first source column of pixel 4j, destination row y
@@ -446,7 +452,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     const LevelGeom& g = e->lg[l];
     const int tiles_x = (g.w + 63) / 64, tiles_y = (g.h + ORBFE_BLUR_TILE_H - 1) / ORBFE_BLUR_TILE_H;
     std::vector<int> jx(tiles_x + 1, 0), ry(tiles_y + 1, 0);
-    bool fuse = l + 1 < nl && e->resize_mode[l + 1] == 2;
+    bool fuse = l + 1 < nl && e->resize_mode[l + 1] >= 2;
     if (fuse) {
       const std::vector<ResizeTap>&xt = hxt[l + 1], &yt = hyt[l + 1];
       const int dw = (int)xt.size(), dh = (int)yt.size(), ndw = (dw + 3) / 4;
