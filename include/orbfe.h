@@ -565,6 +565,69 @@ int orbfe_gather_sync(orbfe_gather* g);
 int orbfe_extractor_prepare(orbfe_extractor* e, int w, int h, int n_images);
 int orbfe_frontend_prepare(orbfe_extractor* left, orbfe_extractor* right, int w, int h, int max_queries);
 
+/* ------------------------------------------------------------------------------- batched stereo pipeline for a C / C++ host */
+/* The batched-sequence mode (north_star) for a host that does not link the HIP runtime: the whole per-chunk step of
+ * `examples/stereo_kitti.py` / `bench.py` -- images H2D, ORBextractor left + right (L/src/ORBextractor.cc:978-1039), Frame::
+ * ComputeStereoMatches (L/src/Frame.cc:477-646), Frame::UnprojectStereo of every stereo point (:668-679), its projection into the
+ * next frame and SearchByProjection(cur, last) (L/src/ORBmatcher.cc:1247-1383), results D2H -- behind one handle that owns the
+ * two extractors, the matcher, `slots` sets of pinned host and device buffers and three streams (copy in, compute, copy out):
+ *     orbfe_pipeline_input(p, s, &in)     pinned, pitched host images of slot s (+ the per-frame camera / pose records, pre-filled
+ *                                         with the identity pose and the configured intrinsics); the host decodes into them
+ *     orbfe_pipeline_submit(p, s, n, hp)  enqueues the chunk (n <= batch frames; hp = 0: frame 0 has no predecessor) and returns
+ *     orbfe_pipeline_wait(p, s)           blocks until slot s's results are in its pinned output block
+ *     orbfe_pipeline_output(p, s, &out)   the block: counts, keypoints, descriptors, mvuRight / mvDepth, tracked assignments
+ * Chunks are processed in submit order; frame 0 of a chunk is searched with the points of the last frame of the previous one.  With
+ * two slots the H2D copy of chunk k + 1 and the D2H copy of chunk k - 1 run beside the kernels of chunk k.  The left records of a
+ * slot stay in HBM for orbfe_gather_records (orbfe_pipeline_device_records, enqueue it on orbfe_pipeline_stream) until the slot is
+ * submitted again.  One host thread per handle at a time; one handle per GPU (orbfe_set_device before orbfe_pipeline_create, or
+ * device >= 0). */
+typedef struct orbfe_pipeline orbfe_pipeline;
+typedef struct orbfe_pipeline_config {
+  orbfe_params extractor;          /* both eyes */
+  int32_t width, height;
+  int32_t batch;                   /* stereo frames per chunk */
+  int32_t slots;                   /* buffer sets, 1 .. 4 */
+  float fx, fy, cx, cy, bf;        /* Camera.fx .. Camera.bf of the settings file (bf = baseline x fx) */
+  float th;                        /* SearchByProjection window factor (7 for stereo, L/src/Tracking.cc:793-798) */
+  int32_t check_orientation;       /* ORBmatcher(0.9, true) */
+} orbfe_pipeline_config;
+typedef struct orbfe_pipeline_input_view {
+  uint8_t* left; uint8_t* right;   /* frame f at + f * image_bytes, rows `pitch` bytes apart (pitch = width rounded up to 64) */
+  int32_t pitch; size_t image_bytes;
+  orbfe_unproject_cam* cams;       /* [batch]: Frame::UnprojectStereo's camera of frame f */
+  orbfe_track_pose* poses;         /* [batch]: CurrentFrame members of frame f for the projection of frame f - 1's points */
+} orbfe_pipeline_input_view;
+typedef struct orbfe_pipeline_output_view {
+  int32_t cap;                     /* keypoint rows per frame */
+  const int32_t* n_left;           /* [batch] */
+  const orbfe_keypoint* kps_left;  /* [batch][cap] */
+  const uint8_t* desc_left;        /* [batch][cap][32] */
+  const int32_t* n_right;          /* [batch] */
+  const float* u_right;            /* [batch][cap] mvuRight (-1: none) */
+  const float* depth;              /* [batch][cap] mvDepth */
+  const int32_t* n_stereo;         /* [batch] */
+  const int32_t* assigned;         /* [batch][cap]: index of the last frame's point matched to keypoint i, or -1 */
+  const int32_t* n_tracked;        /* [batch]: SearchByProjection's return value */
+} orbfe_pipeline_output_view;
+int orbfe_pipeline_create(const orbfe_pipeline_config* cfg, int device, orbfe_pipeline** out);
+int orbfe_pipeline_destroy(orbfe_pipeline* p);
+int orbfe_pipeline_input(orbfe_pipeline* p, int slot, orbfe_pipeline_input_view* in);
+int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n_frames, int has_predecessor);
+int orbfe_pipeline_wait(orbfe_pipeline* p, int slot);
+int orbfe_pipeline_output(orbfe_pipeline* p, int slot, orbfe_pipeline_output_view* out);
+/* DEVICE pointers of slot s's left records ([batch] counts -- rows behind n_frames are zero --, [batch][cap] keypoints and
+ * descriptors), valid from the slot's submit until its next submit, ordered on orbfe_pipeline_stream */
+int orbfe_pipeline_device_records(orbfe_pipeline* p, int slot, const int32_t** d_n, const orbfe_keypoint** d_kps,
+                                  const uint8_t** d_desc, int* cap);
+void* orbfe_pipeline_stream(orbfe_pipeline* p);   /* the compute stream (a hipStream_t) */
+/* orbfe_gather_records of slot s's left records (`batch` frames of `cap` rows each, every rank alike) on a stream of the
+ * pipeline's own, behind the slot's kernels: the collective overlaps the next chunk's kernels and the slot's next submit waits
+ * for it.  Every rank calls it once per chunk, in chunk order (a rank whose shard has ended submits empty chunks).  The *_all
+ * buffers are the caller's (orbfe_device_malloc); orbfe_pipeline_gather_wait blocks until they are filled. */
+int orbfe_pipeline_gather(orbfe_pipeline* p, int slot, orbfe_gather* g, int mode, int32_t* d_n_all, orbfe_keypoint* d_kps_all,
+                          uint8_t* d_desc_all);
+int orbfe_pipeline_gather_wait(orbfe_pipeline* p, int slot);
+
 /* --------------------------------------------------------------------------------------- sequence driver helpers */
 /* Dependency-free PNG input for the dataset drivers (the reference reads with cv::imread(..., IMREAD_UNCHANGED),
  * Source/Examples/Stereo/stereo_kitti.cc:88-89, Source/Examples/RGB-D/rgbd_tum.cc, and converts colour frames in

@@ -153,6 +153,8 @@ struct orbfe_extractor {
   void* h_in = nullptr;  size_t h_in_bytes = 0;    // pinned: caller images, packed
   void* h_out = nullptr; size_t h_out_bytes = 0;   // pinned: [n_out[B] | err | kps | desc] / pyramid planes
   int out_cap = 0;
+  int32_t* h_err = nullptr;   // pinned: where the device error word is read to (a pageable destination makes the copy wait for every
+                              // stream of the device, also the caller's: measured on the batched pipeline, 52 k -> 33 k frames/s)
   int last_images = 0;
   // profiling
   bool profile = false;
@@ -850,6 +852,7 @@ extern "C" int orbfe_extractor_destroy(orbfe_extractor* e) {
                     &e->d_gkeys, &e->d_lvl_kp, &e->d_lvl_n, &e->d_err, &e->d_out_kps, &e->d_out_desc, &e->d_out_n};
   for (auto b : bufs) dev_free(*b);
   dev_free(e->d_in_stage);
+  if (e->h_err) (void)hipHostFree(e->h_err);
   if (e->h_in) (void)hipHostFree(e->h_in);
   if (e->h_out) (void)hipHostFree(e->h_out);
   for (int l = 0; l < ORBFE_MAX_LEVELS; l++) { dev_free(e->d_xt[l]); dev_free(e->d_yt[l]); }
@@ -904,9 +907,11 @@ extern "C" int orbfe_sync(orbfe_extractor* e) {
 }
 
 static int check_device_error(orbfe_extractor* e, hipStream_t s) {
-  int32_t err = 0;
-  HIPCHK(hipMemcpyAsync(&err, e->d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+  if (!e->h_err) HIPCHK(hipHostMalloc((void**)&e->h_err, 64, hipHostMallocDefault));
+  *e->h_err = 0;
+  HIPCHK(hipMemcpyAsync(e->h_err, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  const int32_t err = *e->h_err;
   if (err) {
     orbfe_set_error("device-side capacity error word 0x%x", err);
     (void)hipMemsetAsync(e->d_err.p, 0, 4, s);

@@ -157,35 +157,57 @@ def test_cpp_sequence_driver_on_kitti_layout(tmp_path):
         exp.append((kL, dL, ur, depth, nm, assigned))
         prev = ol.unproject_stereo(cam, kL, dL, depth)
     exe = os.path.join(ROOT, "tests", "cpp", "_build", "stereo_kitti")
+
+    def check_dump(path, expected):
+        raw = open(path, "rb").read()
+        off = 0
+        for i, (kL, dL, ur, depth, nm, assigned) in enumerate(expected):
+            n, nmatches = np.frombuffer(raw, np.int32, 2, off); off += 8
+            assert n == len(kL), (i, n, len(kL))
+            k = np.frombuffer(raw, KP_DTYPE, n, off); off += 28 * n
+            d = np.frombuffer(raw, np.uint8, 32 * n, off).reshape(n, 32); off += 32 * n
+            u = np.frombuffer(raw, np.float32, n, off); off += 4 * n
+            z = np.frombuffer(raw, np.float32, n, off); off += 4 * n
+            a = np.frombuffer(raw, np.int32, n, off); off += 4 * n
+            np.testing.assert_array_equal(k, kL, err_msg=f"keypoints of frame {i}")
+            np.testing.assert_array_equal(d, dL)
+            np.testing.assert_array_equal(u, ur, err_msg=f"mvuRight of frame {i}"); np.testing.assert_array_equal(z, depth)
+            assert nmatches == nm, (i, nmatches, nm)
+            np.testing.assert_array_equal(a, assigned, err_msg=f"tracked assignment of frame {i}")
+        assert off == len(raw)
+
     dump = str(tmp_path / "dump.bin")
-    r = subprocess.run([exe, str(seq), "--dump", dump], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, str(seq), "--dump", dump], capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "median tracking time" in r.stdout and f"Images in the sequence: {N}" in r.stdout
-    raw = open(dump, "rb").read()
-    off = 0
-    for i, (kL, dL, ur, depth, nm, assigned) in enumerate(exp):
-        n, nmatches = np.frombuffer(raw, np.int32, 2, off); off += 8
-        assert n == len(kL), (i, n, len(kL))
-        k = np.frombuffer(raw, KP_DTYPE, n, off); off += 28 * n
-        d = np.frombuffer(raw, np.uint8, 32 * n, off).reshape(n, 32); off += 32 * n
-        u = np.frombuffer(raw, np.float32, n, off); off += 4 * n
-        z = np.frombuffer(raw, np.float32, n, off); off += 4 * n
-        a = np.frombuffer(raw, np.int32, n, off); off += 4 * n
-        np.testing.assert_array_equal(k, kL, err_msg=f"keypoints of frame {i}")
-        np.testing.assert_array_equal(d, dL)
-        np.testing.assert_array_equal(u, ur, err_msg=f"mvuRight of frame {i}"); np.testing.assert_array_equal(z, depth)
-        assert nmatches == nm, (i, nmatches, nm)
-        np.testing.assert_array_equal(a, assigned, err_msg=f"tracked assignment of frame {i}")
-    assert off == len(raw)
+    check_dump(dump, exp)
     assert exp[2][4] > 500 and (exp[1][3] > 0).sum() > 800
+    # ---- the batched pipeline from the C++ host (orbfe_pipeline_*, --batch F): chunks of 3 + 1 frames through two buffer sets, the
+    #      frame that opens the second chunk tracked against the last frame of the first; then the sequence walked twice from
+    #      pre-decoded frames (frame 4 = image 0 again, tracked against image 3's stereo points)
+    dumpb = str(tmp_path / "dump_batch.bin")
+    rb = subprocess.run([exe, str(seq), "--dump", dumpb, "--batch", "3", "--slots", "2"], capture_output=True, text=True, timeout=150)
+    assert rb.returncode == 0, rb.stdout + rb.stderr
+    assert "batched pipeline: chunks of 3 pairs, 2 buffer sets" in rb.stdout and "frames/s end to end" in rb.stdout, rb.stdout
+    check_dump(dumpb, exp)
+    kL0, dL0, ur0, depth0 = exp[0][:4]
+    nm4, as4, _ = ol.OracleFrame(kL0, dL0, sf, 0, W, 0, H, ur0).search_by_projection_frame(
+        ol.track_queries(pose, ol.unproject_stereo(cam, exp[3][0], exp[3][1], exp[3][3])), True)
+    exp2 = exp + [(kL0, dL0, ur0, depth0, nm4, as4)] + exp[1:]
+    dumpr = str(tmp_path / "dump_repeat.bin")
+    rr = subprocess.run([exe, str(seq), "--dump", dumpr, "--batch", "4", "--preload", "1", "--repeat", "2"], capture_output=True, text=True, timeout=150)
+    assert rr.returncode == 0, rr.stdout + rr.stderr
+    assert "Images in the sequence: 8" in rr.stdout and "frames decoded before the clock started" in rr.stdout, rr.stdout
+    check_dump(dumpr, exp2)
     # the report: every frame counts (the front end was prepared before frame 0), tail latencies, the end-to-end rate
     for key in ("mean tracking time", "p95 tracking time", "p99 tracking time", "max tracking time", "frames/s end to end", "front end prepared in"):
         assert key in r.stdout, key
     # the batched mode's exchange through the C ABI (orbfe_gather_create_all + orbfe_gather_records; one GPU here: world 1), both
     # forms, and the reference's load-then-track loop (no decode pool, no warm-up): the same records
-    for extra in (["--gather", "all"], ["--gather", "root", "--decode-threads", "0", "--prepare", "0"]):
+    for extra in (["--gather", "all"], ["--gather", "root", "--decode-threads", "0", "--prepare", "0"],
+                  ["--gather", "all", "--batch", "2"], ["--gather", "root", "--batch", "3", "--slots", "1"]):   # the last two: per chunk, from HBM
         gd = str(tmp_path / "gather.bin")
-        r2 = subprocess.run([exe, str(seq), "--gather-dump", gd] + extra, capture_output=True, text=True, timeout=600)
+        r2 = subprocess.run([exe, str(seq), "--gather-dump", gd] + extra, capture_output=True, text=True, timeout=150)
         assert r2.returncode == 0, r2.stdout + r2.stderr
         assert "RCCL through the C ABI" in r2.stdout and "0 frame(s) differ" in r2.stdout, r2.stdout
         graw = open(gd, "rb").read()
