@@ -594,6 +594,14 @@ def main():
                 for f in range(F):
                     oy, ox = (37 * f) % demo.shape[1], (53 * f) % demo.shape[2]
                     L[f, :, :W] = big[f % 4][oy:oy + H, ox:ox + W]
+            elif kind == "dense_texture":   # a stand-in for foliage: the demo images at twice the contrast plus +-6 grey levels of pixel noise
+                demo = np.load(os.path.join(ROOT, "tests", "golden", "real_demo.npz"))["images"][:4]
+                reps = (H + demo.shape[1] - 1) // demo.shape[1] + 1, (W + 64 + demo.shape[2] - 1) // demo.shape[2] + 1
+                big = [np.tile(d, reps) for d in demo]
+                for f in range(F):
+                    oy, ox = (37 * f) % demo.shape[1], (53 * f) % demo.shape[2]
+                    t = big[f % 4][oy:oy + H, ox:ox + W].astype(np.int16)
+                    L[f, :, :W] = np.clip(128 + 2 * (t - 128) + rng.integers(-6, 7, (H, W)), 0, 255).astype(np.uint8)
             elif kind == "uniform_noise":
                 base = rng.integers(0, 256, (8, H, W + 64), dtype=np.uint8)
                 for f in range(F):
@@ -609,7 +617,7 @@ def main():
             return torch.from_numpy(L), torch.from_numpy(R)
 
         content = {}
-        for kind in ("real_texture", "sensor_noise", "uniform_noise", "flat"):
+        for kind in ("real_texture", "dense_texture", "sensor_noise", "uniform_noise", "flat"):
             try:
                 tl, tr = content_images(kind)
                 B0.dL_full.copy_(tl); B0.dR_full.copy_(tr)
@@ -629,7 +637,9 @@ def main():
                     step()
                 barrier()
                 dtc = time.perf_counter() - tc
+                cand_lv = [round(float(np.mean([len(exL.debug_candidates(i, l)[0]) for i in range(min(F, 4))])), 1) for l in range(NLEVELS)]
                 content[kind] = {"frames_per_s": round(F * args.content_steps / dtc, 1), "ms_per_step": round(dtc / args.content_steps * 1e3, 4),
+                                 "fast_candidates_per_level": cand_lv,
                                  "stage_ms_per_batch": st, "keypoints_per_image": round((int(B0.nl.sum().item()) + int(B0.nr.sum().item())) / (2 * F), 1),
                                  "stereo_matches_per_frame": round(int(B0.n_stereo.sum().item()) / F, 1),
                                  "tracked_per_frame": round(int(B0.n_track.sum().item()) / F, 1)}
@@ -712,7 +722,8 @@ def main():
         if content is not None:
             out["content"] = content
             out["content_note"] = (f"the same step ({args.content_steps} steps each, outside the timed region) on other content: the DBoW2 demo images tiled "
-                                   f"to {W}x{H}, the synthetic sequence with +-8 grey levels of pixel noise (the quadtree's keys of level 0 leave LDS), "
+                                   f"to {W}x{H}, the same at twice the contrast with +-6 grey levels of noise (a stand-in for foliage), the synthetic sequence with +-8 grey levels "
+                                   f"of pixel noise (the quadtree's keys of level 0 leave LDS: 1 664 per level), "
                                    f"uniform noise (every level's keys in HBM), a flat frame; `value` is the synthetic sequence of SURVEY.md 8(d)")
         if world == 1 and args.per_frame > 0 and STEREO:
             pf = per_frame_latency(cfg, args.per_frame)

@@ -975,12 +975,35 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     }
     size = tot;
   }
+  for (int i = tid; i < size * 4; i += OCT_T) cnt4[i] = 0;
   __syncthreads();
-  for (int k = tid; k < C; k += OCT_T) {
-    unsigned long long kk = keys[k];
-    const int nn = ini_map[KEY_NODE(kk)];
-    keys[k] = (kk & ~(0xffffULL << 32)) | ((unsigned long long)(uint16_t)nn << 32);
-  }
+  // A key's new leaf and, in the same visit, the quadrant of that leaf it falls into with the leaf's quadrant count (DivideNode
+  // :505-517) for the NEXT subdivision round: one read and one write of every key per round instead of two passes (a count
+  // pass and a relabel pass).  Four keys per thread are requested together (the spill path reads them from HBM: one round trip
+  // per key otherwise).
+  auto relabel_and_count = [&](const OctNode* nodes, auto&& new_leaf) {
+    for (int k0 = tid; k0 < C; k0 += 4 * OCT_T) {
+      unsigned long long kk[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) kk[j] = keys[min(k0 + j * OCT_T, C - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = k0 + j * OCT_T;
+        if (k >= C) break;
+        const int np = new_leaf(kk[j]);
+        const OctNode nd = nodes[np];
+        int q = 0;
+        if (nd.cnt > 1) {
+          const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);  // UL.x + ceil(w/2)
+          const int my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+          q = (KEY_X(kk[j]) >= mx ? 1 : 0) + (KEY_Y(kk[j]) >= my ? 2 : 0);  // 0:n1 1:n2 2:n3 3:n4
+          atomicAdd(&cnt4[np * 4 + q], 1);
+        }
+        keys[k] = (kk[j] & 0x00ff0000ffffffffULL) | ((unsigned long long)(uint16_t)np << 32) | ((unsigned long long)q << 56);
+      }
+    }
+  };
+  relabel_and_count(nodeA, [&](unsigned long long kk) { return ini_map[KEY_NODE(kk)]; });
   __syncthreads();
 
   // 4. subdivision loop (:581-709)
@@ -991,23 +1014,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 #if FC_TIMING
     n_iter++;
 #endif
-    const int prev = size;
-    for (int i = tid; i < size * 4; i += OCT_T) cnt4[i] = 0;
-    __syncthreads();
-    // keys -> quadrant counts of their leaf (DivideNode :505-517)
-    for (int k = tid; k < C; k += OCT_T) {
-      unsigned long long kk = keys[k];
-      const int p = KEY_NODE(kk);
-      const OctNode nd = nodeA[p];
-      if (nd.cnt > 1) {
-        const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);  // UL.x + ceil(w/2)
-        const int my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-        const int q = (KEY_X(kk) >= mx ? 1 : 0) + (KEY_Y(kk) >= my ? 2 : 0);  // 0:n1 1:n2 2:n3 3:n4
-        atomicAdd(&cnt4[p * 4 + q], 1);
-        keys[k] = (kk & ~(0xffULL << 56)) | ((unsigned long long)q << 56);
-      }
-    }
-    __syncthreads();
+    const int prev = size;   // cnt4 holds the quadrant counts of every multi-key leaf of nodeA (relabel_and_count)
 
     // which leaves split, and in which order their children are created
     int K = 0;        // number of children created
@@ -1135,12 +1142,12 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       }
     }
     __syncthreads();
-    for (int k = tid; k < C; k += OCT_T) {
-      unsigned long long kk = keys[k];
+    for (int i = tid; i < newsize * 4; i += OCT_T) cnt4[i] = 0;   // the build above was the last reader of this round's counts
+    __syncthreads();
+    relabel_and_count(nodeB, [&](unsigned long long kk) {
       const int p = KEY_NODE(kk);
-      const int np = aux[p] >= 0 ? (int)childpos[p * 4 + KEY_Q(kk)] : aux2[p];
-      keys[k] = (kk & ~(0xffffULL << 32)) | ((unsigned long long)(uint16_t)np << 32);
-    }
+      return aux[p] >= 0 ? (int)childpos[p * 4 + KEY_Q(kk)] : aux2[p];
+    });
     { OctNode* t = nodeA; nodeA = nodeB; nodeB = t; }
     size = newsize;
     __syncthreads();
