@@ -326,6 +326,10 @@ def main():
                                                                 "liborbfe) in both modes, compare with the local records, report on stderr (default off: "
                                                                 "the path has never run with peers and must not be able to cost the line)")
     ap.add_argument("--content-steps", type=int, default=30, help="steps per image content of the content-sensitivity key (0 = skip)")
+    ap.add_argument("--gather-impl", choices=("torch", "cabi"), default="torch",
+                    help="which implementation of the record gather is the timed collective: torch.distributed (sharding.AsyncGather, the default until "
+                         "the other one has run with peers once) or the C ABI's (orbfe_gather_*: RCCL called by liborbfe, what a C++ host uses); "
+                         "with cabi the gather also runs at N = 1 (a one-rank communicator: the code path on a one-GPU box)")
     ap.add_argument("--gather", choices=("all", "root"), default="all",
                     help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
     ap.add_argument("--blur-kind", type=int, default=0, choices=(0, 1, 2),
@@ -343,7 +347,7 @@ def main():
     import torch.distributed as dist
     from refactored_orb_slam2_amd import ORBextractor, synth
     from refactored_orb_slam2_amd.matcher import Matcher, track_queries_batch, unproject_stereo_batch
-    from refactored_orb_slam2_amd.sharding import AsyncGather, gather_traffic
+    from refactored_orb_slam2_amd.sharding import AsyncGather, CabiAsyncGather, gather_traffic
 
     cfg = CONFIGS[args.config]
     W, H, NFEAT, STEREO = cfg["w"], cfg["h"], cfg["nfeat"], cfg["stereo"]
@@ -461,14 +465,18 @@ def main():
             # SearchByBoW's brute force: frame f against frame f-1 (slices of the same buffers: no copies), grouped by node id
             B.grp.copy_(node_ids(B.dl))
             mt.hamming_bf_batch(B.dl[1:], B.nl[1:], B.dl[:-1], B.nl[:-1], B.grp[1:], B.grp[:-1], B.bf[1:], stream=cur)
-        if world > 1:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
+        if gatherer is not None:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
             gatherer.launch(B.nl, B.kl, B.dl)
 
     def step():
         with torch.cuda.stream(sM):
             _step(sM, B0)
 
-    gatherer = AsyncGather(B0.nl, B0.kl, B0.dl, mode=args.gather) if world > 1 else None
+    gatherer = None
+    if args.gather_impl == "cabi" and backend == "nccl":
+        gatherer = CabiAsyncGather(B0.nl, B0.kl, B0.dl, rank, world, local, mode=args.gather)
+    elif world > 1:
+        gatherer = AsyncGather(B0.nl, B0.kl, B0.dl, mode=args.gather)
 
     def barrier():
         if gatherer is not None:
@@ -518,6 +526,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rank_rates, coll_ms = None, None
+    gather_check = None
+    if gatherer is not None:
+        # the gathered records of the last timed step == this rank's own records at its slot (the collective moved the right bytes)
+        res = gatherer.result()
+        if res is not None:
+            mine = slice(rank * F, (rank + 1) * F)
+            gather_check = bool((res[0][mine].to(B0.nl.device) == B0.nl).all()) and bool((res[2][mine].to(B0.dl.device) == B0.dl).all())
     if world > 1:
         # every rank's own clock (the straggler shows), the MAX over ranks is the job's time
         mine = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -704,7 +719,8 @@ def main():
             "input_layout": f"u8 images resident in HBM, rows {PITCH} bytes apart (16-byte aligned: level 0 of the pyramid in place)",
             "config": {"workload": cfg["label"], "name": args.config, "frames_per_gpu_per_step": F,
                        "images_per_step": n_img * world, "parallelism": f"frame-shard x{world}",
-                       "collective": (f"{backend} {'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {dist.get_world_size()}" if world > 1 else "none"),
+                       "collective": ((f"{'RCCL through the C ABI (orbfe_gather_records)' if (args.gather_impl == 'cabi' and backend == 'nccl') else backend} "
+                                       f"{'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {world}") if gatherer is not None else "none"),
                        "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
                        "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -712,9 +728,13 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
+        if gatherer is not None:
+            out["config"]["gather"] = dict(gather_traffic(B0.nl, B0.kl, B0.dl, world, args.gather), impl=args.gather_impl if backend == "nccl" else "torch",
+                                           own_slot_equal_rank0=gather_check,
+                                           standalone_ms_rank0=(round(coll_ms, 4) if coll_ms is not None else None),
+                                           note="per step, overlapped with the next step's kernels; standalone_ms = the same collective alone, HIP events on rank 0"
+                                                + ("; world 1: a one-rank communicator, the collective degenerates to a copy" if world == 1 else ""))
         if world > 1:
-            out["config"]["gather"] = dict(gather_traffic(B0.nl, B0.kl, B0.dl, world, args.gather), standalone_ms_rank0=round(coll_ms, 4),
-                                           note="per step, overlapped with the next step's kernels; standalone_ms = the same collective alone, HIP events on rank 0")
             out["config"]["frames_per_s_by_rank"] = rank_rates
         if e2e is not None:
             out["e2e_frames_per_s"] = round(e2e, 1)

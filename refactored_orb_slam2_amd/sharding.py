@@ -165,6 +165,55 @@ class AsyncGather:
         return tuple(self.out) if self.out is not None else None
 
 
+class CabiAsyncGather:
+    """AsyncGather's interface over the C ABI's gather (RcclGather: RCCL called by liborbfe itself -- what a C++ host of the batched
+    mode uses): the step's records are snapshotted on the compute stream, the collective runs on a side stream behind it and overlaps
+    the next step; launch() / wait() / result() as AsyncGather.  The communicator's unique id travels over the torch.distributed
+    control-plane group when world > 1 (any side channel would do); world 1 is a valid communicator (self-check on one GPU)."""
+
+    def __init__(self, n, kps, desc, rank: int, world: int, device: int, mode: str = "all", group=None):
+        import torch
+        import torch.distributed as dist
+        if mode not in ("all", "root"):
+            raise ValueError("mode must be 'all' or 'root'")
+        uid = [RcclGather.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0, group=group)
+        self.g = RcclGather(uid[0], rank, world, device)
+        self.mode, self.rank, self.world = mode, rank, world
+        self.snap = [torch.empty_like(t) for t in (n, kps, desc)]
+        self.stream = torch.cuda.Stream(n.device)
+        self.ev = torch.cuda.Event()
+        self.out = None
+        self.pending = False
+
+    def wait(self):
+        """Orders the current stream behind the collective in flight (its snapshot / output buffers are free again after it)."""
+        import torch
+        if self.pending:
+            torch.cuda.current_stream().wait_event(self.ev)
+            self.pending = False
+
+    def launch(self, n, kps, desc):
+        import torch
+        cur = torch.cuda.current_stream()
+        self.wait()
+        for s, t in zip(self.snap, (n, kps, desc)):
+            s.copy_(t, non_blocking=True)
+        self.stream.wait_stream(cur)
+        self.out = self.g.gather(self.snap[0], self.snap[1], self.snap[2], mode=self.mode, stream=self.stream)
+        self.ev.record(self.stream)
+        self.pending = True
+
+    def result(self):
+        self.ev.synchronize()
+        self.pending = False
+        return self.out
+
+    def close(self):
+        self.g.close()
+
+
 def gather_records(n, kps, desc, group=None, mode: str = "all"):
     """Gather of fixed-size padded per-frame records {n[f]; kps[f, cap, 28]; desc[f, cap, 32]}.
 

@@ -547,3 +547,21 @@ def test_bench_spawns_its_ranks_and_checks_the_gather():
         g = out["config"]["gather"]
         assert g["mode"] == mode and g["record_bytes_per_rank"] > 8 * 2000 * 60 and g["standalone_ms_rank0"] > 0
         assert len(out["config"]["frames_per_s_by_rank"]) == 2 and min(out["config"]["frames_per_s_by_rank"]) > 0
+
+
+def test_bench_times_the_c_abi_gather_when_asked():
+    """`bench.py --gather-impl cabi`: the record gather of every step goes through the C ABI (orbfe_gather_records: RCCL called by
+    liborbfe, the collective a C++ host uses) instead of torch.distributed; on one GPU a one-rank communicator -- the code path,
+    the bench line's `config.gather` block and the check that the gathered records equal the step's own."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("all", "root"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--frames", "8", "--cpu-sample", "0", "--e2e-steps", "0",
+                            "--per-frame", "0", "--content-steps", "0", "--gather-impl", "cabi", "--gather", mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        g = out["config"]["gather"]
+        assert g["impl"] == "cabi" and g["mode"] == mode and g["own_slot_equal_rank0"] is True, g
+        assert "orbfe_gather_records" in out["config"]["collective"] and out["value"] > 0
