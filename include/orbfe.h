@@ -639,6 +639,11 @@ int orbfe_png_info(const char* path, int* w, int* h);
 /* ... with the bit depth (8 / 16) and channel count (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA); any output may be NULL */
 int orbfe_png_info2(const char* path, int* w, int* h, int* depth, int* channels);
 int orbfe_png_read_gray(const char* path, uint8_t* dst, int stride, int cap_rows, int* w, int* h);
+/* Colour files and the settings file's Camera.RGB: the reference converts cv::imread's BGR data with RGB2GRAY when Camera.RGB is 1
+ * -- every settings file it ships -- i.e. grey = 0.299 B + 0.587 G + 0.114 R, and with BGR2GRAY (the luminance) when it is 0
+ * (L/src/Tracking.cc:164-178).  orbfe_png_read_gray is camera_rgb = 0; pass the file's flag here to get the reference's grey
+ * levels (and so its keypoints) on colour input.  Grey files are unaffected. */
+int orbfe_png_read_gray2(const char* path, uint8_t* dst, int stride, int cap_rows, int* w, int* h, int camera_rgb);
 /* 16-bit greyscale: h rows of w uint16 samples (host byte order), `stride_elems` ELEMENTS apart */
 int orbfe_png_read_gray16(const char* path, uint16_t* dst, int stride_elems, int cap_rows, int* w, int* h);
 

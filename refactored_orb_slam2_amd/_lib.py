@@ -101,7 +101,7 @@ EXPORTS = [
     "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_kf_search", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
     "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
-    "orbfe_bow_transform_device", "orbfe_compute_bow", "orbfe_png_info", "orbfe_png_info2", "orbfe_png_read_gray", "orbfe_png_read_gray16",
+    "orbfe_bow_transform_device", "orbfe_compute_bow", "orbfe_png_info", "orbfe_png_info2", "orbfe_png_read_gray", "orbfe_png_read_gray2", "orbfe_png_read_gray16",
     "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_input", "orbfe_pipeline_submit", "orbfe_pipeline_wait",
     "orbfe_pipeline_output", "orbfe_pipeline_device_records", "orbfe_pipeline_stream", "orbfe_pipeline_gather", "orbfe_pipeline_gather_wait",
 ]

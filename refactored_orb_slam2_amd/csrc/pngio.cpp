@@ -144,7 +144,7 @@ static int png_info(const char* path, int* w, int* h, int* depth, int* channels)
   return ORBFE_OK;
 }
 
-static int png_read_gray(const char* path, uint8_t* dst, int stride, int cap_rows, int* w_out, int* h_out) {
+static int png_read_gray(const char* path, uint8_t* dst, int stride, int cap_rows, int* w_out, int* h_out, int camera_rgb) {
   std::vector<uint8_t> b, idat, raw;
   int rc = read_file(path, b);
   if (rc) return rc;
@@ -171,9 +171,13 @@ static int png_read_gray(const char* path, uint8_t* dst, int stride, int cap_row
     if (channels == 1) memcpy(out, cur, (size_t)w);
     else if (channels == 2) for (int x = 0; x < w; x++) out[x] = cur[2 * (size_t)x];
     else
-      for (int x = 0; x < w; x++) {   // cvtColor RGB2GRAY, 8-bit: (R * 4899 + G * 9617 + B * 1868 + (1 << 13)) >> 14
+      for (int x = 0; x < w; x++) {   // cvtColor, 8-bit: (c0 * 4899 + G * 9617 + c2 * 1868 + (1 << 13)) >> 14
+        // camera_rgb = 0: c0 = R, c2 = B -- the luminance, what Tracking::GrabImage* computes with Camera.RGB: 0 (BGR2GRAY on
+        // imread's BGR data).  camera_rgb = 1: c0 = B, c2 = R -- what it computes with Camera.RGB: 1, the value of every settings
+        // file the reference ships: RGB2GRAY applied to imread's BGR data (L/src/Tracking.cc:164-178)
         const uint8_t* p = &cur[(size_t)x * channels];
-        out[x] = (uint8_t)((p[0] * 4899 + p[1] * 9617 + p[2] * 1868 + 8192) >> 14);
+        const int c0 = camera_rgb ? p[2] : p[0], c2 = camera_rgb ? p[0] : p[2];
+        out[x] = (uint8_t)((c0 * 4899 + p[1] * 9617 + c2 * 1868 + 8192) >> 14);
       }
   }
   return ORBFE_OK;
@@ -233,7 +237,12 @@ extern "C" int orbfe_png_info2(const char* path, int* w, int* h, int* depth, int
 // Decodes `path` into dst (h rows of w bytes, `stride` bytes apart; cap_rows >= h, stride >= w).
 extern "C" int orbfe_png_read_gray(const char* path, uint8_t* dst, int stride, int cap_rows, int* w_out, int* h_out) {
   if (!path || !dst) return ORBFE_ERR_INVALID;
-  return guarded(path, [&] { return png_read_gray(path, dst, stride, cap_rows, w_out, h_out); });
+  return guarded(path, [&] { return png_read_gray(path, dst, stride, cap_rows, w_out, h_out, 0); });
+}
+// ... with the settings file's Camera.RGB flag for colour input (see the conversion above); grey files are unaffected
+extern "C" int orbfe_png_read_gray2(const char* path, uint8_t* dst, int stride, int cap_rows, int* w_out, int* h_out, int camera_rgb) {
+  if (!path || !dst) return ORBFE_ERR_INVALID;
+  return guarded(path, [&] { return png_read_gray(path, dst, stride, cap_rows, w_out, h_out, camera_rgb != 0); });
 }
 // 16-bit greyscale (depth maps): h rows of w uint16, `stride_elems` elements apart.
 extern "C" int orbfe_png_read_gray16(const char* path, uint16_t* dst, int stride_elems, int cap_rows, int* w_out, int* h_out) {

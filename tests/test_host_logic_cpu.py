@@ -206,6 +206,19 @@ def test_png_reader_decodes_all_filters_and_rgb(tmp_path):
     Image.fromarray(rgb).save(tmp_path / "rgb.png")
     ref = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14)
     np.testing.assert_array_equal(read(tmp_path / "rgb.png"), ref.astype(np.uint8))
+    # Camera.RGB: 1 (every settings file the reference ships): Tracking::GrabImage* applies RGB2GRAY to imread's BGR data
+    # (L/src/Tracking.cc:164-178), i.e. the 0.299 weight meets the file's BLUE channel; grey files do not depend on the flag
+    L.orbfe_png_read_gray2.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    w2, h2 = C.c_int(0), C.c_int(0)
+    sw = np.empty((50, 70), np.uint8)
+    assert L.orbfe_png_read_gray2(str(tmp_path / "rgb.png").encode(), sw.ctypes.data_as(C.c_void_p), 70, 50, C.byref(w2), C.byref(h2), 1) == 0
+    ref_sw = ((rgb[..., 2].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 0].astype(np.int64) * 1868 + 8192) >> 14)
+    np.testing.assert_array_equal(sw, ref_sw.astype(np.uint8))
+    assert L.orbfe_png_read_gray2(str(tmp_path / "rgb.png").encode(), sw.ctypes.data_as(C.c_void_p), 70, 50, C.byref(w2), C.byref(h2), 0) == 0
+    np.testing.assert_array_equal(sw, ref.astype(np.uint8))
+    g2 = np.empty_like(img)
+    assert L.orbfe_png_read_gray2(str(tmp_path / "pil.png").encode(), g2.ctypes.data_as(C.c_void_p), g2.strides[0], g2.shape[0], C.byref(w2), C.byref(h2), 1) == 0
+    np.testing.assert_array_equal(g2, img)
     # errors are codes, not crashes
     w, h = C.c_int(0), C.c_int(0)
     assert L.orbfe_png_info(str(tmp_path / "missing.png").encode(), C.byref(w), C.byref(h)) != 0
