@@ -1203,6 +1203,27 @@ __device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {
 // round half up.  One 64 x BT_H (56) output tile per workgroup, separable through LDS.  Interior tiles stage the
 // (64+8) x (56+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
 // REFLECT_101 indexing.  Both passes produce 4 adjacent pixels per work item (dword LDS/global accesses).
+// ---- the tile kernel's blur on the matrix cores (BT_MFMA, the default): the arithmetic of gauss_blur7_mfma_kernel below -- a 7-tap
+// pass is Out = In x Band, pixels as i8 (x ^ 0x80), exact in v_mfma_i32_16x16x64_i8 -- fed from the tile's staged window instead of
+// a strip walk.  Wave w of the four owns output columns 16w .. 16w + 15 of the 64 x 56 tile and all of its rows:
+//   horizontal: per 16-row block of the window ONE product: A = lane (q, r): window row 16 blk + r, bytes 16w + 16q .. + 15 (one
+//     aligned ds_read_b128: the operand layout IS the staged rows), B = the band matrix (output column 4 + 16w + n of the window
+//     <- input columns 16w + k: the same matrix for every column group), C = 128.  D: lane (q, c) holds H - 32768 + 128 of rows
+//     4q .. 4q + 3 at column c, packed (blur_pack) into the i8 digits (a, b) of H - 32768 = 256 a + b;
+//   vertical: those dwords of the four blocks ARE the second product's A operand of the same lane (K order: byte 4 ww + i <->
+//     window row 16 ww + 4q + i; the band matrices T_b are written in that order), B = T_b for output rows 16b .. 16b + 15:
+//     V = 256 (T a) + (T b) + 256 * 32768, pixel = byte 2 of V + 32768; lane (q, n) holds columns 4q .. 4q + 3 of output row
+//     16b + n: one dword of the 16 x 8-tiled plane.
+// REFLECT_101 needs no matrix of its own here: the staging has put the reflected pixels into the window.  No second LDS buffer, no
+// second barrier, 154 instead of 243 vector instructions per wave; rows 62, 63 of the last block meet zero coefficients only.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __attribute__((aligned(16))) int8_t g_blur_tile_tab[5 * 1024];   // [0]: the horizontal band matrix; [1..4]: T_b (1 KB each: 64 lanes x 16 bytes)
+__device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
+  const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x05010400u);   // [d0.b0, d1.b0, d0.b1, d1.b1]
+  const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x05010400u);
+  lo = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+  hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+}
 #define BT_W 64
 #define BT_H ORBFE_BLUR_TILE_H   // 56: (56 + 6) / 2 = 31 row pairs x 16 groups: two 256-thread passes; 7 blocks of 8 output rows = 7 storage tiles
                                 // (58 filled both passes exactly; 56 measured 2-3 % faster: its rows end on storage-tile boundaries)
@@ -1214,18 +1235,37 @@ __device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {
 // destination dword (four pixels) belongs to the tile that holds the first source column of its first pixel, a destination row
 // to the tile that holds its upper source row (BlurTile::j0 .. r1, from the plan): every tap of an owned dword-row then lies
 // inside the window -- staged one dword wider (19 instead of 18) than the blur alone needs --, nothing is computed twice and no
-// halo is added.  Thread = (dword column, three consecutive destination rows); its taps are requested before the window's
-// pixels, so they have arrived when the barrier behind the staging opens.
-#ifndef BT_THREADS
-#define BT_THREADS 256   // threads per tile (128: eleven tiles per CU instead of eight, measured -6 % on the blur alone, +3 % fused)
+// halo is added.  Thread = (dword column, every (BT_THREADS / 16)-th destination row); its horizontal taps are requested before the
+// window's pixels, so they have arrived when the barrier behind the staging opens; the rows' vertical taps go through LDS.
+#ifndef BT_MFMA
+#define BT_MFMA 1        // 0: the two passes on the vector ALUs (v_dot4 / v_dot2 through a second LDS buffer: rounds 1-4)
 #endif
-#define BT_FUSE_ROWS (ORBFE_FUSE_ROWS * 256 / BT_THREADS)   // destination rows per thread of the fused resize (16 dword columns x BT_THREADS / 16 row groups)
+#ifndef BT_NT_STORE
+#define BT_NT_STORE 1   // the blurred planes are next read by the descriptor gather, 0.5 GB of other traffic later: stored non-temporal
+#endif                  // they leave more of the raw levels in the Infinity Cache for FAST (+0.5 % on the step)
+#ifndef BT_MIN_WAVES
+#define BT_MIN_WAVES 2   // with one argument hipcc puts the MFMA results into AGPRs and copies every one back (lesson 31)
+#endif
+#ifndef BT_THREADS
+#define BT_THREADS 128   // threads per tile: with the matrix-core blur a tile needs 5 KB of LDS and 56 registers, so sixteen two-wave tiles
+#endif                   // are resident per CU (256 threads: eight; 64: the fused resize needs 69 registers): 0.506 / 0.474 / 0.492 ms per level chain
 template <bool RESIZE>
-__global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
+__global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
                                                          LevelResize rz) {
+#if BT_MFMA
+  __shared__ __attribute__((aligned(16))) uint8_t in[65 * BT_INP];   // 62 staged rows; the last 16-row block reads two more, the last column
+                                                                     // group 32 bytes past its row (zero coefficients)
+#else
   __shared__ __attribute__((aligned(16))) uint8_t in[(BT_H + 6) * BT_INP];
   __shared__ __attribute__((aligned(16))) uint32_t hbp[((BT_H + 6) / 2) * BT_HP];
+#endif
   const int tid = threadIdx.x;
+#if BT_MFMA
+  // this wave's band matrix and the four vertical ones: 5 x 16 bytes per lane, requested before anything else
+  const int mlane = tid & 63, mwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const v4i* mtab = reinterpret_cast<const v4i*>(g_blur_tile_tab);
+  const v4i HB = mtab[mlane];
+#endif
   // XCD-aware mapping: runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
   const int q = blockIdx.x >> 3;
   const int tile_id = (int)blockIdx.x >= (n_tiles / 64) * 64 ? (int)blockIdx.x : (q >> 3) * 64 + (blockIdx.x & 7) * 8 + (q & 7);
@@ -1235,14 +1275,15 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
   const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
-  // the resize taps of this thread: dword column J (pixels 4J .. 4J + 3), rows Y0 .. Y0 + 2
-  const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1)), Y0 = t.r0 + (tid >> 4) * BT_FUSE_ROWS;
-  uint2 txr[4], tyr[BT_FUSE_ROWS];
+  // the resize taps: this thread's dword column J (pixels 4J .. 4J + 3) in registers; the vertical taps of the tile's (at most 48)
+  // destination rows go through LDS -- a thread's rows are BT_THREADS / 16 apart, held in registers they cost a wave of occupancy
+  const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1));
+  __shared__ uint2 ytap[16 * ORBFE_FUSE_ROWS];
+  uint2 txr[4], tyl = make_uint2(0u, 0u);
   if constexpr (RESIZE) {
 #pragma unroll
     for (int i = 0; i < 4; i++) txr[i] = reinterpret_cast<const uint2*>(rz.xt)[min(4 * J + i, rz.dw - 1)];
-#pragma unroll
-    for (int k = 0; k < BT_FUSE_ROWS; k++) tyr[k] = reinterpret_cast<const uint2*>(rz.yt)[min(Y0 + k, rz.dh - 1)];
+    tyl = reinterpret_cast<const uint2*>(rz.yt)[min(t.r0 + min(tid, 16 * ORBFE_FUSE_ROWS - 1), rz.dh - 1)];
   }
   {
     // (BT_H+6) rows x NC dwords (x = ox-4 .. ox+67, or .. ox+71 with the resize).  Thread -> dword column c = tid % NC and rows
@@ -1286,6 +1327,8 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
       }
     }
   }
+  if constexpr (RESIZE)
+    if (tid < 16 * ORBFE_FUSE_ROWS) ytap[tid] = tyl;
   __syncthreads();
   if constexpr (RESIZE) {
     // level + 1: the destination dword J of rows Y0 .. Y0 + 2.  Per source row three aligned LDS dwords, two v_alignbyte to start
@@ -1293,7 +1336,7 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
     // v_dot2_u32_u16 against (c0, c1); (b * (t >> 4)) >> 16 == mul_hi_u24(b << 12, t & ~15).  Rows differ between the lanes of a
     // wave here, so the horizontal result of a source row is not carried over to the next destination row (a divergent test).
     typedef __attribute__((ext_vector_type(2))) unsigned short us2;
-    if (J < t.j1 && Y0 < t.r1) {
+    if (J < t.j1) {
       const int s00 = (int)(int16_t)(txr[0].x & 0xffff);
       const int base = s00 - (ox - 4);   // >= 4: the dword's first source column lies in this tile column
       const uint32_t sh = (uint32_t)base & 3u;
@@ -1318,15 +1361,16 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
         }
       };
       uint8_t* N = rz.dst + (size_t)blockIdx.y * rz.dimg + 4 * J;
-#pragma unroll
-      for (int k = 0; k < BT_FUSE_ROWS; k++) {
-        const int y = Y0 + k;
-        if (y < t.r1) {
-          const int ra = (int)(int16_t)(tyr[k].x & 0xffff) - (oy - 3), rb = (int)(int16_t)(tyr[k].x >> 16) - (oy - 3);
+      // rows t.r0 + (tid >> 4), + BT_THREADS / 16, ...: the row groups of a wave take consecutive rows
+      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += BT_THREADS / 16) {
+        const int y = t.r0 + yi;
+        {
+          const uint2 ty = ytap[yi];
+          const int ra = (int)(int16_t)(ty.x & 0xffff) - (oy - 3), rb = (int)(int16_t)(ty.x >> 16) - (oy - 3);
           uint32_t h0[4], h1[4];
           hrow(ra, h0);
           hrow(rb, h1);
-          const uint32_t B0 = (tyr[k].y & 0xffffu) << 12, B1 = (tyr[k].y >> 16) << 12;
+          const uint32_t B0 = (ty.y & 0xffffu) << 12, B1 = (ty.y >> 16) << 12;
           uint32_t sm[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) sm[i] = mulhi_u24(B0, h0[i]) + mulhi_u24(B1, h1[i]) + 2u;
@@ -1336,6 +1380,54 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
       }
     }
   }
+#if BT_MFMA
+  {
+    const int q = mlane >> 4, r = mlane & 15;
+    const v4i c128 = {128, 128, 128, 128}, zero = {0, 0, 0, 0};
+    const v4i cfin = {8388608 + 32768, 8388608 + 32768, 8388608 + 32768, 8388608 + 32768};
+    v4i TB[4];   // requested here, used behind the first product: not live through the resize part above
+#pragma unroll
+    for (int b = 0; b < 4; b++) TB[b] = mtab[(1 + b) * 64 + mlane];
+    const uint32_t bstep = (uint32_t)(dst.pitch[lvl] >> 4) << 8;      // 16 rows further: 2 tile rows x (pitch / 16) tiles x 128 bytes
+#pragma unroll
+    for (int g = mwave; g < BT_W / 16; g += BT_THREADS / 64) {   // column group g: output columns 16g .. 16g + 15 of the tile
+      v4i Xh, Xl;
+      {
+        const v4i* arow = reinterpret_cast<const v4i*>(in + r * BT_INP + 16 * g + 16 * q);   // window columns 16g + 16q ..: every tap of the group inside
+        v4i A[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++) A[blk] = arow[blk * BT_INP];   // window rows 16 blk + r
+        int ph[4], pl[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++) {
+          const v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[blk] ^ (int)0x80808080, HB, c128, 0, 0, 0);
+          blur_pack(d, ph[blk], pl[blk]);
+        }
+        Xh = v4i{ph[0], ph[1], ph[2], ph[3]};
+        Xl = v4i{pl[0], pl[1], pl[2], pl[3]};
+      }
+      const int gx = ox + 16 * g + 4 * q;   // a multiple of 4: the four pixels lie in one storage-tile row
+      uint8_t* o = D + blur_tiled_offset(gx, oy + r, dst.pitch[lvl]);   // output row oy + 16 b + r: two storage-tile rows further per block
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const v4i vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(Xh, TB[b], zero, 0, 0, 0);
+        const v4i vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(Xl, TB[b], cfin, 0, 0, 0);
+        const uint32_t r0 = ((uint32_t)vh.x << 8) + (uint32_t)vl.x, r1 = ((uint32_t)vh.y << 8) + (uint32_t)vl.y;
+        const uint32_t r2 = ((uint32_t)vh.z << 8) + (uint32_t)vl.z, r3 = ((uint32_t)vh.w << 8) + (uint32_t)vl.w;
+        const uint32_t out = __builtin_amdgcn_perm(r1, r0, 0x0c0c0602u) | __builtin_amdgcn_perm(r3, r2, 0x06020c0cu);
+        const int row = 16 * b + r;
+        if (gx < w && row < BT_H && oy + row < h) {
+#if BT_NT_STORE
+          __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(o + b * bstep));
+#else
+          *reinterpret_cast<uint32_t*>(o + b * bstep) = out;
+#endif
+        }
+      }
+    }
+  }
+}
+#else
   // horizontal pass: item = (row pair k, 4-pixel group g).  Output x = 4g+i needs window columns 4g+i+1 .. 4g+i+7:
   // two byte windows cut with v_alignbyte and two v_dot4_u32_u8 against the packed taps.  The two rows of a pair
   // are stored interleaved (even row in the low half) so the vertical pass can use v_dot2_u32_u16.
@@ -1397,9 +1489,6 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
     const int gy = oy + 2 * rp, gx = ox + 4 * g;
     if (gx < w) {   // gx is a multiple of 4: the four pixels lie in one tile row; gy is even: row gy + 1 is the next row of the same tile
       uint8_t* o = D + blur_tiled_offset(gx, gy, dst.pitch[lvl]);
-#ifndef BT_NT_STORE
-#define BT_NT_STORE 1   // the blurred planes are next read by the descriptor gather, 0.5 GB of other traffic later: stored non-temporal
-#endif                  // they leave more of the raw levels in the Infinity Cache for FAST (+0.5 % on the step)
 #if BT_NT_STORE
       if (gy < h) __builtin_nontemporal_store(outE, reinterpret_cast<uint32_t*>(o));
       if (gy + 1 < h) __builtin_nontemporal_store(outO, reinterpret_cast<uint32_t*>(o + 16));
@@ -1411,6 +1500,7 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
     }
   }
 }
+#endif
 
 // ---- the same blur on the matrix cores.  A 7-tap pass over a row is Out = In x Band, a band (Toeplitz) matrix of the taps; with
 // pixels as i8 (x ^ 0x80 = x - 128) and taps <= 56 (folded REFLECT_101 taps <= 96) v_mfma_i32_16x16x64_i8 computes it exactly.
@@ -1427,13 +1517,6 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(PyrView src, Pyr
 //     data as A and the band matrix as B the result comes out transposed: lane (q, r) holds columns 4q .. 4q + 3 of output row r,
 //     one dword of the 16 x 8-tiled blurred plane.  V = 256 (T a) + (T b) + 256 * 32768, pixel = (V + 32768) >> 16 = byte 2.
 // A window of four 16-row blocks yields the two middle ones; the walk advances by two blocks.  No LDS, no barrier.
-typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
-  const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x05010400u);   // [d0.b0, d1.b0, d0.b1, d1.b1]
-  const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x05010400u);
-  lo = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-  hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
-}
 #ifndef BLUR_RING
 #define BLUR_RING 2         // passes of source rows in flight per wave (LDS-DMA ring: 2 KB per pass and wave)
 #endif
@@ -2042,7 +2125,21 @@ int orbfe_upload_pattern_floats() {
       wtab[it * 2 + 1] |= (uint32_t)(uint8_t)(int8_t)v << (8 * t);
     }
   }
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ic_w), wtab, sizeof(wtab));
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_ic_w), wtab, sizeof(wtab));
+  if (e != hipSuccess) return (int)e;
+  // band matrices of the tile kernel's matrix-core blur (blur_level_kernel, BT_MFMA): lane (q, n) of a matrix holds 16 bytes.
+  //   horizontal (one for every column group g): byte j <-> window column 16g + 16q + j, output = window column 4 + 16g + n
+  //   vertical, block b:  byte j = 4 ww + i <-> window row 16 ww + 4q + i, output = window row 3 + 16b + n
+  static const int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+  static int8_t bt[5 * 1024];
+  for (int m = 0; m < 5; m++)
+    for (int lane = 0; lane < 64; lane++)
+      for (int j = 0; j < 16; j++) {
+        const int q = lane >> 4, n = lane & 15;
+        const int d = m == 0 ? (16 * q + j) - (4 + n) : (16 * (j >> 2) + 4 * q + (j & 3)) - (3 + 16 * (m - 1) + n);
+        bt[(m * 64 + lane) * 16 + j] = (int8_t)(d >= -3 && d <= 3 ? taps[d + 3] : 0);
+      }
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_tile_tab), bt, sizeof(bt));
 }
 
 int orbfe_set_octree_lds(size_t lds_bytes) {
