@@ -1243,6 +1243,12 @@ __device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
 #ifndef BT_NT_STORE
 #define BT_NT_STORE 1   // the blurred planes are next read by the descriptor gather, 0.5 GB of other traffic later: stored non-temporal
 #endif                  // they leave more of the raw levels in the Infinity Cache for FAST (+0.5 % on the step)
+#ifndef BT_NT_LOAD
+#define BT_NT_LOAD 0     // non-temporal window loads: 0.46 -> 0.53 ms per level chain (neighbouring tiles share lines through L2)
+#endif
+#ifndef BT_XCD_IMAGES
+#define BT_XCD_IMAGES 1  // whole images per XCD instead of runs of eight tiles: 88.1 k -> 90.2 k frames/s (level chain 0.466 -> 0.441 ms)
+#endif
 #ifndef BT_MIN_WAVES
 #define BT_MIN_WAVES 2   // with one argument hipcc puts the MFMA results into AGPRs and copies every one back (lesson 31)
 #endif
@@ -1266,14 +1272,30 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
   const v4i* mtab = reinterpret_cast<const v4i*>(g_blur_tile_tab);
   const v4i HB = mtab[mlane];
 #endif
+#if BT_XCD_IMAGES
+  // whole images per XCD (workgroups go to the XCDs round-robin in linear order): XCD k walks images k, k + 8, ... tile by tile in
+  // raster order, so the halo rows and the 128-byte lines neighbouring tiles share are fetched into ONE L2 once
+  int tile_id = (int)blockIdx.x, img = (int)blockIdx.y;
+  {
+    const unsigned gx = gridDim.x;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned grp = lin / (8u * gx);
+    if (8u * grp + 8u <= gridDim.y) {
+      const unsigned within = lin - grp * 8u * gx;
+      img = (int)(8u * grp + (within & 7u));
+      tile_id = (int)(within >> 3);
+    }
+  }
+#else
   // XCD-aware mapping: runs of 8 raster-consecutive tiles per XCD, interleaved over the 8 XCDs
-  const int q = blockIdx.x >> 3;
+  const int q = blockIdx.x >> 3, img = (int)blockIdx.y;
   const int tile_id = (int)blockIdx.x >= (n_tiles / 64) * 64 ? (int)blockIdx.x : (q >> 3) * 64 + (blockIdx.x & 7) * 8 + (q & 7);
+#endif
   const BlurTile t = tiles[tile_id];
   const int lvl = t.level;
   const int w = src.w[lvl], h = src.h[lvl], pitch = src.pitch[lvl];
-  const uint8_t* S = src.base[lvl] + (size_t)blockIdx.y * src.img_stride[lvl];
-  uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)blockIdx.y * dst.img_stride[lvl];
+  const uint8_t* S = src.base[lvl] + (size_t)img * src.img_stride[lvl];
+  uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)img * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
   // the resize taps: this thread's dword column J (pixels 4J .. 4J + 3) in registers; the vertical taps of the tile's (at most 48)
   // destination rows go through LDS -- a thread's rows are BT_THREADS / 16 apart, held in registers they cost a wave of occupancy
@@ -1303,7 +1325,11 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
         const uint8_t* p0 = S + (size_t)(oy - 3 + r0) * pitch + x;
 #pragma unroll
         for (int k = 0; k < NLD; k++)
+#if BT_NT_LOAD
+          v[k] = r0 + RPP * k < BT_H + 6 ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p0 + (size_t)(RPP * k) * pitch)) : 0u;
+#else
           v[k] = r0 + RPP * k < BT_H + 6 ? *reinterpret_cast<const uint32_t*>(p0 + (size_t)(RPP * k) * pitch) : 0u;
+#endif
       } else {
         const bool whole = x >= 0 && x + 3 < w;
         int gx[4];
@@ -1360,7 +1386,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
           hh[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, u), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
         }
       };
-      uint8_t* N = rz.dst + (size_t)blockIdx.y * rz.dimg + 4 * J;
+      uint8_t* N = rz.dst + (size_t)img * rz.dimg + 4 * J;
       // rows t.r0 + (tid >> 4), + BT_THREADS / 16, ...: the row groups of a wave take consecutive rows
       for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += BT_THREADS / 16) {
         const int y = t.r0 + yi;
