@@ -715,7 +715,11 @@ def main():
             pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_dominant.json")))[-1]   # the latest round's pass
             pmc = json.load(open(pmc_path))
             if pmc["stage"] == dom and pmc["config"] == args.config:
-                traffic = int((pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]) * 1024 * F / pmc["images_per_launch"])
+                if pmc.get("read_kb_by_request_size") is not None:   # fabric requests split by size (TCC_EA0_RDREQ / WRREQ passes): no correction factor
+                    kb = pmc["read_kb_by_request_size"] + pmc["write_kb_by_request_size"]
+                else:
+                    kb = pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]
+                traffic = int(kb * 1024 * F / pmc["images_per_launch"])
                 traffic_src = f"committed rocprofv3 --pmc pass ({pmc['kernel']}, {os.path.basename(pmc_path)}), not measured in this run"
         except Exception:
             pass

@@ -21,8 +21,23 @@ ALG_KB = {  # algorithmic KB per 256-image launch at KITTI geometry (DESIGN.md s
     "pyr_resize": ((1444097 - 36330) + (1444097 - 466616)) * 256 / 1024 / 7,
     "fast_cells": (1444097 + 8 * 4600) * 256 / 1024,
     "gauss_blur7": 2 * 1444097 * 256 / 1024,
+    # the fused level chain: seven launches read a level, write its blurred plane and the next level (averaged per launch), the last
+    # level's launch only blurs
+    "blur_level_kernel<true>": ((1444097 - 36330) + (1444097 - 36330) + (1444097 - 466616)) * 256 / 1024 / 7,
+    "blur_level_kernel<false>": 2 * 36330 * 256 / 1024,
     "orient_describe": 2000 * (749 + 512 + 60) * 256 / 1024,
 }
+
+
+def fabric_kb(c):
+    """Bytes the L2 moved to / from the fabric, from the request counters by size: read requests are 32, 64 or 128 bytes
+    (TCC_EA0_RDREQ counts all, _32B and _128B the two named sizes), write requests 32 or 64 (TCC_EA0_WRREQ / _64B).  None without
+    the passes.  FETCH_SIZE = RDREQ x 64 B tallies a 128-byte request at half its bytes: the guide's x2 for wide streaming loads."""
+    if "TCC_EA0_RDREQ_sum" not in c or "TCC_EA0_WRREQ_sum" not in c:
+        return None, None
+    r, r32, r128 = c["TCC_EA0_RDREQ_sum"], c.get("TCC_EA0_RDREQ_32B_sum", 0), c.get("TCC_EA0_RDREQ_128B_sum", 0)
+    w, w64 = c["TCC_EA0_WRREQ_sum"], c.get("TCC_EA0_WRREQ_64B_sum", 0)
+    return (r128 * 128 + r32 * 32 + max(r - r128 - r32, 0) * 64) / 1024, (w64 * 64 + max(w - w64, 0) * 32) / 1024
 
 
 def short(name):
@@ -90,15 +105,35 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
                     f"{c.get('SQ_WAIT_ANY', 0)/wc:.2f} | {c.get('SQ_WAIT_INST_ANY', 0)/wc:.2f} | "
                     f"{(c.get('SQ_ACTIVE_INST_VALU', 0)*4/(1024*clocks) if clocks else 0):.2f} | {(c.get('SQ_LDS_IDX_ACTIVE', 0)/(256*clocks) if clocks else 0):.2f} | "
                     f"{c.get('SQ_LDS_BANK_CONFLICT', 0)/max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1):.2f} |\n")
-        f.write("\n(`pyr_resize_dot_kernel`: average of the seven level launches.)\n")
+        f.write("\n(`blur_level_kernel<true>` / `pyr_resize_dot_kernel`: average of the seven level launches.)\n")
+        # ---- fabric traffic from the request-size split, against the algorithmic bytes, for every kernel above 0.2 ms per step
+        f.write("\n## Fabric traffic by request size\n\n`TCC_EA0_RDREQ` (all read requests), `_32B`, `_128B` and `TCC_EA0_WRREQ`, `_64B` in passes of their own: read bytes = "
+                "128 x RDREQ_128B + 32 x RDREQ_32B + 64 x the rest, write bytes = 64 x WRREQ_64B + 32 x the rest.  This settles which kernels need the "
+                "guide's x 2 on FETCH_SIZE (= RDREQ x 64 B): all whose read requests are 128-byte ones -- on this build every kernel of the table, the "
+                "4-byte-per-lane window loads of the level kernel and the patch gathers of the describe kernel included.  Per launch; `x calls` = launches of "
+                "that kernel per extractor (or per step for the matcher kernels).\n\n")
+        f.write("| kernel | us | read req | 128 B | 32 B | read MB | write req | 64 B | write MB | traffic MB | alg. MB | traffic / alg. |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for k, c in cs.items():
+            if k.startswith("at::") or "rocclr" in k or k not in avg_us:
+                continue
+            rk, wk = fabric_kb(c)
+            if rk is None or avg_us[k] < 20:
+                continue
+            alg = next((v for a, v in ALG_KB.items() if k.startswith(a)), None)
+            f.write(f"| {k[:40]} | {avg_us[k]:.1f} | {c['TCC_EA0_RDREQ_sum']:.3g} | {c.get('TCC_EA0_RDREQ_128B_sum', 0):.3g} | {c.get('TCC_EA0_RDREQ_32B_sum', 0):.3g} | {rk / 1024:.1f} | "
+                    f"{c['TCC_EA0_WRREQ_sum']:.3g} | {c.get('TCC_EA0_WRREQ_64B_sum', 0):.3g} | {wk / 1024:.1f} | {(rk + wk) / 1024:.1f} | "
+                    f"{'' if alg is None else format(alg / 1024, '.1f')} | {'' if alg is None else format((rk + wk) / alg, '.2f')} |\n")
     dom = max((k for k in cs if k in avg_us and not k.startswith("at::") and "rocclr" not in k), key=lambda k: avg_us[k])
-    stage = {"fast_cells": "fast", "fast_groups": "fast", "orient_describe": "describe", "gauss_blur7": "blur"}
+    stage = {"fast_cells": "fast", "fast_groups": "fast", "orient_describe": "describe", "gauss_blur7": "blur", "blur_level": "pyramid"}
     st = next((v for a, v in stage.items() if dom.startswith(a)), dom)
     wide = any(dom.startswith(w) for w in WIDE)
+    rk, wk = fabric_kb(cs[dom])
     json.dump({"stage": st, "config": config, "kernel": dom, "images_per_launch": 256, "fetch_kb": cs[dom].get("FETCH_SIZE", 0),
                "fetch_correction": 2.0 if wide else 1.0, "write_kb": cs[dom].get("WRITE_SIZE", 0), "avg_us_stats_pass": avg_us[dom],
+               "read_kb_by_request_size": rk, "write_kb_by_request_size": wk,
                "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                         "--warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0; FETCH_SIZE x 2 for 16-byte-per-lane coalesced loads on gfx950 (MI355X_MICROARCH.md, HBM section)"},
+                         "--warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0; FETCH_SIZE x 2 for 16-byte-per-lane coalesced loads on gfx950 (MI355X_MICROARCH.md, HBM section); "
+                         "read / write_kb_by_request_size: TCC_EA0_RDREQ / WRREQ split by request size (passes of their own)"},
               open(out_prefix + "_pmc_dominant.json", "w"), indent=1)
     print("dominant:", dom, avg_us[dom])
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Raw data behind profiles/rNN_*: tools/profile_round.sh <tag> [bench args, e.g. --config tum_bow]   (run through gpurun from the repo root)
 #   one rocprofv3 --kernel-trace --stats pass of bench.py, then separate --pmc passes (never combined with other trace
-#   domains): two SQ sets, FETCH_SIZE, WRITE_SIZE, TCC hit/miss.  tools/profile_report.py turns gpurun_out/<tag>/ into
+#   domains): two SQ sets, FETCH_SIZE, WRITE_SIZE, TCC hit/miss, the fabric requests by size (TCC_EA0_RDREQ / _32B / _128B, TCC_EA0_WRREQ / _64B).  tools/profile_report.py turns gpurun_out/<tag>/ into
 #   the markdown / json files committed under profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; shift; mkdir -p $OUT
@@ -10,7 +10,8 @@ tail -1 $OUT/stats.log | cut -c1-200
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
   echo "pass $i done"
