@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
   // the resize taps: this thread's dword column J (pixels 4J .. 4J + 3) in registers; the vertical taps of the tile's (at most 48)
   // destination rows go through LDS -- a thread's rows are BT_THREADS / 16 apart, held in registers they cost a wave of occupancy
   const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1));
-  __shared__ uint2 ytap[16 * ORBFE_FUSE_ROWS];
+  __shared__ uint4 ytap[16 * ORBFE_FUSE_ROWS];   // per destination row: dword offsets of its two source rows in the window, the two weights << 12
   uint2 txr[4], tyl = make_uint2(0u, 0u);
   if constexpr (RESIZE) {
 #pragma unroll
@@ -1354,7 +1354,10 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
     }
   }
   if constexpr (RESIZE)
-    if (tid < 16 * ORBFE_FUSE_ROWS) ytap[tid] = tyl;
+    if (tid < 16 * ORBFE_FUSE_ROWS) {
+      const int ra = (int)(int16_t)(tyl.x & 0xffff) - (oy - 3), rb = (int)(int16_t)(tyl.x >> 16) - (oy - 3);
+      ytap[tid] = make_uint4((uint32_t)(ra * (BT_INP / 4)), (uint32_t)(rb * (BT_INP / 4)), (tyl.y & 0xffffu) << 12, (tyl.y >> 16) << 12);
+    }
   __syncthreads();
   if constexpr (RESIZE) {
     // level + 1: the destination dword J of rows Y0 .. Y0 + 2.  Per source row three aligned LDS dwords, two v_alignbyte to start
@@ -1374,8 +1377,8 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
         cp[i] = txr[i].y;                                                         // c0 | c1 << 16
       }
       const uint32_t* trow = reinterpret_cast<const uint32_t*>(in + (base & ~3));
-      auto hrow = [&](int r, uint32_t (&hh)[4]) {
-        const uint32_t* p = trow + r * (BT_INP / 4);
+      auto hrow = [&](uint32_t row_off, uint32_t (&hh)[4]) {
+        const uint32_t* p = trow + row_off;
         const uint32_t* p2 = p + 2;
         asm("" : "+v"(p2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow)
         const uint32_t w0 = p[0], w1 = p[1], w2 = *p2;
@@ -1386,22 +1389,21 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
           hh[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, u), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
         }
       };
-      uint8_t* N = rz.dst + (size_t)img * rz.dimg + 4 * J;
       // rows t.r0 + (tid >> 4), + BT_THREADS / 16, ...: the row groups of a wave take consecutive rows
-      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += BT_THREADS / 16) {
-        const int y = t.r0 + yi;
+      uint8_t* N = rz.dst + (size_t)img * rz.dimg + (size_t)(t.r0 + (tid >> 4)) * rz.dpitch + 4 * J;
+      const size_t nstep = (size_t)(BT_THREADS / 16) * rz.dpitch;
+      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += BT_THREADS / 16, N += nstep) {
         {
-          const uint2 ty = ytap[yi];
-          const int ra = (int)(int16_t)(ty.x & 0xffff) - (oy - 3), rb = (int)(int16_t)(ty.x >> 16) - (oy - 3);
+          const uint4 ty = ytap[yi];
           uint32_t h0[4], h1[4];
-          hrow(ra, h0);
-          hrow(rb, h1);
-          const uint32_t B0 = (ty.y & 0xffffu) << 12, B1 = (ty.y >> 16) << 12;
+          hrow(ty.x, h0);
+          hrow(ty.y, h1);
+          const uint32_t B0 = ty.z, B1 = ty.w;
           uint32_t sm[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) sm[i] = mulhi_u24(B0, h0[i]) + mulhi_u24(B1, h1[i]) + 2u;
           const uint32_t P01 = (sm[0] | (sm[1] << 16)) >> 2, P23 = (sm[2] | (sm[3] << 16)) >> 2;   // values <= 255 in bytes 0 and 2
-          *reinterpret_cast<uint32_t*>(N + (size_t)y * rz.dpitch) = __builtin_amdgcn_perm(P23, P01, 0x06040200u);
+          *reinterpret_cast<uint32_t*>(N) = __builtin_amdgcn_perm(P23, P01, 0x06040200u);
         }
       }
     }
