@@ -459,6 +459,9 @@ extern "C" int orbfe_debug_fc_profile(unsigned long long* out, int reset) {
 #else
 #define FC_T(i)
 #endif
+#ifndef FC_PE_COND
+#define FC_PE_COND 1   // the dword in front of a chunk is loaded only for cells whose tile is shifted by a column (-1 %)
+#endif
 #ifndef FC_WAVES_PER_EU
 #define FC_WAVES_PER_EU 7
 #endif
@@ -526,7 +529,11 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
           const int r = min((lane >> 2) + 16 * kk, cd.rows - 1);
           const uint8_t* p = src + (size_t)r * pitch + 16 * c;
           pv[kk] = *reinterpret_cast<const uint4*>(p);
+#if FC_PE_COND
+          pe[kk] = ((cd.x0 & 15) + 3) & 1 ? *reinterpret_cast<const uint32_t*>(p - 4) : 0u;   // only a shifted tile needs it (wave-uniform)
+#else
           pe[kk] = *reinterpret_cast<const uint32_t*>(p - 4);   // the dword in front (x0 >= 16: never before the row)
+#endif
         }
       } else {
         const int items = cd.rows * ndq;
@@ -1805,6 +1812,9 @@ __device__ __forceinline__ void patch_store16(uint8_t* base, int r, int c, const
 #ifndef OD_K
 #define OD_K 8
 #endif
+#ifndef OD_FAKE_TILED_RAW
+#define OD_FAKE_TILED_RAW 0
+#endif
 #if FC_TIMING
 __device__ unsigned long long g_od_prof[4096 * 8];
 extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
@@ -1900,7 +1910,12 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     for (int j = 0; j < 2; j++) {
       const int i = lane + WAVE * j;
       const int r = i / 3, c = i - r * 3;
+#if OD_FAKE_TILED_RAW   // timing experiment only (wrong angles): the raw patch fetched from the TILED blurred plane -- what the gather would cost with the
+      (void)pitch; (void)plane;   // raw levels in 16 x 8 tiles: 0.346 -> 0.277 ms (DESIGN lesson 44)
+      vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(P.blur.base[level] + (size_t)img * P.blur.img_stride[level] + blur_tiled_offset(ax_o + 16 * c, cy - 15 + r, P.blur.pitch[level])) : make_uint4(0, 0, 0, 0);
+#else
       vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 16 * c) : make_uint4(0, 0, 0, 0);
+#endif
     }
   };
   auto issue_dsc = [&](int k, uint4 vd[3]) {
