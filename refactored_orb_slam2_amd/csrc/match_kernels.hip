@@ -1310,12 +1310,29 @@ struct SmLevel {
 // own values live in the lanes of its DPP row, reductions are four row rotations, the first-minimum / parabola epilogue runs with
 // lane k = shift k.  A keypoint that drops out (no candidate, window outside the level) only idles its row; the wave leaves when
 // all four have.
+#ifndef SM_XCD_PAIRS
+#define SM_XCD_PAIRS 1
+#endif
 __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
-  const int pair = blockIdx.y;
+  int pair = blockIdx.y, bx = blockIdx.x;
+#if SM_XCD_PAIRS
+  // whole pairs per XCD (workgroups go to the XCDs round-robin in linear order): XCD k works on pairs k, k + 8, ...: the two
+  // pyramids a pair's SAD windows are cut from (3 MB) stay in one L2 instead of every pair passing through all eight
+  {
+    const unsigned gx = gridDim.x;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned g8 = lin / (8u * gx);
+    if (8u * g8 + 8u <= gridDim.y) {
+      const unsigned within = lin - g8 * 8u * gx;
+      pair = (int)(8u * g8 + (within & 7u));
+      bx = (int)(within >> 3);
+    }
+  }
+#endif
   const int lane = threadIdx.x & (WAVE - 1);
   const int sub = lane & (SM_G - 1);
   const int grp = threadIdx.x / SM_G;
-  const int iL = blockIdx.x * SM_KPB + grp;
+  const int iL = bx * SM_KPB + grp;
   __shared__ SmLevel s_lv[ORBFE_MAX_LEVELS];
   __shared__ float s_r[ORBFE_MAX_LEVELS];  // r = 2 * scale[octave] of a right keypoint (L/src/Frame.cc:496)
   __shared__ __attribute__((aligned(16))) uint8_t sad_win[SM_KPB][SAD_WIN];
