@@ -1262,8 +1262,8 @@ __device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
 #ifndef BT_THREADS
 #define BT_THREADS 128   // threads per tile: with the matrix-core blur a tile needs 5 KB of LDS and 56 registers, so sixteen two-wave tiles
 #endif                   // are resident per CU (256 threads: eight; 64: the fused resize needs 69 registers): 0.506 / 0.474 / 0.492 ms per level chain
-template <bool RESIZE>
-__global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
+template <bool RESIZE, int THREADS>   // THREADS per tile: THREADS for batches (tiles in flight), 256 for a handful of images (latency of a tile)
+__global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrView src, PyrView dst, const BlurTile* __restrict__ tiles, int n_tiles,
                                                          LevelResize rz) {
 #if BT_MFMA
   __shared__ __attribute__((aligned(16))) uint8_t in[65 * BT_INP];   // 62 staged rows; the last 16-row block reads two more, the last column
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)img * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
   // the resize taps: this thread's dword column J (pixels 4J .. 4J + 3) in registers; the vertical taps of the tile's (at most 48)
-  // destination rows go through LDS -- a thread's rows are BT_THREADS / 16 apart, held in registers they cost a wave of occupancy
+  // destination rows go through LDS -- a thread's rows are THREADS / 16 apart, held in registers they cost a wave of occupancy
   const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1));
   __shared__ uint4 ytap[16 * ORBFE_FUSE_ROWS];   // per destination row: dword offsets of its two source rows in the window, the two weights << 12
   uint2 txr[4], tyl = make_uint2(0u, 0u);
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
     // whole.
     uint32_t* in32 = reinterpret_cast<uint32_t*>(in);
     constexpr int NC = RESIZE ? 19 : 18;
-    constexpr int RPP = BT_THREADS / NC, NLD = (BT_H + 6 + RPP - 1) / RPP;
+    constexpr int RPP = THREADS / NC, NLD = (BT_H + 6 + RPP - 1) / RPP;
     const int r0 = tid / NC, c = tid - r0 * NC;
     const int x = ox - 4 + 4 * c;
     uint32_t v[NLD];
@@ -1396,10 +1396,10 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
           hh[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, u), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
         }
       };
-      // rows t.r0 + (tid >> 4), + BT_THREADS / 16, ...: the row groups of a wave take consecutive rows
+      // rows t.r0 + (tid >> 4), + THREADS / 16, ...: the row groups of a wave take consecutive rows
       uint8_t* N = rz.dst + (size_t)img * rz.dimg + (size_t)(t.r0 + (tid >> 4)) * rz.dpitch + 4 * J;
-      const size_t nstep = (size_t)(BT_THREADS / 16) * rz.dpitch;
-      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += BT_THREADS / 16, N += nstep) {
+      const size_t nstep = (size_t)(THREADS / 16) * rz.dpitch;
+      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += THREADS / 16, N += nstep) {
         {
           const uint4 ty = ytap[yi];
           uint32_t h0[4], h1[4];
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
     for (int b = 0; b < 4; b++) TB[b] = mtab[(1 + b) * 64 + mlane];
     const uint32_t bstep = (uint32_t)(dst.pitch[lvl] >> 4) << 8;      // 16 rows further: 2 tile rows x (pitch / 16) tiles x 128 bytes
 #pragma unroll
-    for (int g = mwave; g < BT_W / 16; g += BT_THREADS / 64) {   // column group g: output columns 16g .. 16g + 15 of the tile
+    for (int g = mwave; g < BT_W / 16; g += THREADS / 64) {   // column group g: output columns 16g .. 16g + 15 of the tile
       v4i Xh, Xl;
       {
         const v4i* arow = reinterpret_cast<const v4i*>(in + r * BT_INP + 16 * g + 16 * q);   // window columns 16g + 16q ..: every tap of the group inside
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
   // horizontal pass: item = (row pair k, 4-pixel group g).  Output x = 4g+i needs window columns 4g+i+1 .. 4g+i+7:
   // two byte windows cut with v_alignbyte and two v_dot4_u32_u8 against the packed taps.  The two rows of a pair
   // are stored interleaved (even row in the low half) so the vertical pass can use v_dot2_u32_u16.
-  for (int it = tid; it < ((BT_H + 6) / 2) * 16; it += BT_THREADS) {
+  for (int it = tid; it < ((BT_H + 6) / 2) * 16; it += THREADS) {
     const int k = it >> 4, g = it & 15;
     uint32_t o[2][4];
 #pragma unroll
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_MIN_WAVES) void blur_level_kernel(Py
   // vertical pass: thread = (4-pixel group g, row pair rp): output rows 2rp, 2rp+1 from the row pairs rp .. rp+3
   {
     typedef __attribute__((ext_vector_type(2))) unsigned short us2;
-    for (int it = tid; it < (BT_H / 2) * 16; it += BT_THREADS) {
+    for (int it = tid; it < (BT_H / 2) * 16; it += THREADS) {
     const int g = it & 15, rp = it >> 4;
     uint4 P[4];
 #pragma unroll
@@ -2127,12 +2127,20 @@ void orbfe_launch_blur(const PyrView& src, const PyrView& dst, const BlurTile* t
 void orbfe_launch_blur_level(const PyrView& src, const PyrView& dst, const BlurTile* tiles, int n_tiles, const LevelResize* rz,
                              int n_images, hipStream_t s) {
   if (n_tiles <= 0) return;
-  dim3 block(BT_THREADS), grid(n_tiles, n_images);
+  dim3 grid(n_tiles, n_images);
 #ifndef BT_LDS_PAD
 #define BT_LDS_PAD 0   // unused dynamic LDS: an occupancy limiter for experiments
 #endif
-  if (rz) hipLaunchKernelGGL(blur_level_kernel<true>, grid, block, BT_LDS_PAD, s, src, dst, tiles, n_tiles, *rz);
-  else hipLaunchKernelGGL(blur_level_kernel<false>, grid, block, BT_LDS_PAD, s, src, dst, tiles, n_tiles, LevelResize{});
+  // a batch wants many tiles in flight per CU (two waves per tile); a one- or two-image call has fewer tiles than the chip has CUs
+  // and wants each tile done quickly (four waves per tile: 0.292 -> 0.27 ms for a stereo pair's two extractions)
+  const bool few = n_images <= 8;
+  if (rz) {
+    if (few) hipLaunchKernelGGL((blur_level_kernel<true, 256>), grid, dim3(256), BT_LDS_PAD, s, src, dst, tiles, n_tiles, *rz);
+    else hipLaunchKernelGGL((blur_level_kernel<true, BT_THREADS>), grid, dim3(BT_THREADS), BT_LDS_PAD, s, src, dst, tiles, n_tiles, *rz);
+  } else {
+    if (few) hipLaunchKernelGGL((blur_level_kernel<false, 256>), grid, dim3(256), BT_LDS_PAD, s, src, dst, tiles, n_tiles, LevelResize{});
+    else hipLaunchKernelGGL((blur_level_kernel<false, BT_THREADS>), grid, dim3(BT_THREADS), BT_LDS_PAD, s, src, dst, tiles, n_tiles, LevelResize{});
+  }
 }
 
 void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s) {
