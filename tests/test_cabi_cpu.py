@@ -80,3 +80,25 @@ def test_argument_validation_without_compute(L):
     assert L.orbfe_extractor_create(C.byref(bad), -1, C.byref(h)) == _lib.ERR_INVALID
     assert L.orbfe_extractor_destroy(None) == 0 and L.orbfe_matcher_destroy(None) == 0
     assert L.orbfe_sync(None) == _lib.ERR_INVALID
+
+
+def test_pipeline_handle_validates_and_has_no_cpu_fallback(L):
+    """orbfe_pipeline_* (the batched stereo step behind one handle, for hosts without the HIP runtime): the config struct has the
+    header's layout, a bad configuration is refused before anything touches a device, and without a device creation is an error."""
+    from refactored_orb_slam2_amd.pipeline import PipelineConfig, StereoPipeline
+    assert C.sizeof(PipelineConfig) == 64
+    L.orbfe_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_int, C.POINTER(C.c_void_p)]
+    h = C.c_void_p(None)
+    good = PipelineConfig(_lib.Params(2000, 1.2, 8, 20, 7), 1241, 376, 8, 2, 718.856, 718.856, 607.19, 185.21, 386.14, 7.0, 1)
+    assert L.orbfe_pipeline_create(None, -1, C.byref(h)) == _lib.ERR_INVALID
+    assert L.orbfe_pipeline_create(C.byref(good), -1, None) == _lib.ERR_INVALID
+    for field, value in (("batch", 0), ("slots", 0), ("slots", 5), ("width", 0), ("fx", 0.0)):
+        bad = PipelineConfig.from_buffer_copy(bytes(good))
+        setattr(bad, field, value)
+        assert L.orbfe_pipeline_create(C.byref(bad), -1, C.byref(h)) == _lib.ERR_INVALID and not h.value, field
+    L.orbfe_pipeline_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    assert L.orbfe_pipeline_submit(None, 0, 1, 0) == _lib.ERR_INVALID and L.orbfe_pipeline_destroy(None) == 0
+    if not _gpu_present(L):
+        assert L.orbfe_pipeline_create(C.byref(good), -1, C.byref(h)) == _lib.ERR_NO_DEVICE and not h.value
+        with pytest.raises(_lib.OrbfeError):
+            StereoPipeline(1241, 376, 8, 718.856, 718.856, 607.19, 185.21, 386.14)

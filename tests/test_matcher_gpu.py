@@ -1098,3 +1098,59 @@ def test_stereo_matches_one_pair_host_api(geom):
     with pytest.raises(_lib.OrbfeError):
         compute_stereo_matches(exL, exR, kL, dL, kR, dR, mbf, 0.0)
     exL.close(); exR.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_handle_equals_the_oracle_across_chunks():
+    """refactored_orb_slam2_amd.pipeline.StereoPipeline (ctypes mirror of orbfe_pipeline_*): seven EuRoC-size stereo frames in chunks of
+    3 + 3 + 1 through two buffer sets -- every frame's keypoints, descriptors, mvuRight / mvDepth and its SearchByProjection(cur, last)
+    assignment against the points of the frame before it (the last frame of the previous chunk for a chunk's first frame) equal the
+    oracle's; a chunk with no frames and a re-submitted slot are harmless; per-frame poses written into the slot are honoured."""
+    from refactored_orb_slam2_amd._lib import TRACK_POSE_DTYPE, UNPROJECT_CAM_DTYPE
+    from refactored_orb_slam2_amd.pipeline import StereoPipeline
+    W, H, NF, N, F = 752, 480, 1200, 7, 3
+    fx, fy, cx, cy, bf = (np.float32(v) for v in (435.2047, 435.2047, 367.4517, 252.2008, 47.9064))
+    pairs = synth.sequence(W, H, N, seq=31, stereo=True)
+    oL, oR = ol.OracleExtractor(NF), ol.OracleExtractor(NF)
+    sf, isf = oL.scale_factors, oL.inv_scale_factors
+    cam = np.zeros(1, UNPROJECT_CAM_DTYPE); pose = np.zeros(1, TRACK_POSE_DTYPE)
+    eye = np.eye(3, dtype=np.float32).reshape(9)
+    cam["Rwc"] = eye; cam["cx"] = cx; cam["cy"] = cy; cam["invfx"] = np.float32(1) / fx; cam["invfy"] = np.float32(1) / fy
+    pose["Rcw"] = eye; pose["fx"] = fx; pose["fy"] = fy; pose["cx"] = cx + np.float32(-2.0); pose["cy"] = cy; pose["mbf"] = bf
+    pose["max_x"] = W; pose["max_y"] = H; pose["th"] = 7.0; pose["scale_factors"][0, :8] = sf
+    exp, prev = [], None
+    for (Li, Ri) in pairs:
+        kL, dL = oL(Li); kR, dR = oR(Ri)
+        _, ur, depth = ol.compute_stereo_matches(kL, dL, kR, dR, [oL.level_pixels(l) for l in range(8)], [oR.level_pixels(l) for l in range(8)],
+                                                 sf, isf, float(bf), float(bf / fx))
+        nm, assigned = 0, np.full(len(kL), -1, np.int32)
+        if prev is not None:
+            nm, assigned, _ = ol.OracleFrame(kL, dL, sf, 0, W, 0, H, ur).search_by_projection_frame(ol.track_queries(pose, prev), True)
+        exp.append((kL, dL, ur, depth, nm, assigned))
+        prev = ol.unproject_stereo(cam, kL, dL, depth)
+    with StereoPipeline(W, H, F, float(fx), float(fy), float(cx), float(cy), float(bf), 7.0, n_features=NF, slots=2) as p:
+        for s in range(2):
+            p.poses(s)["cx"] = cx + np.float32(-2.0)     # the synthetic sequence moves 2 px per frame: the prediction follows it
+        got = []
+        chunks = [list(range(0, 3)), list(range(3, 6)), [], [6]]       # an empty chunk in between changes nothing
+        for k, idx in enumerate(chunks):
+            s = k % 2
+            p.wait(s)                                                  # the slot's previous results have been consumed below
+            for j, i in enumerate(idx):
+                p.left(s)[j, :, :W] = pairs[i][0]; p.right(s)[j, :, :W] = pairs[i][1]
+            p.submit(s, len(idx), has_predecessor=bool(got) or k > 0)
+            p.wait(s)
+            out = p.output(s)
+            assert int(out["n_left"][len(idx):].sum()) == 0           # rows behind the chunk carry no keypoints
+            for j, i in enumerate(idx):
+                n = int(out["n_left"][j])
+                got.append((out["kps_left"][j, :n].copy(), out["desc_left"][j, :n].copy(), out["u_right"][j, :n].copy(),
+                            out["depth"][j, :n].copy(), int(out["n_tracked"][j]), out["assigned"][j, :n].copy()))
+        assert len(got) == N
+        for i, (g, e) in enumerate(zip(got, exp)):
+            np.testing.assert_array_equal(g[0], e[0], err_msg=f"keypoints of frame {i}")
+            np.testing.assert_array_equal(g[1], e[1]); np.testing.assert_array_equal(g[2], e[2], err_msg=f"mvuRight of frame {i}")
+            np.testing.assert_array_equal(g[3], e[3])
+            assert g[4] == e[4], (i, g[4], e[4])
+            np.testing.assert_array_equal(g[5], e[5], err_msg=f"tracked assignment of frame {i}")
+        assert exp[4][4] > 300
