@@ -141,9 +141,14 @@ int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* imgs, int n_im
 int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_imgs, int n_images, int w, int h, int stride,
                                size_t image_pitch, orbfe_keypoint* d_kps, uint8_t* d_desc, int cap,
                                int32_t* d_n_out, void* stream);
-/* Device pointer + geometry of pyramid level `level` of image `image` of the last device batch. */
+/* Device pointer + geometry of pyramid level `level` of image `image` of the last device batch.  Level 0 is row-major (rows
+ * `pitch` bytes apart).  Levels >= 1 are row-major too when a stand-alone resize kernel wrote them, but the fused level chain (the
+ * default) stores the levels it writes in TILES of 16 pixels x 8 rows = 128 bytes, tiles in raster order, pitch / 16 tiles per tile
+ * row: pixel (x, y) at ((y >> 3) * (pitch >> 4) + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15); orbfe_device_pyramid_layout says which.
+ * orbfe_pyramid_level / orbfe_pyramid_levels always deliver row-major host copies. */
 int orbfe_device_pyramid(const orbfe_extractor* e, int image, int level, const uint8_t** d_ptr, int* pitch,
                          int* w, int* h);
+int orbfe_device_pyramid_layout(const orbfe_extractor* e, int level, int* tiled);   /* *tiled = 1: the 16 x 8 tiles described above */
 int orbfe_sync(orbfe_extractor* e);   /* wait for the handle's stream(s) */
 /* Waits for the handle's stream and returns ORBFE_ERR_CAPACITY if a kernel of an earlier (asynchronous)
  * batch flagged an internal table overflow; ORBFE_OK otherwise. */

@@ -92,7 +92,7 @@ EXPORTS = [
     "orbfe_extractor_levels", "orbfe_extractor_scale_factors", "orbfe_extractor_inv_scale_factors",
     "orbfe_extractor_sigma2", "orbfe_extractor_inv_sigma2", "orbfe_extractor_features_per_level",
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_pyramid_level", "orbfe_pyramid_level_size", "orbfe_pyramid_levels",
-    "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_device_pyramid", "orbfe_sync",
+    "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_device_pyramid", "orbfe_device_pyramid_layout", "orbfe_sync",
     "orbfe_device_status", "orbfe_debug_candidates", "orbfe_debug_blurred", "orbfe_debug_blur_kernel", "orbfe_debug_pyramid",
     "orbfe_debug_level_keypoints", "orbfe_profile_enable", "orbfe_stage_times",
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",

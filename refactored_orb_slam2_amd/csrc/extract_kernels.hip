@@ -521,18 +521,29 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
     {
       const int ndq = ((cd.x0 & 15) + (((cd.x0 & 15) + 3) & 1) + cd.cols + 15) >> 4;   // chunks of the SHIFTED row
       const uint8_t* src = plane + (size_t)cd.y0 * pitch + (cd.x0 & ~15);
+      // a 16-byte chunk of a TILED level is one tile row; the dword in front of it the last dword of the tile row to its left
+      const bool ltiled = (pyr.tiled >> level) & 1u;
+      const uint32_t tstep = (uint32_t)(pitch >> 4) << 7;
+      auto chunk_ptr = [&](int r, int c) {
+        const int y = cd.y0 + r;
+        return ltiled ? plane + (uint32_t)(y >> 3) * tstep + ((uint32_t)(((cd.x0 & ~15) >> 4) + c) << 7) + (uint32_t)((y & 7) * 16)
+                      : src + (size_t)r * pitch + 16 * c;
+      };
+      auto front_ptr = [&](int r, int c, const uint8_t* p) {   // x0 >= 16: never before the row
+        return ltiled ? p - 128 + 12 : p - 4;
+      };
       if constexpr (PB == 64) {
         // four 16-byte chunks per staged row: lane -> (row, chunk) by shift and mask, sixteen rows per round
         const int c = min(lane & 3, ndq - 1);
 #pragma unroll
         for (int kk = 0; kk < NLD; kk++) {
           const int r = min((lane >> 2) + 16 * kk, cd.rows - 1);
-          const uint8_t* p = src + (size_t)r * pitch + 16 * c;
+          const uint8_t* p = chunk_ptr(r, c);
           pv[kk] = *reinterpret_cast<const uint4*>(p);
 #if FC_PE_COND
-          pe[kk] = ((cd.x0 & 15) + 3) & 1 ? *reinterpret_cast<const uint32_t*>(p - 4) : 0u;   // only a shifted tile needs it (wave-uniform)
+          pe[kk] = ((cd.x0 & 15) + 3) & 1 ? *reinterpret_cast<const uint32_t*>(front_ptr(r, c, p)) : 0u;   // only a shifted tile needs it (wave-uniform)
 #else
-          pe[kk] = *reinterpret_cast<const uint32_t*>(p - 4);   // the dword in front (x0 >= 16: never before the row)
+          pe[kk] = *reinterpret_cast<const uint32_t*>(front_ptr(r, c, p));   // the dword in front
 #endif
         }
       } else {
@@ -542,9 +553,9 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         for (int kk = 0; kk < NLD; kk++) {
           const int i = min(lane + WAVE * kk, items - 1);
           const int r = (int)((i + 0.5f) * inv), c = i - r * ndq;
-          const uint8_t* p = src + (size_t)r * pitch + 16 * c;
+          const uint8_t* p = chunk_ptr(r, c);
           pv[kk] = *reinterpret_cast<const uint4*>(p);
-          pe[kk] = *reinterpret_cast<const uint32_t*>(p - 4);
+          pe[kk] = *reinterpret_cast<const uint32_t*>(front_ptr(r, c, p));
         }
       }
     }
@@ -1203,9 +1214,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 // memory request per window row in a row-major plane (~55 per keypoint).  They are therefore stored TILED: 16 pixels x 8 rows
 // = one 128-byte line, tiles in raster order (pitch / 16 tiles per tile row).  A window then touches ~4 x 6 tiles.
 // Byte offset of pixel (x, y); x, y >= 0:
-__device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) {   // a plane is < 2^25 bytes (4095 x 4095)
-  return (((uint32_t)(y >> 3) * (uint32_t)(pitch >> 4) + (uint32_t)(x >> 4)) << 7) + (uint32_t)((y & 7) * 16 + (x & 15));
-}
+__device__ __forceinline__ uint32_t blur_tiled_offset(int x, int y, int pitch) { return orbfe_tiled_offset(x, y, pitch); }   // orbfe_internal.h
 // 7x7 sigma-2 Gaussian, OpenCV's 8.8 fixed-point taps [18,34,48,56,48,34,18], exact 16.16 accumulation,
 // round half up.  One 64 x BT_H (56) output tile per workgroup, separable through LDS.  Interior tiles stage the
 // (64+8) x (56+6) input window with aligned dword loads; tiles touching a level edge take the byte path with
@@ -1231,10 +1240,19 @@ __device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
   lo = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
   hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
 }
+#ifndef BT_MFMA
+#define BT_MFMA 1        // 0: the two passes on the vector ALUs (v_dot4 / v_dot2 through a second LDS buffer: rounds 1-4)
+#endif
 #define BT_W 64
 #define BT_H ORBFE_BLUR_TILE_H   // 56: (56 + 6) / 2 = 31 row pairs x 16 groups: two 256-thread passes; 7 blocks of 8 output rows = 7 storage tiles
                                 // (58 filled both passes exactly; 56 measured 2-3 % faster: its rows end on storage-tile boundaries)
+#if BT_MFMA
+#define BT_INP 96   // LDS pitch (bytes) of the input window: six 16-byte pieces, column j <-> level x = ox - 16 + j (a tiled level arrives
+#define BT_COL0 12  // as whole tile rows); BT_COL0: the column of x = ox - 4, where the window the two passes need begins
+#else
 #define BT_INP 80   // LDS pitch (bytes) of the input window: column j <-> level x = ox - 4 + j
+#define BT_COL0 0
+#endif
 #define BT_HP 68    // LDS pitch (dwords) of one row PAIR of the horizontal-pass result (two u16 rows interleaved)
 // RESIZE: the tile also produces its part of level + 1 (cv::resize INTER_LINEAR, the arithmetic of pyr_resize_dot_kernel) from
 // the window it has staged for the blur: the pyramid chain and the blur then read every level ONCE, and the seven resize
@@ -1244,9 +1262,6 @@ __device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
 // inside the window -- staged one dword wider (19 instead of 18) than the blur alone needs --, nothing is computed twice and no
 // halo is added.  Thread = (dword column, every (BT_THREADS / 16)-th destination row); its horizontal taps are requested before the
 // window's pixels, so they have arrived when the barrier behind the staging opens; the rows' vertical taps go through LDS.
-#ifndef BT_MFMA
-#define BT_MFMA 1        // 0: the two passes on the vector ALUs (v_dot4 / v_dot2 through a second LDS buffer: rounds 1-4)
-#endif
 #ifndef BT_NT_STORE
 #define BT_NT_STORE 1   // the blurred planes are next read by the descriptor gather, 0.5 GB of other traffic later: stored non-temporal
 #endif                  // they leave more of the raw levels in the Infinity Cache for FAST (+0.5 % on the step)
@@ -1304,6 +1319,7 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
   const uint8_t* S = src.base[lvl] + (size_t)img * src.img_stride[lvl];
   uint8_t* D = const_cast<uint8_t*>(dst.base[lvl]) + (size_t)img * dst.img_stride[lvl];
   const int ox = t.tx * BT_W, oy = t.ty * BT_H;
+  const bool stiled = (src.tiled >> lvl) & 1u;   // the level this launch reads lies in 16 x 8 tiles (written by the launch before it)
   // the resize taps: this thread's dword column J (pixels 4J .. 4J + 3) in registers; the vertical taps of the tile's (at most 48)
   // destination rows go through LDS -- a thread's rows are THREADS / 16 apart, held in registers they cost a wave of occupancy
   const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1));
@@ -1327,8 +1343,17 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
     const int x = ox - 4 + 4 * c;
     uint32_t v[NLD];
     const bool interior = oy >= 3 && oy + BT_H + 3 <= h && ox >= 4 && ox - 4 + 4 * NC <= w;
-    if (r0 < RPP) {
-      if (interior) {
+    const bool tilepath = stiled && BT_COL0 != 0;   // a tiled level arrives as whole tile rows (below), also at the level's edges
+    if (r0 < RPP && !tilepath) {
+      if (interior && stiled) {
+        // (vector-ALU build) an aligned dword of a tiled level lies inside one tile row: the same loads, tile addresses
+        const uint32_t xoff = ((uint32_t)(x >> 4) << 7) + (uint32_t)(x & 15), tstep = (uint32_t)(pitch >> 4) << 7;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+          const int y = oy - 3 + r0 + RPP * k;
+          v[k] = r0 + RPP * k < BT_H + 6 ? *reinterpret_cast<const uint32_t*>(S + (uint32_t)(y >> 3) * tstep + (uint32_t)((y & 7) * 16) + xoff) : 0u;
+        }
+      } else if (interior) {
         const uint8_t* p0 = S + (size_t)(oy - 3 + r0) * pitch + x;
 #pragma unroll
         for (int k = 0; k < NLD; k++)
@@ -1347,18 +1372,72 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
           const int r = r0 + RPP * k;
           v[k] = 0u;
           if (r < BT_H + 6) {
-            const uint8_t* row = S + (size_t)reflect101(oy + r - 3, h) * pitch;
-            if (whole) v[k] = *reinterpret_cast<const uint32_t*>(row + x);
-            else v[k] = (uint32_t)row[gx[0]] | ((uint32_t)row[gx[1]] << 8) | ((uint32_t)row[gx[2]] << 16) | ((uint32_t)row[gx[3]] << 24);
+            const int yy = reflect101(oy + r - 3, h);
+            auto px = [&](int xx) { return (uint32_t)S[orbfe_level_offset(xx, yy, pitch, stiled)]; };
+            if (whole) v[k] = *reinterpret_cast<const uint32_t*>(S + orbfe_level_offset(x, yy, pitch, stiled));
+            else v[k] = px(gx[0]) | (px(gx[1]) << 8) | (px(gx[2]) << 16) | (px(gx[3]) << 24);
           }
         }
       }
 #pragma unroll
       for (int k = 0; k < NLD; k++) {
         const int r = r0 + RPP * k;
-        if (r < BT_H + 6) in32[r * (BT_INP / 4) + c] = v[k];
+        if (r < BT_H + 6) in32[r * (BT_INP / 4) + BT_COL0 / 4 + c] = v[k];
       }
     }
+#if BT_MFMA
+    if (tilepath) {
+      // A tiled level arrives as whole tile rows: the window's 6 x 9 tiles, eight lanes per tile (one 16-byte tile row each), so a
+      // load instruction covers eight complete 128-byte lines -- 54 lines per window where the row-major form touches 124.
+      // Rows of the first and last tile row outside the window are dropped at the store; tiles outside the plane are not read.
+      constexpr int NP = (6 * 9 * 8 + THREADS - 1) / THREADS;
+      const int ty0 = (oy - 3) >> 3, tx0 = (ox - 16) >> 4;   // (arithmetic shifts: -1 in the first tile row / column)
+      const int tiles_y = (h + 7) >> 3, tiles_x = pitch >> 4;
+      const uint32_t tstep = (uint32_t)tiles_x << 7;
+      uint4 pv[NP];
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int pid = min(tid + k * THREADS, 6 * 9 * 8 - 1);
+        const int rr = pid & 7, tl = pid >> 3;
+        const int tyi = (int)((tl + 0.5f) * (1.0f / 6.0f)), txi = tl - tyi * 6;
+        const int tr = min(max(ty0 + tyi, 0), tiles_y - 1), tc = min(max(tx0 + txi, 0), tiles_x - 1);   // clamped: a valid address in any case
+        pv[k] = *reinterpret_cast<const uint4*>(S + (uint32_t)tr * tstep + ((uint32_t)tc << 7) + (uint32_t)(rr * 16));
+      }
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int pid = tid + k * THREADS;
+        const int rr = pid & 7, tl = pid >> 3;
+        const int tyi = (int)((tl + 0.5f) * (1.0f / 6.0f)), txi = tl - tyi * 6;
+        const int wr = (ty0 + tyi) * 8 + rr - (oy - 3);
+        if (pid < 6 * 9 * 8 && wr >= 0 && wr < BT_H + 6) *reinterpret_cast<uint4*>(in + wr * BT_INP + 16 * txi) = pv[k];
+      }
+      if (!interior) {
+        // REFLECT_101 at the level's edges, inside LDS: what the passes read outside the level is within three pixels of it, and
+        // the pixels those reflect to lie inside the window.  Columns first (rows inside the level), then whole rows.
+        __syncthreads();
+        {
+          const int nl = ox == 0 ? 3 : 0, nr = w < ox - 4 + 4 * NC ? 3 : 0;   // x = -3 .. -1; x = w .. w + 2
+          for (int i = tid; i < (BT_H + 6) * (nl + nr); i += THREADS) {
+            const int wr = (int)((i + 0.5f) * (1.0f / (float)(nl + nr))), j = i - wr * (nl + nr);
+            const int xx = j < nl ? j - 3 : w + (j - nl);
+            const int y = oy - 3 + wr;
+            if (y >= 0 && y < h && xx - (ox - 16) < BT_INP)
+              in[wr * BT_INP + (xx - (ox - 16))] = in[wr * BT_INP + (reflect101(xx, w) - (ox - 16))];
+          }
+        }
+        __syncthreads();
+        {
+          const int nt = oy == 0 ? 3 : 0, nb = h < oy + BT_H + 3 ? 3 : 0;     // y = -3 .. -1; y = h .. h + 2
+          for (int i = tid; i < (nt + nb) * (BT_INP / 4); i += THREADS) {
+            const int j = (int)((i + 0.5f) * (1.0f / (float)(BT_INP / 4))), cdw = i - j * (BT_INP / 4);
+            const int y = j < nt ? j - 3 : h + (j - nt);
+            const int wr = y - (oy - 3), ws = reflect101(y, h) - (oy - 3);
+            if (wr >= 0 && wr < BT_H + 6) in32[wr * (BT_INP / 4) + cdw] = in32[ws * (BT_INP / 4) + cdw];
+          }
+        }
+      }
+    }
+#endif
   }
   if constexpr (RESIZE)
     if (tid < 16 * ORBFE_FUSE_ROWS) {
@@ -1374,7 +1453,7 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
     typedef __attribute__((ext_vector_type(2))) unsigned short us2;
     if (J < t.j1) {
       const int s00 = (int)(int16_t)(txr[0].x & 0xffff);
-      const int base = s00 - (ox - 4);   // >= 4: the dword's first source column lies in this tile column
+      const int base = s00 - (ox - 4) + BT_COL0;   // >= 4 + BT_COL0: the dword's first source column lies in this tile column
       const uint32_t sh = (uint32_t)base & 3u;
       uint32_t sel[4], cp[4];
 #pragma unroll
@@ -1397,9 +1476,18 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
         }
       };
       // rows t.r0 + (tid >> 4), + THREADS / 16, ...: the row groups of a wave take consecutive rows
+#if ORBFE_TILED_LEVELS
+      // level + 1 is written in 16 x 8 tiles (orbfe_internal.h): the dword's place inside its tile row is the thread's, the row's is the loop's
+      uint8_t* N0 = rz.dst + (size_t)img * rz.dimg + (((uint32_t)((4 * J) >> 4) << 7) + (uint32_t)((4 * J) & 15));
+      const uint32_t ntile = (uint32_t)(rz.dpitch >> 4) << 7;
+      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += THREADS / 16) {
+        const int yd = t.r0 + yi;
+        uint8_t* N = N0 + (uint32_t)(yd >> 3) * ntile + (uint32_t)((yd & 7) * 16);
+#else
       uint8_t* N = rz.dst + (size_t)img * rz.dimg + (size_t)(t.r0 + (tid >> 4)) * rz.dpitch + 4 * J;
       const size_t nstep = (size_t)(THREADS / 16) * rz.dpitch;
       for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += THREADS / 16, N += nstep) {
+#endif
         {
           const uint4 ty = ytap[yi];
           uint32_t h0[4], h1[4];
@@ -1914,7 +2002,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       (void)pitch; (void)plane;   // raw levels in 16 x 8 tiles: 0.346 -> 0.277 ms (DESIGN lesson 44)
       vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(P.blur.base[level] + (size_t)img * P.blur.img_stride[level] + blur_tiled_offset(ax_o + 16 * c, cy - 15 + r, P.blur.pitch[level])) : make_uint4(0, 0, 0, 0);
 #else
-      vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + (size_t)(cy - 15 + r) * pitch + ax_o + 16 * c) : make_uint4(0, 0, 0, 0);
+      vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + orbfe_level_offset(ax_o + 16 * c, cy - 15 + r, pitch, (P.pyr.tiled >> level) & 1u)) : make_uint4(0, 0, 0, 0);
 #endif
     }
   };
@@ -2179,7 +2267,7 @@ int orbfe_upload_pattern_floats() {
   e = hipMemcpyToSymbol(HIP_SYMBOL(g_ic_w), wtab, sizeof(wtab));
   if (e != hipSuccess) return (int)e;
   // band matrices of the tile kernel's matrix-core blur (blur_level_kernel, BT_MFMA): lane (q, n) of a matrix holds 16 bytes.
-  //   horizontal (one for every column group g): byte j <-> window column 16g + 16q + j, output = window column 4 + 16g + n
+  //   horizontal (one for every column group g): byte j <-> LDS column 16g + 16q + j, output = LDS column BT_COL0 + 4 + 16g + n
   //   vertical, block b:  byte j = 4 ww + i <-> window row 16 ww + 4q + i, output = window row 3 + 16b + n
   static const int taps[7] = {18, 34, 48, 56, 48, 34, 18};
   static int8_t bt[5 * 1024];
@@ -2187,7 +2275,7 @@ int orbfe_upload_pattern_floats() {
     for (int lane = 0; lane < 64; lane++)
       for (int j = 0; j < 16; j++) {
         const int q = lane >> 4, n = lane & 15;
-        const int d = m == 0 ? (16 * q + j) - (4 + n) : (16 * (j >> 2) + 4 * q + (j & 3)) - (3 + 16 * (m - 1) + n);
+        const int d = m == 0 ? (16 * q + j) - (4 + BT_COL0 + n) : (16 * (j >> 2) + 4 * q + (j & 3)) - (3 + 16 * (m - 1) + n);
         bt[(m * 64 + lane) * 16 + j] = (int8_t)(d >= -3 && d <= 3 ? taps[d + 3] : 0);
       }
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_tile_tab), bt, sizeof(bt));

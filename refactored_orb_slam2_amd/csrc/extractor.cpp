@@ -156,6 +156,7 @@ struct orbfe_extractor {
   int32_t* h_err = nullptr;   // pinned: where the device error word is read to (a pageable destination makes the copy wait for every
                               // stream of the device, also the caller's: measured on the batched pipeline, 52 k -> 33 k frames/s)
   int last_images = 0;
+  unsigned last_tiled = 0;    // PyrView::tiled of the pyramid the last call left in d_pyr (the download entry points un-tile by it)
   // profiling
   bool profile = false;
   unsigned profile_mask = ~0u;  // bit s: stage s is timed
@@ -584,9 +585,19 @@ static uint8_t* level_ptr(const orbfe_extractor* e, const DevBuf& buf, int level
   return (uint8_t*)buf.p + (size_t)e->cap_images * e->lg[level].off + (size_t)image * e->lg[level].plane;
 }
 
+// which raw levels the level chain leaves tiled: those the fused kernel writes (kind 0, a fusable step in front of them)
+static unsigned tiled_mask(const orbfe_extractor* e) {
+  unsigned m = 0;
+  if (ORBFE_TILED_LEVELS && e->blur_kind == 0)
+    for (int l = 1; l < e->prm.n_levels; l++)
+      if (e->fuse_ok[l - 1]) m |= 1u << l;
+  return m;
+}
+
 static void make_view(const orbfe_extractor* e, const DevBuf& buf, PyrView& v) {
   memset(&v, 0, sizeof(v));
   v.n_levels = e->prm.n_levels;
+  v.tiled = &buf == &e->d_pyr ? tiled_mask(e) : ~0u;   // the blurred planes are always tiled
   for (int l = 0; l < v.n_levels; l++) {
     v.base[l] = level_ptr(e, buf, l, 0);
     v.img_stride[l] = e->lg[l].plane;
@@ -600,6 +611,10 @@ static void make_view(const orbfe_extractor* e, const DevBuf& buf, PyrView& v) {
     v.pitch[0] = e->ext0_pitch;
   }
 }
+// Host copy of level `level` of image `image` (w x h bytes, rows dst_stride apart), whatever its layout in HBM: through the pinned
+// block `stage` (>= pitch x padded rows bytes), synchronous on `s`
+static int download_level(orbfe_extractor* e, int level, int image, uint8_t* dst, int dst_stride, uint8_t* stage, hipStream_t s);
+
 // plane of image `image` at pyramid level `level` (raw pyramid) and its row pitch
 static const uint8_t* pyr_plane(const orbfe_extractor* e, int level, int image, int* pitch) {
   if (level == 0 && e->ext0) {
@@ -608,6 +623,28 @@ static const uint8_t* pyr_plane(const orbfe_extractor* e, int level, int image, 
   }
   *pitch = e->lg[level].pitch;
   return level_ptr(e, e->d_pyr, level, image);
+}
+
+static size_t level_stage_bytes(const orbfe_extractor* e, int level) {
+  return (size_t)e->lg[level].pitch * (size_t)((e->lg[level].h + 7) & ~7);
+}
+static int download_level(orbfe_extractor* e, int level, int image, uint8_t* dst, int dst_stride, uint8_t* stage, hipStream_t s) {
+  const LevelGeom& g = e->lg[level];
+  int sp = 0;
+  const uint8_t* src = pyr_plane(e, level, image, &sp);
+  const bool tiled = level > 0 && ((e->last_tiled >> level) & 1u);
+  if (tiled) {   // the whole plane as it lies in HBM, un-tiled here
+    HIPCHK(hipMemcpyAsync(stage, src, level_stage_bytes(e, level), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int y = 0; y < g.h; y++)
+      for (int x0 = 0; x0 < g.w; x0 += 16)
+        memcpy(dst + (size_t)y * dst_stride + x0, stage + orbfe_tiled_offset(x0, y, g.pitch), (size_t)std::min(16, g.w - x0));
+  } else {
+    HIPCHK(hipMemcpy2DAsync(stage, g.pitch, src, sp, g.w, g.h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int y = 0; y < g.h; y++) memcpy(dst + (size_t)y * dst_stride, stage + (size_t)y * g.pitch, (size_t)g.w);
+  }
+  return ORBFE_OK;
 }
 
 struct StageTimer {
@@ -962,6 +999,7 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
   }
   if ((rc = enqueue_pipeline(e, n_images, d_kps, d_desc, cap, d_n_out, s))) return rc;
   e->last_images = n_images;
+  e->last_tiled = tiled_mask(e);
   return ORBFE_OK;
 }
 
@@ -1068,6 +1106,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     HIPCHK(hipMemcpyAsync(ho + hdr_bytes + kp_bytes, e->d_out_desc.p, desc_bytes, hipMemcpyDeviceToHost, s));
   }
   e->last_images = n_images;   // host state of the pipeline: set here, not inside the (replayable) launches
+  e->last_tiled = tiled_mask(e);
   HIPCHK(hipStreamSynchronize(s));
   if (e->profile) drain_events(e);
   const int32_t* hn = (const int32_t*)ho;
@@ -1108,13 +1147,9 @@ extern "C" int orbfe_pyramid_level(orbfe_extractor* e, int level, uint8_t* dst, 
   if (h) *h = g.h;
   if (dst) {
     if (dst_stride < g.w) return ORBFE_ERR_INVALID;
-    const size_t bytes = (size_t)g.pitch * g.h;
-    int rc, sp = 0;
-    if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, bytes))) return rc;
-    const uint8_t* src = pyr_plane(e, level, 0, &sp);
-    HIPCHK(hipMemcpy2DAsync(e->h_out, g.pitch, src, sp, g.w, g.h, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    for (int y = 0; y < g.h; y++) memcpy(dst + (size_t)y * dst_stride, (uint8_t*)e->h_out + (size_t)y * g.pitch, (size_t)g.w);
+    int rc;
+    if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, level_stage_bytes(e, level)))) return rc;
+    if ((rc = download_level(e, level, 0, dst, dst_stride, (uint8_t*)e->h_out, e->stream))) return rc;
   }
   return ORBFE_OK;
 }
@@ -1125,25 +1160,32 @@ extern "C" int orbfe_pyramid_levels(orbfe_extractor* e, uint8_t* const* dst, con
   HIPCHK(hipSetDevice(e->device));
   const int nl = e->prm.n_levels;
   size_t total = 0;
-  for (int l = 0; l < nl; l++) total += (size_t)e->lg[l].pitch * e->lg[l].h;
+  for (int l = 0; l < nl; l++) total += level_stage_bytes(e, l);
   int rc;
   if ((rc = pinned_alloc(e->h_out, e->h_out_bytes, total))) return rc;
   size_t off = 0;
-  for (int l = 0; l < nl; l++) {  // image 0 of every level: contiguous pitched plane -> pinned, one sync for all
-    const size_t bytes = (size_t)e->lg[l].pitch * e->lg[l].h;
+  for (int l = 0; l < nl; l++) {  // image 0 of every level: its plane as it lies in HBM -> pinned, one sync for all
     int sp = 0;
     const uint8_t* src = pyr_plane(e, l, 0, &sp);
-    if (sp == e->lg[l].pitch) HIPCHK(hipMemcpyAsync((uint8_t*)e->h_out + off, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    const bool tiled = l > 0 && ((e->last_tiled >> l) & 1u);
+    if (tiled || sp == e->lg[l].pitch) HIPCHK(hipMemcpyAsync((uint8_t*)e->h_out + off, src, tiled ? level_stage_bytes(e, l) : (size_t)e->lg[l].pitch * e->lg[l].h, hipMemcpyDeviceToHost, e->stream));
     else HIPCHK(hipMemcpy2DAsync((uint8_t*)e->h_out + off, e->lg[l].pitch, src, sp, e->lg[l].w, e->lg[l].h, hipMemcpyDeviceToHost, e->stream));
-    off += bytes;
+    off += level_stage_bytes(e, l);
   }
   HIPCHK(hipStreamSynchronize(e->stream));
   off = 0;
   for (int l = 0; l < nl; l++) {
     const LevelGeom& g = e->lg[l];
     if (!dst[l] || dst_stride[l] < g.w) return ORBFE_ERR_INVALID;
-    for (int y = 0; y < g.h; y++) memcpy(dst[l] + (size_t)y * dst_stride[l], (uint8_t*)e->h_out + off + (size_t)y * g.pitch, (size_t)g.w);
-    off += (size_t)g.pitch * g.h;
+    const uint8_t* st = (const uint8_t*)e->h_out + off;
+    if (l > 0 && ((e->last_tiled >> l) & 1u)) {
+      for (int y = 0; y < g.h; y++)
+        for (int x0 = 0; x0 < g.w; x0 += 16)
+          memcpy(dst[l] + (size_t)y * dst_stride[l] + x0, st + orbfe_tiled_offset(x0, y, g.pitch), (size_t)std::min(16, g.w - x0));
+    } else {
+      for (int y = 0; y < g.h; y++) memcpy(dst[l] + (size_t)y * dst_stride[l], st + (size_t)y * g.pitch, (size_t)g.w);
+    }
+    off += level_stage_bytes(e, l);
   }
   return ORBFE_OK;
 }
@@ -1161,10 +1203,17 @@ extern "C" int orbfe_device_pyramid(const orbfe_extractor* e, int image, int lev
   return ORBFE_OK;
 }
 
+extern "C" int orbfe_device_pyramid_layout(const orbfe_extractor* e, int level, int* tiled) {
+  if (!e || !tiled || level < 0 || level >= e->prm.n_levels) return ORBFE_ERR_INVALID;
+  *tiled = level > 0 && ((e->last_tiled >> level) & 1u) ? 1 : 0;
+  return ORBFE_OK;
+}
+
 // internal accessor for the stereo matcher (match side lives in matcher.cpp)
 int orbfe_internal_pyr_view(const orbfe_extractor* e, PyrView* v, int* n_images) {
   if (!e || e->plan_w == 0 || e->cap_images < 1) return ORBFE_ERR_INVALID;
   make_view(e, e->d_pyr, *v);
+  v->tiled = e->last_tiled;
   if (n_images) *n_images = e->last_images;
   return ORBFE_OK;
 }
@@ -1244,11 +1293,10 @@ extern "C" int orbfe_debug_pyramid(orbfe_extractor* e, int image, int level, uin
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->device));
   const LevelGeom& g = e->lg[level];
+  if (dst_stride < g.w) return ORBFE_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(e->stream));
-  int sp = 0;
-  const uint8_t* src = pyr_plane(e, level, image, &sp);
-  HIPCHK(hipMemcpy2D(dst, dst_stride, src, sp, g.w, g.h, hipMemcpyDeviceToHost));
-  return ORBFE_OK;
+  std::vector<uint8_t> stage(level_stage_bytes(e, level));
+  return download_level(e, level, image, dst, dst_stride, stage.data(), e->stream);
 }
 
 extern "C" int orbfe_debug_level_keypoints(orbfe_extractor* e, int image, int level, int32_t* x, int32_t* y,

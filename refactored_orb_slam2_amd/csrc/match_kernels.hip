@@ -1295,6 +1295,7 @@ struct SmLevel {
   unsigned long long strideL, strideR;
   int pitchL, pitchR, wL, hL, wR, hR;
   float scale, inv_scale;
+  int tiledL, tiledR;   // the level lies in 16 x 8 tiles (orbfe_internal.h: written by the fused level kernel), not row-major
 };
 #define SM_G 16                      // lanes per left keypoint
 #define SM_KPB (256 / SM_G)          // left keypoints per workgroup
@@ -1302,9 +1303,9 @@ struct SmLevel {
 #define SM_ROUNDS 2
 #endif
 // SM_ROUNDS: bucket entries requested up front per keypoint: SM_ROUNDS * SM_G
-#define SAD_LP 16   // LDS pitch of the staged left window: 11 pixels at byte offset <= 3 of 4 aligned dwords
-#define SAD_RP 24   // LDS pitch of the staged right window: 21 pixels at byte offset <= 3 of 6 aligned dwords
-#define SAD_WIN (11 * SAD_LP + 11 * SAD_RP + 8)
+#define SAD_LP 32   // LDS pitch of the staged left window: 11 pixels at byte offset <= 15 of two aligned 16-byte pieces
+#define SAD_RP 48   // LDS pitch of the staged right window: 21 pixels at byte offset <= 15 of three aligned 16-byte pieces
+#define SAD_WIN (11 * SAD_LP + 11 * SAD_RP + 16)   // a multiple of 16: every keypoint's slice starts 16-byte aligned
 // Sixteen lanes per left keypoint, four keypoints per wave (L/src/Frame.cc:504-632).  What the whole-wave kernel paid once per
 // keypoint -- the wave-uniform set-up, six 64-lane reductions, the scalar epilogue -- is paid once per FOUR here: the keypoint's
 // own values live in the lanes of its DPP row, reductions are four row rotations, the first-minimum / parabola epilogue runs with
@@ -1336,11 +1337,11 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
   __shared__ SmLevel s_lv[ORBFE_MAX_LEVELS];
   __shared__ float s_r[ORBFE_MAX_LEVELS];  // r = 2 * scale[octave] of a right keypoint (L/src/Frame.cc:496)
   __shared__ __attribute__((aligned(16))) uint8_t sad_win[SM_KPB][SAD_WIN];
-  __shared__ uint8_t s_offL[128], s_offR[128];   // window pixel p = 11 * yy + xx -> byte offset inside the staged windows
+  __shared__ uint16_t s_offL[128], s_offR[128];   // window pixel p = 11 * yy + xx -> byte offset inside the staged windows
   if (threadIdx.x >= 128) {
     const unsigned p = threadIdx.x - 128, yy = p / 11u, xx = p - yy * 11u;
-    s_offL[p] = (uint8_t)(p < 121 ? yy * SAD_LP + xx : 0);
-    s_offR[p] = (uint8_t)(p < 121 ? yy * SAD_RP + xx : 0);
+    s_offL[p] = (uint16_t)(p < 121 ? yy * SAD_LP + xx : 0);
+    s_offR[p] = (uint16_t)(p < 121 ? yy * SAD_RP + xx : 0);
   }
   if (threadIdx.x < ORBFE_MAX_LEVELS) {
     const int l = threadIdx.x;
@@ -1353,6 +1354,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
     v.wL = in ? P.pyrL.w[l] : 0; v.hL = in ? P.pyrL.h[l] : 0;
     v.wR = in ? P.pyrR.w[l] : 0; v.hR = in ? P.pyrR.h[l] : 0;
     v.scale = P.scale[l]; v.inv_scale = P.inv_scale[l];
+    v.tiledL = (int)((P.pyrL.tiled >> l) & 1u); v.tiledR = (int)((P.pyrR.tiled >> l) & 1u);
     s_lv[l] = v;
     s_r[l] = 2.0f * P.scale[l];
   }
@@ -1450,26 +1452,32 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
                  yW + 2 * w >= lv.hR);
   if (__ballot(act) == 0ull) return;
   // stage the 11 x 11 left window and the 11 x 21 right window (all 11 shifts) of the row's keypoint in its LDS slice: lane r of
-  // the row loads window row r -- 16 bytes of the left level and 24 of the right one from the aligned dword below the window's
-  // first column (dwordx4 / dwordx2 loads need dword alignment only) -- three load instructions for the wave's four keypoints
+  // the row loads window row r as aligned 16-byte pieces -- two of the left level, three of the right one, from the piece that
+  // holds the window's first column on -- five load instructions for the wave's four keypoints.  A piece is 16 bytes of a row
+  // in a row-major level and one tile row in a tiled one (orbfe_level_offset): the same loads, another address.
   uint8_t* winL = &sad_win[grp][0];
   uint8_t* winR = winL + 11 * SAD_LP;
-  const int axL = xW & ~3, axR = xR0 & ~3;
+  const int axL = xW & ~15, axR = xR0 & ~15;
   if (act && sub < 11) {
     // (a pointer that comes out of LDS is a generic one to the compiler: say that it is global memory, or the loads are flat_load)
     typedef const __attribute__((address_space(1))) uint8_t* gptr_t;
-    gptr_t pl = (gptr_t)(uintptr_t)lv.baseL + ((yW + sub) * lv.pitchL + axL);
-    gptr_t pr = (gptr_t)(uintptr_t)lv.baseR + ((yW + sub) * lv.pitchR + axR);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const u32x4 vl = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(pl);
-    const u32x4 vr0 = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(pr);
-    const u32x2 vr1 = *reinterpret_cast<const __attribute__((address_space(1))) u32x2*>(pr + 16);
-    *reinterpret_cast<u32x4*>(winL + sub * SAD_LP) = vl;
-    u32x2* wr = reinterpret_cast<u32x2*>(winR + sub * SAD_RP);
-    wr[0] = vr0.xy;
-    wr[1] = vr0.zw;
-    wr[2] = vr1;
+    const int y = yW + sub;
+    u32x4 vl[2], vr[3];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {   // a piece beyond the row's last one is not part of the window: the last one again
+      const int x = min(axL + 16 * k, lv.pitchL - 16);
+      vl[k] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((gptr_t)(uintptr_t)lv.baseL + orbfe_level_offset(x, y, lv.pitchL, lv.tiledL != 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int x = min(axR + 16 * k, lv.pitchR - 16);
+      vr[k] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((gptr_t)(uintptr_t)lv.baseR + orbfe_level_offset(x, y, lv.pitchR, lv.tiledR != 0));
+    }
+    u32x4* wl = reinterpret_cast<u32x4*>(winL + sub * SAD_LP);
+    wl[0] = vl[0]; wl[1] = vl[1];
+    u32x4* wr = reinterpret_cast<u32x4*>(winR + sub * SAD_RP);
+    wr[0] = vr[0]; wr[1] = vr[1]; wr[2] = vr[2];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -22,7 +22,24 @@ struct PyrView {
   int pitch[ORBFE_MAX_LEVELS];
   int w[ORBFE_MAX_LEVELS], h[ORBFE_MAX_LEVELS];
   int n_levels;
+  unsigned tiled;   // bit l: level l is stored in 16 x 8-pixel tiles of 128 bytes (orbfe_level_offset) instead of row-major
 };
+
+// A raw level written by the fused level kernel (blur_level_kernel<true>) is stored TILED -- 16 pixels x 8 rows = one 128-byte
+// line, tiles in raster order, pitch / 16 tiles per tile row, rows padded to 8 (the planes are sized for that) -- because its
+// readers fetch windows (the next level's tiles, FAST cells, 31 x 31 orientation patches, 11-row SAD windows) and the memory path
+// charges per 128-byte line touched, not per byte (DESIGN lesson 44).  Level 0 (the caller's image) and levels written by the
+// stand-alone resize kernels stay row-major; PyrView::tiled says which is which.
+#ifndef ORBFE_TILED_LEVELS
+#define ORBFE_TILED_LEVELS 1
+#endif
+// byte offset of pixel (x, y), x, y >= 0; a plane is < 2^25 bytes (4095 x 4095)
+__host__ __device__ inline uint32_t orbfe_tiled_offset(int x, int y, int pitch) {
+  return (((uint32_t)(y >> 3) * (uint32_t)(pitch >> 4) + (uint32_t)(x >> 4)) << 7) + (uint32_t)((y & 7) * 16 + (x & 15));
+}
+__host__ __device__ inline uint32_t orbfe_level_offset(int x, int y, int pitch, bool tiled) {
+  return tiled ? orbfe_tiled_offset(x, y, pitch) : (uint32_t)y * (uint32_t)pitch + (uint32_t)x;
+}
 
 // Horizontal / vertical coefficient tables of cv::resize INTER_LINEAR (8 bytes per destination index)
 struct ResizeTap {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B builds of liborbfe.so for kernel experiments: tools/ab_build.sh <name> "<extra -D flags>" [file.hip ...]
+# A/B builds of liborbfe.so for kernel experiments: tools/ab_build.sh <name> "<extra -D flags>" [file.hip | file.cpp ...]
 # Recompiles the named .hip files (default: extract_kernels.hip) with the extra flags and links them with the objects of the
 # regular build into refactored_orb_slam2_amd/csrc/_ab/liborbfe_<name>.so (git-ignored; travels to the GPU box).
 # Select it with ORBFE_AB_LIB=<name> in tools/stage_times.py / bench.py --ab-lib (tools only; the product loads liborbfe.so).
@@ -15,6 +15,9 @@ for o in _obj/*.o; do
   if echo " $files " | grep -q " $b.hip "; then
     /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $extra \
       --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -c $b.hip -o _ab/obj_$name/$b.o
+    objs="$objs _ab/obj_$name/$b.o"
+  elif echo " $files " | grep -q " $b.cpp "; then   # a host file that shares the macro (e.g. the plan side of a layout switch)
+    /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $extra -c $b.cpp -o _ab/obj_$name/$b.o
     objs="$objs _ab/obj_$name/$b.o"
   else
     objs="$objs $o"
