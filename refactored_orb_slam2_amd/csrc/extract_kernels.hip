@@ -68,7 +68,7 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // pitch padding.
 __global__ __launch_bounds__(256) void copy_level0_kernel(const uint8_t* __restrict__ src, int sstride,
                                                            unsigned long long simg, uint8_t* __restrict__ dst,
-                                                           int dpitch, unsigned long long dimg, int w, int h) {
+                                                           int dpitch, unsigned long long dimg, int w, int h, int tiled) {
   const int nchunk = (w + 15) >> 4;  // 16-byte chunks per row; (row, chunk) pairs are dealt to threads in raster order
   const int item = blockIdx.x * 256 + threadIdx.x;
   const int y = (int)((item + 0.5f) * (1.0f / (float)nchunk));  // exact for item < 2^22
@@ -95,6 +95,11 @@ __global__ __launch_bounds__(256) void copy_level0_kernel(const uint8_t* __restr
         out[i] |= (uint32_t)S[x] << (8 * j);
       }
     }
+  }
+  if (tiled) {   // the copy is written in 16 x 8 tiles like the levels behind it (orbfe_internal.h): a chunk is one tile row
+    uint8_t* D = dst + (size_t)blockIdx.z * dimg + orbfe_tiled_offset(x16, y, dpitch);   // dpitch is a multiple of 64: the chunk is whole
+    *reinterpret_cast<uint4*>(D) = make_uint4(out[0], out[1], out[2], out[3]);
+    return;
   }
   uint8_t* D = dst + (size_t)blockIdx.z * dimg + (size_t)y * dpitch + x16;
   if (x16 + 16 <= dpitch) *reinterpret_cast<uint4*>(D) = make_uint4(out[0], out[1], out[2], out[3]);
@@ -1390,26 +1395,34 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
       // A tiled level arrives as whole tile rows: the window's 6 x 9 tiles, eight lanes per tile (one 16-byte tile row each), so a
       // load instruction covers eight complete 128-byte lines -- 54 lines per window where the row-major form touches 124.
       // Rows of the first and last tile row outside the window are dropped at the store; tiles outside the plane are not read.
-      constexpr int NP = (6 * 9 * 8 + THREADS - 1) / THREADS;
+      // Only the window's 62 rows are requested: rows 5 .. 7 of the first tile row, the seven tile rows in between whole, rows 0 .. 2
+      // of the last one (oy is a multiple of 56 = 7 x 8, so the window always starts at row 5 of a tile row) -- 372 pieces of 16 bytes.
+      constexpr int N_TOP = 3 * 6, N_MID = 7 * 8 * 6, N_ALL = N_TOP + N_MID + 3 * 6;
+      constexpr int NP = (N_ALL + THREADS - 1) / THREADS;
       const int ty0 = (oy - 3) >> 3, tx0 = (ox - 16) >> 4;   // (arithmetic shifts: -1 in the first tile row / column)
       const int tiles_y = (h + 7) >> 3, tiles_x = pitch >> 4;
       const uint32_t tstep = (uint32_t)tiles_x << 7;
+      // piece -> (tile row, tile column, row inside the tile): eight (three) consecutive lanes share a tile
+      auto piece = [&](int pid, int& tyi, int& txi, int& rr) {
+        if (pid < N_TOP) { txi = (int)((pid + 0.5f) * (1.0f / 3.0f)); rr = 5 + pid - 3 * txi; tyi = 0; }
+        else if (pid < N_TOP + N_MID) { const int q = pid - N_TOP, tl = q >> 3; rr = q & 7; tyi = (int)((tl + 0.5f) * (1.0f / 6.0f)); txi = tl - 6 * tyi; tyi += 1; }
+        else { const int q = pid - N_TOP - N_MID; txi = (int)((q + 0.5f) * (1.0f / 3.0f)); rr = q - 3 * txi; tyi = 8; }
+      };
       uint4 pv[NP];
 #pragma unroll
       for (int k = 0; k < NP; k++) {
-        const int pid = min(tid + k * THREADS, 6 * 9 * 8 - 1);
-        const int rr = pid & 7, tl = pid >> 3;
-        const int tyi = (int)((tl + 0.5f) * (1.0f / 6.0f)), txi = tl - tyi * 6;
+        int tyi, txi, rr;
+        piece(min(tid + k * THREADS, N_ALL - 1), tyi, txi, rr);
         const int tr = min(max(ty0 + tyi, 0), tiles_y - 1), tc = min(max(tx0 + txi, 0), tiles_x - 1);   // clamped: a valid address in any case
         pv[k] = *reinterpret_cast<const uint4*>(S + (uint32_t)tr * tstep + ((uint32_t)tc << 7) + (uint32_t)(rr * 16));
       }
 #pragma unroll
       for (int k = 0; k < NP; k++) {
+        int tyi, txi, rr;
         const int pid = tid + k * THREADS;
-        const int rr = pid & 7, tl = pid >> 3;
-        const int tyi = (int)((tl + 0.5f) * (1.0f / 6.0f)), txi = tl - tyi * 6;
-        const int wr = (ty0 + tyi) * 8 + rr - (oy - 3);
-        if (pid < 6 * 9 * 8 && wr >= 0 && wr < BT_H + 6) *reinterpret_cast<uint4*>(in + wr * BT_INP + 16 * txi) = pv[k];
+        piece(min(pid, N_ALL - 1), tyi, txi, rr);
+        const int wr = tyi * 8 + rr - 5;   // = (ty0 + tyi) * 8 + rr - (oy - 3)
+        if (pid < N_ALL) *reinterpret_cast<uint4*>(in + wr * BT_INP + 16 * txi) = pv[k];
       }
       if (!interior) {
         // REFLECT_101 at the level's edges, inside LDS: what the passes read outside the level is within three pixels of it, and
@@ -1476,18 +1489,13 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
         }
       };
       // rows t.r0 + (tid >> 4), + THREADS / 16, ...: the row groups of a wave take consecutive rows
-#if ORBFE_TILED_LEVELS
-      // level + 1 is written in 16 x 8 tiles (orbfe_internal.h): the dword's place inside its tile row is the thread's, the row's is the loop's
-      uint8_t* N0 = rz.dst + (size_t)img * rz.dimg + (((uint32_t)((4 * J) >> 4) << 7) + (uint32_t)((4 * J) & 15));
+      // level + 1 is written in 16 x 8 tiles (orbfe_internal.h; row-major where a stand-alone kernel reads it next): the dword's
+      // place inside its row / tile row is the thread's, the row's is the loop's
+      uint8_t* N0 = rz.dst + (size_t)img * rz.dimg + (rz.dst_tiled ? (((uint32_t)((4 * J) >> 4) << 7) + (uint32_t)((4 * J) & 15)) : (uint32_t)(4 * J));
       const uint32_t ntile = (uint32_t)(rz.dpitch >> 4) << 7;
       for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += THREADS / 16) {
         const int yd = t.r0 + yi;
-        uint8_t* N = N0 + (uint32_t)(yd >> 3) * ntile + (uint32_t)((yd & 7) * 16);
-#else
-      uint8_t* N = rz.dst + (size_t)img * rz.dimg + (size_t)(t.r0 + (tid >> 4)) * rz.dpitch + 4 * J;
-      const size_t nstep = (size_t)(THREADS / 16) * rz.dpitch;
-      for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += THREADS / 16, N += nstep) {
-#endif
+        uint8_t* N = N0 + (rz.dst_tiled ? (uint32_t)(yd >> 3) * ntile + (uint32_t)((yd & 7) * 16) : (uint32_t)yd * (uint32_t)rz.dpitch);
         {
           const uint4 ty = ytap[yi];
           uint32_t h0[4], h1[4];
@@ -2133,10 +2141,10 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
 
 // ------------------------------------------------------------------------------------------------ launchers
 void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
-                        int h, int n_images, hipStream_t s) {
+                        int h, int n_images, int tiled, hipStream_t s) {
   dim3 block(256), grid((((w + 15) / 16) * h + 255) / 256, 1, n_images);
   hipLaunchKernelGGL(copy_level0_kernel, grid, block, 0, s, src, sstride, (unsigned long long)simg, dst, dpitch,
-                     (unsigned long long)dimg, w, h);
+                     (unsigned long long)dimg, w, h, tiled);
 }
 
 void orbfe_launch_resize(const uint8_t* src, int spitch, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int dw,

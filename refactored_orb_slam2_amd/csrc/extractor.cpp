@@ -22,7 +22,7 @@
 #include "orbfe_internal.h"
 
 void orbfe_launch_copy0(const uint8_t* src, int sstride, size_t simg, uint8_t* dst, int dpitch, size_t dimg, int w,
-                        int h, int n_images, hipStream_t s);
+                        int h, int n_images, int tiled, hipStream_t s);
 int orbfe_set_octree_lds(size_t lds_bytes);
 int orbfe_upload_pattern_floats();
 
@@ -586,18 +586,26 @@ static uint8_t* level_ptr(const orbfe_extractor* e, const DevBuf& buf, int level
 }
 
 // which raw levels the level chain leaves tiled: those the fused kernel writes (kind 0, a fusable step in front of them)
-static unsigned tiled_mask(const orbfe_extractor* e) {
+static unsigned tiled_mask(const orbfe_extractor* e, int n_images = 1 << 30) {
+  // a level is tiled when the kernel that writes it can (the fused level kernel; copy_level0 for a level 0 that is not the caller's
+  // image in place) AND the launch that reads it as its source is a level kernel too (the stand-alone resize kernels read rows)
   unsigned m = 0;
-  if (ORBFE_TILED_LEVELS && e->blur_kind == 0)
-    for (int l = 1; l < e->prm.n_levels; l++)
-      if (e->fuse_ok[l - 1]) m |= 1u << l;
+  if (!ORBFE_TILED_LEVELS || e->blur_kind != 0) return 0;
+  const int nl = e->prm.n_levels;
+  for (int l = 0; l < nl; l++) {
+    // (a level-0 copy is tiled for a handful of images only: the level kernel streams a tiled level 0 slower than a row-major one
+    //  -- +0.06 ms per 256 images -- which a batch does not get back from the gathers; a one-image call does: 0.187 -> 0.179 ms)
+    const bool writer = l == 0 ? (!e->ext0 && n_images <= 8) : e->fuse_ok[l - 1];
+    const bool reader = l == nl - 1 || e->fuse_ok[l];
+    if (writer && reader) m |= 1u << l;
+  }
   return m;
 }
 
-static void make_view(const orbfe_extractor* e, const DevBuf& buf, PyrView& v) {
+static void make_view(const orbfe_extractor* e, const DevBuf& buf, PyrView& v, int n_images) {
   memset(&v, 0, sizeof(v));
   v.n_levels = e->prm.n_levels;
-  v.tiled = &buf == &e->d_pyr ? tiled_mask(e) : ~0u;   // the blurred planes are always tiled
+  v.tiled = &buf == &e->d_pyr ? tiled_mask(e, n_images) : ~0u;   // the blurred planes are always tiled
   for (int l = 0; l < v.n_levels; l++) {
     v.base[l] = level_ptr(e, buf, l, 0);
     v.img_stride[l] = e->lg[l].plane;
@@ -632,7 +640,7 @@ static int download_level(orbfe_extractor* e, int level, int image, uint8_t* dst
   const LevelGeom& g = e->lg[level];
   int sp = 0;
   const uint8_t* src = pyr_plane(e, level, image, &sp);
-  const bool tiled = level > 0 && ((e->last_tiled >> level) & 1u);
+  const bool tiled = (e->last_tiled >> level) & 1u;
   if (tiled) {   // the whole plane as it lies in HBM, un-tiled here
     HIPCHK(hipMemcpyAsync(stage, src, level_stage_bytes(e, level), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -709,8 +717,8 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
                             int32_t* d_n_out, hipStream_t s) {
   const int nl = e->prm.n_levels;
   PyrView pv, bv;
-  make_view(e, e->d_pyr, pv);
-  make_view(e, e->d_blur, bv);
+  make_view(e, e->d_pyr, pv, n_images);
+  make_view(e, e->d_blur, bv, n_images);
   // Fused level chain (the default): launch l blurs level l and, from the same staged windows, writes level l + 1 -- every level
   // is read once by the two stages together and the separate resize launches disappear; a step the fused kernel cannot run
   // (scale factors outside its thread layout) falls back to resize + blur launches of its own.  orbfe_debug_blur_kernel(e, 1 | 2)
@@ -732,6 +740,7 @@ static int enqueue_pipeline(orbfe_extractor* e, int n_images, orbfe_keypoint* d_
         rz.dst = const_cast<uint8_t*>(pv.base[l + 1]);
         rz.dimg = e->lg[l + 1].plane;
         rz.dpitch = pv.pitch[l + 1]; rz.dw = pv.w[l + 1]; rz.dh = pv.h[l + 1];
+        rz.dst_tiled = (int)((pv.tiled >> (l + 1)) & 1u);
         rz.xt = (const ResizeTap*)e->d_xt[l + 1].p;
         rz.yt = (const ResizeTap*)e->d_yt[l + 1].p;
         orbfe_launch_blur_level(pv, bv, lt, e->tile_count[l], &rz, n_images, s);
@@ -994,12 +1003,12 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
     } else {
       e->ext0 = nullptr;
       orbfe_launch_copy0(d_imgs, stride, image_pitch, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w, h,
-                         n_images, s);
+                         n_images, (int)(tiled_mask(e, n_images) & 1u), s);
     }
   }
   if ((rc = enqueue_pipeline(e, n_images, d_kps, d_desc, cap, d_n_out, s))) return rc;
   e->last_images = n_images;
-  e->last_tiled = tiled_mask(e);
+  e->last_tiled = tiled_mask(e, n_images);
   return ORBFE_OK;
 }
 
@@ -1049,7 +1058,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     {
       StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
       orbfe_launch_copy0((const uint8_t*)e->h_in, w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w, h,
-                         n_images, s);
+                         n_images, (int)(tiled_mask(e, n_images) & 1u), s);
     }
     int r = enqueue_pipeline(e, n_images, (orbfe_keypoint*)(ho + hdr_bytes), ho + hdr_bytes + kp_bytes, cap, (int32_t*)ho, s);
     if (r) return r;
@@ -1095,7 +1104,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     {
       StageTimer t(e, s, ORBFE_STAGE_PYRAMID);
       orbfe_launch_copy0((const uint8_t*)e->d_in_stage.p, w, img_bytes, level_ptr(e, e->d_pyr, 0, 0), e->lg[0].pitch, e->lg[0].plane, w,
-                         h, n_images, s);
+                         h, n_images, (int)(tiled_mask(e, n_images) & 1u), s);
     }
     if ((rc = enqueue_pipeline(e, n_images, (orbfe_keypoint*)e->d_out_kps.p, (uint8_t*)e->d_out_desc.p, cap, d_hdr, s)))
       return rc;
@@ -1106,7 +1115,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* const* img
     HIPCHK(hipMemcpyAsync(ho + hdr_bytes + kp_bytes, e->d_out_desc.p, desc_bytes, hipMemcpyDeviceToHost, s));
   }
   e->last_images = n_images;   // host state of the pipeline: set here, not inside the (replayable) launches
-  e->last_tiled = tiled_mask(e);
+  e->last_tiled = tiled_mask(e, n_images);
   HIPCHK(hipStreamSynchronize(s));
   if (e->profile) drain_events(e);
   const int32_t* hn = (const int32_t*)ho;
@@ -1167,7 +1176,7 @@ extern "C" int orbfe_pyramid_levels(orbfe_extractor* e, uint8_t* const* dst, con
   for (int l = 0; l < nl; l++) {  // image 0 of every level: its plane as it lies in HBM -> pinned, one sync for all
     int sp = 0;
     const uint8_t* src = pyr_plane(e, l, 0, &sp);
-    const bool tiled = l > 0 && ((e->last_tiled >> l) & 1u);
+    const bool tiled = (e->last_tiled >> l) & 1u;
     if (tiled || sp == e->lg[l].pitch) HIPCHK(hipMemcpyAsync((uint8_t*)e->h_out + off, src, tiled ? level_stage_bytes(e, l) : (size_t)e->lg[l].pitch * e->lg[l].h, hipMemcpyDeviceToHost, e->stream));
     else HIPCHK(hipMemcpy2DAsync((uint8_t*)e->h_out + off, e->lg[l].pitch, src, sp, e->lg[l].w, e->lg[l].h, hipMemcpyDeviceToHost, e->stream));
     off += level_stage_bytes(e, l);
@@ -1178,7 +1187,7 @@ extern "C" int orbfe_pyramid_levels(orbfe_extractor* e, uint8_t* const* dst, con
     const LevelGeom& g = e->lg[l];
     if (!dst[l] || dst_stride[l] < g.w) return ORBFE_ERR_INVALID;
     const uint8_t* st = (const uint8_t*)e->h_out + off;
-    if (l > 0 && ((e->last_tiled >> l) & 1u)) {
+    if ((e->last_tiled >> l) & 1u) {
       for (int y = 0; y < g.h; y++)
         for (int x0 = 0; x0 < g.w; x0 += 16)
           memcpy(dst[l] + (size_t)y * dst_stride[l] + x0, st + orbfe_tiled_offset(x0, y, g.pitch), (size_t)std::min(16, g.w - x0));
@@ -1205,14 +1214,14 @@ extern "C" int orbfe_device_pyramid(const orbfe_extractor* e, int image, int lev
 
 extern "C" int orbfe_device_pyramid_layout(const orbfe_extractor* e, int level, int* tiled) {
   if (!e || !tiled || level < 0 || level >= e->prm.n_levels) return ORBFE_ERR_INVALID;
-  *tiled = level > 0 && ((e->last_tiled >> level) & 1u) ? 1 : 0;
+  *tiled = (e->last_tiled >> level) & 1u ? 1 : 0;
   return ORBFE_OK;
 }
 
 // internal accessor for the stereo matcher (match side lives in matcher.cpp)
 int orbfe_internal_pyr_view(const orbfe_extractor* e, PyrView* v, int* n_images) {
   if (!e || e->plan_w == 0 || e->cap_images < 1) return ORBFE_ERR_INVALID;
-  make_view(e, e->d_pyr, *v);
+  make_view(e, e->d_pyr, *v, e->last_images);
   v->tiled = e->last_tiled;
   if (n_images) *n_images = e->last_images;
   return ORBFE_OK;

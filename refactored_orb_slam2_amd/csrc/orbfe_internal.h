@@ -127,6 +127,7 @@ struct LevelResize {
   uint8_t* dst;               // level l + 1 of image 0
   unsigned long long dimg;    // bytes between images
   int dpitch, dw, dh;
+  int dst_tiled;              // level l + 1 is written in 16 x 8 tiles (PyrView::tiled bit l + 1)
   const ResizeTap* xt;
   const ResizeTap* yt;
 };
