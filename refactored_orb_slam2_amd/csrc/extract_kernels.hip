@@ -900,12 +900,17 @@ size_t orbfe_octree_lds_bytes(int M, int lds_keys) {
 }
 
 #if FC_TIMING
-__device__ unsigned long long g_oct_prof[64];   // [level] cycles, [32 + level] iterations of the subdivision loop
-extern "C" int orbfe_debug_oct_profile(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_prof), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
-  if (reset) { unsigned long long z[64]; memset(z, 0, sizeof(z)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), z, sizeof(z)) != hipSuccess) return 1; }
+__device__ unsigned long long g_oct_prof[256];   // [level] cycles, [32 + level] iterations of the subdivision loop, [64 + 8 level + phase] cycles
+extern "C" int orbfe_debug_oct_profile(unsigned long long* out, int reset) {   // out: 256 entries
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_prof), sizeof(unsigned long long) * 256) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[256]; memset(z, 0, sizeof(z)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
 }
+// phases (tools/oct_phase_profile.py): 0 cell offsets, 1 key gather, 2 first relabel / histogram, 3 node work of the subdivision
+// rounds, 4 their key sweeps, 5 best key + output
+#define OCT_TP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); tph[i] += _t - t_prev; t_prev = _t; } while (0)
+#else
+#define OCT_TP(i)
 #endif
 #define OCT_T ORBFE_OCT_THREADS   // 256 measured best (64: 0.120, 128: 0.091, 256: 0.069, 512: 0.091 ms per 256 images)
 static_assert(ORBFE_MAX_INI <= ORBFE_OCT_THREADS, "one thread per root node in step 3");
@@ -917,6 +922,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   const int level = blockIdx.y, img = blockIdx.x;
 #if FC_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
+  unsigned long long t_prev = t_begin, tph[6] = {0, 0, 0, 0, 0, 0};
   int n_iter = 0;
 #endif
   const OctLevel L = P.lv[level];
@@ -942,17 +948,29 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   const uint32_t* slots = P.slots + (size_t)img * P.slots_per_image;
   uint32_t* out_kp = P.lvl_kp + (size_t)img * P.kp_per_image + L.kp_off;
 
-  // 1. exclusive offsets of the cells' candidate lists (cell raster order == vToDistributeKeys order)
+  // 1. exclusive offsets of the cells' candidate lists (cell raster order == vToDistributeKeys order).  Offset, count and slot
+  //    address of every cell go to LDS (the quadrant-count array, idle until step 3) when the level's cells fit: the gather below
+  //    then has the candidates themselves as its only memory requests
+  const int tab_cap = (M * 4) / 3;
+  const bool use_tab = L.n_cells <= tab_cap;
+  int* tb_o = cnt4;
+  int* tb_n = cnt4 + tab_cap;
+  uint32_t* tb_so = reinterpret_cast<uint32_t*>(cnt4 + 2 * tab_cap);
   int running = 0;
   for (int base = 0; base < L.n_cells; base += OCT_T) {
     const int c = base + tid;
     const int v = c < L.n_cells ? cnt[c] : 0;
+    const uint32_t so = c < L.n_cells ? cells[c].slot_off : 0u;
     int tot;
     const int incl = block_incl_scan_t<OCT_T>(v, scan_tmp, &tot);
-    if (c < L.n_cells) coff[c] = running + incl - v;
+    if (c < L.n_cells) {
+      if (use_tab) { tb_o[c] = running + incl - v; tb_n[c] = v; tb_so[c] = so; }
+      else coff[c] = running + incl - v;
+    }
     running += tot;
   }
   const int C = running;
+  OCT_TP(0);
   if (C > L.key_cap || C > 0xFFFFFF) {  // cannot happen: key_cap = sum of slot caps
     if (tid == 0) { atomicOr(P.err, 1); P.lvl_n[(size_t)img * ORBFE_MAX_LEVELS + level] = 0; }
     return;
@@ -963,20 +981,52 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
   __syncthreads();
 
   // 2. gather keys, assign to the root nodes: vpIniNodes[kp.pt.x / hX] (L/src/ORBextractor.cc:559)
-  for (int c = tid; c < L.n_cells; c += OCT_T) {
-    const int n = cnt[c];
-    const int o = coff[c];
-    const uint32_t* src = slots + cells[c].slot_off;
-    for (int j = 0; j < n; j++) {
-      const uint32_t e = src[j];
-      const int x = e & 0xfff, y = (e >> 12) & 0xfff, s = e >> 24;
-      int node = (int)((float)x / L.hX);
-      if (node >= L.n_ini) node = L.n_ini - 1;
-      keys[o + j] = key_pack(x, y, node, s, 0);
-      atomicAdd(&ini_cnt[node], 1);
+  auto put_key = [&](uint32_t e, int at) {
+    const int x = e & 0xfff, y = (e >> 12) & 0xfff, s = e >> 24;
+    int node = (int)((float)x / L.hX);
+    if (node >= L.n_ini) node = L.n_ini - 1;
+    keys[at] = key_pack(x, y, node, s, 0);
+    atomicAdd(&ini_cnt[node], 1);
+  };
+  if (use_tab) {
+    // G lanes per cell, G = the power of two at or above the mean list length (1 .. 64): few candidates per cell -> many cells per
+    // pass; dense texture -> a wave per cell, coalesced reads and writes.  Two cells x four candidates per lane are requested
+    // together (thread per cell with one request at a time was a chain of round trips: a quarter of the level-0 workgroup's time,
+    // a third with dense texture)
+    int gs = 0;
+    while (gs < 6 && ((L.n_cells << gs) < C)) gs++;
+    const int G = 1 << gs, NG = OCT_T >> gs;
+    const int g = tid >> gs, jl = tid & (G - 1);
+    for (int c0 = g; c0 < L.n_cells; c0 += 2 * NG) {
+      const int c1 = c0 + NG;
+      const bool h1 = c1 < L.n_cells;
+      const int nA = tb_n[c0], oA = tb_o[c0], nB = h1 ? tb_n[c1] : 0, oB = h1 ? tb_o[c1] : 0;
+      const uint32_t* sA = slots + tb_so[c0];
+      const uint32_t* sB = slots + (h1 ? tb_so[c1] : 0u);
+      for (int j0 = jl; j0 < max(nA, nB); j0 += 4 * G) {
+        uint32_t eA[4], eB[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          eA[u] = j0 + u * G < nA ? sA[j0 + u * G] : 0u;
+          eB[u] = j0 + u * G < nB ? sB[j0 + u * G] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (j0 + u * G < nA) put_key(eA[u], oA + j0 + u * G);
+          if (j0 + u * G < nB) put_key(eB[u], oB + j0 + u * G);
+        }
+      }
+    }
+  } else {
+    for (int c = tid; c < L.n_cells; c += OCT_T) {   // more cells than the table holds (very large images): thread per cell
+      const int n = cnt[c];
+      const int o = coff[c];
+      const uint32_t* src = slots + cells[c].slot_off;
+      for (int j = 0; j < n; j++) put_key(src[j], o + j);
     }
   }
   __syncthreads();
+  OCT_TP(1);
 
   // 3. root nodes that hold keys, in order (empty ones are erased, :564-572)
   int size;
@@ -1026,8 +1076,76 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       }
     }
   };
-  relabel_and_count(nodeA, [&](unsigned long long kk) { return ini_map[KEY_NODE(kk)]; });
+  // ---- fast-forward for levels whose keys live in HBM (dense texture).  Where a node is cut depends on the node alone, so a key's
+  // path through the first D = L.ff_depth subdivisions is a function of its position: ONE sweep counts the keys per depth-D cell,
+  // sums of four give the counts of every shallower node, and the subdivision rounds below take a new leaf's quadrant counts from
+  // those tables instead of sweeping the keys (a sweep = 16 bytes per key through the fabric for all workgroups at once: the four
+  // rounds of uniform noise were 630 k of the level-0 workgroup's 1.4 M cycles).  Keys keep their ROOT index meanwhile; the first
+  // round that creates a multi-key leaf at depth D writes real labels (`materialise`) and the explicit rounds take over.
+  // Tables T_1 .. T_D (T_d: n_ini * 4^d counts, index = 4 * parent index + quadrant), the cell -> leaf map and the leaves'
+  // (depth, index) words live in the LDS key array, which is idle exactly when the keys are in HBM.
+  const int FD = (keys != lkeys) ? L.ff_depth : 0;
+  bool ff = FD > 0;
+  int* ffT = reinterpret_cast<int*>(lkeys);                         // T_d starts at n_ini * (4^d - 4) / 3
+  const int ff_nT = L.n_ini * (((1 << (2 * FD + 2)) - 4) / 3);
+  uint16_t* f2l = reinterpret_cast<uint16_t*>(ffT + ff_nT);         // depth-D cell -> leaf
+  const int ff_nF = L.n_ini << (2 * FD);
+  uint16_t* infoA = f2l + ((ff_nF + 1) & ~1);                       // leaf -> depth << 12 | index at that depth
+  uint16_t* infoB = infoA + M;
+  auto ff_tab = [&](int d) { return ffT + L.n_ini * (((1 << (2 * d)) - 4) / 3); };
+  auto ff_cell = [&](unsigned long long kk) {   // index of the key's depth-D cell (KEY_NODE = root index)
+    const int r = KEY_NODE(kk), x = KEY_X(kk), y = KEY_Y(kk);
+    int x0 = (int16_t)(int)(L.hX * (float)r), x1 = (int16_t)(int)(L.hX * (float)(r + 1)), y0 = 0, y1 = (int16_t)L.height;
+    int idx = r;
+    for (int d = 0; d < FD; d++) {
+      const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+      const int qx = x >= mx ? 1 : 0, qy = y >= my ? 1 : 0;
+      if (qx) x0 = mx; else x1 = mx;
+      if (qy) y0 = my; else y1 = my;
+      idx = idx * 4 + qx + 2 * qy;
+    }
+    return idx;
+  };
+  auto ff_fill_f2l = [&](const uint16_t* info, int n) {   // every leaf marks the depth-D cells it covers
+    for (int p = tid; p < n; p += OCT_T) {
+      const int d = info[p] >> 12, sh = 2 * (FD - d);
+      const int first = (int)(info[p] & 0xfffu) << sh;
+      for (int i = 0; i < (1 << sh); i++) f2l[first + i] = (uint16_t)p;
+    }
+  };
+  auto ff_counts = [&](const OctNode* nodes, const uint16_t* info, int n) {   // quadrant counts of the multi-key leaves from the tables
+    for (int i = tid; i < n * 4; i += OCT_T) {
+      const int p = i >> 2;
+      if (nodes[p].cnt > 1) cnt4[i] = ff_tab((info[p] >> 12) + 1)[4 * (int)(info[p] & 0xfffu) + (i & 3)];
+    }
+  };
+  if (ff) {
+    for (int i = tid; i < ff_nT; i += OCT_T) ffT[i] = 0;
+    __syncthreads();
+    int* TD = ff_tab(FD);
+    for (int k0 = tid; k0 < C; k0 += 8 * OCT_T) {
+      unsigned long long kk[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) kk[j] = keys[min(k0 + j * OCT_T, C - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (k0 + j * OCT_T < C) atomicAdd(&TD[ff_cell(kk[j])], 1);
+    }
+    __syncthreads();
+    for (int d = FD - 1; d >= 1; d--) {
+      int* Td = ff_tab(d);
+      const int* Tc = ff_tab(d + 1);
+      for (int i = tid; i < (L.n_ini << (2 * d)); i += OCT_T) Td[i] = Tc[4 * i] + Tc[4 * i + 1] + Tc[4 * i + 2] + Tc[4 * i + 3];
+      __syncthreads();
+    }
+    if (tid < L.n_ini && ini_cnt[tid] > 0) infoA[ini_map[tid]] = (uint16_t)tid;   // depth 0
+    __syncthreads();
+    ff_counts(nodeA, infoA, size);
+  } else {
+    relabel_and_count(nodeA, [&](unsigned long long kk) { return ini_map[KEY_NODE(kk)]; });
+  }
   __syncthreads();
+  OCT_TP(2);
 
   // 4. subdivision loop (:581-709)
   int phase = 1;
@@ -1157,23 +1275,45 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
             const int pos = K - 1 - j;
             nodeB[pos] = ch;
             childpos[p * 4 + q] = (uint16_t)pos;
+            if (ff) infoB[pos] = (uint16_t)((((infoA[p] >> 12) + 1) << 12) | ((infoA[p] & 0xfffu) * 4 + q));
             j++;
           }
         }
       } else {
         nodeB[aux2[p]] = nd;
+        if (ff) infoB[aux2[p]] = infoA[p];
       }
     }
     __syncthreads();
     for (int i = tid; i < newsize * 4; i += OCT_T) cnt4[i] = 0;   // the build above was the last reader of this round's counts
-    __syncthreads();
-    relabel_and_count(nodeB, [&](unsigned long long kk) {
-      const int p = KEY_NODE(kk);
-      return aux[p] >= 0 ? (int)childpos[p * 4 + KEY_Q(kk)] : aux2[p];
-    });
+    if (ff) {   // a multi-key leaf at depth D: its quadrant counts are not in the tables
+      const bool last = newsize >= N || newsize == prev;   // the loop ends below: nobody reads the next round's counts
+      int deep = 0;
+      for (int p = tid; p < newsize; p += OCT_T) deep |= (nodeB[p].cnt > 1 && (infoB[p] >> 12) >= FD) ? 1 : 0;
+      deep = __syncthreads_or(deep);
+      OCT_TP(3);
+      if (last) {
+      } else if (!deep) {
+        ff_counts(nodeB, infoB, newsize);
+      } else {
+        ff_fill_f2l(infoB, newsize);
+        __syncthreads();
+        relabel_and_count(nodeB, [&](unsigned long long kk) { return (int)f2l[ff_cell(kk)]; });   // labels from here on
+        ff = false;
+      }
+      { uint16_t* t = infoA; infoA = infoB; infoB = t; }
+    } else {
+      __syncthreads();
+      OCT_TP(3);
+      relabel_and_count(nodeB, [&](unsigned long long kk) {
+        const int p = KEY_NODE(kk);
+        return aux[p] >= 0 ? (int)childpos[p * 4 + KEY_Q(kk)] : aux2[p];
+      });
+    }
     { OctNode* t = nodeA; nodeA = nodeB; nodeB = t; }
     size = newsize;
     __syncthreads();
+    OCT_TP(4);
 
     if (phase == 1) {
       // nToExpand = leaves with more than one key (all of them are new children)
@@ -1189,13 +1329,29 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     __syncthreads();
   }
 
+  OCT_TP(3);
   // 5. best key of every leaf: max response, first candidate wins ties (:712-728)
   uint32_t* best = reinterpret_cast<uint32_t*>(cnt4);
   for (int p = tid; p < size; p += OCT_T) best[p] = 0;
   __syncthreads();
-  for (int k = tid; k < C; k += OCT_T) {
-    const unsigned long long kk = keys[k];
-    atomicMax(&best[KEY_NODE(kk)], ((uint32_t)KEY_SCORE(kk) << 24) | (0xFFFFFFu - (uint32_t)k));
+  if (ff) {   // the tree was finished inside the tables: the keys never got labels, a key's leaf is its cell's
+    ff_fill_f2l(infoA, size);
+    __syncthreads();
+    for (int k0 = tid; k0 < C; k0 += 8 * OCT_T) {
+      unsigned long long kk[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) kk[j] = keys[min(k0 + j * OCT_T, C - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k = k0 + j * OCT_T;
+        if (k < C) atomicMax(&best[f2l[ff_cell(kk[j])]], ((uint32_t)KEY_SCORE(kk[j]) << 24) | (0xFFFFFFu - (uint32_t)k));
+      }
+    }
+  } else {
+    for (int k = tid; k < C; k += OCT_T) {
+      const unsigned long long kk = keys[k];
+      atomicMax(&best[KEY_NODE(kk)], ((uint32_t)KEY_SCORE(kk) << 24) | (0xFFFFFFu - (uint32_t)k));
+    }
   }
   __syncthreads();
   for (int p = tid; p < size; p += OCT_T) {
@@ -1210,6 +1366,8 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 #if FC_TIMING
     atomicAdd(&g_oct_prof[level], __builtin_readcyclecounter() - t_begin);
     atomicAdd(&g_oct_prof[32 + level], (unsigned long long)n_iter);
+    OCT_TP(5);
+    for (int i = 0; i < 6; i++) atomicAdd(&g_oct_prof[64 + 8 * level + i], tph[i]);
 #endif
   }
 }

@@ -509,6 +509,18 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     const size_t budget = 40 * 1024;
     e->lds_keys = fixed + 8 * 512 <= budget ? (int)((budget - fixed) / 8) : 512;
     e->oct_lds = orbfe_octree_lds_bytes(e->max_nodes, e->lds_keys);
+    // a level whose keys leave LDS takes its first ff_depth subdivisions from count tables kept in the idle LDS key array
+    // (octree_select_kernel): n_ini * (4 + .. + 4^D) counts, n_ini * 4^D cell -> leaf entries, two (depth, index) words per node
+    for (int l = 0; l < e->prm.n_levels; l++) {
+      OctLevel& o = e->oct[l];
+      o.ff_depth = 0;
+      for (int D = 1; D <= 5; D++) {
+        const size_t cells = (size_t)o.n_ini << (2 * D);
+        const size_t counts = (size_t)o.n_ini * (((size_t)1 << (2 * D + 2)) - 4) / 3;
+        const size_t need = counts * 4 + ((cells + 1) & ~(size_t)1) * 2 + (size_t)e->max_nodes * 4;
+        if (cells <= 4096 && need <= (size_t)e->lds_keys * 8) o.ff_depth = D;
+      }
+    }
     if (e->oct_lds > 160 * 1024) {
       orbfe_set_error("octree LDS %zu exceeds 160 KiB", e->oct_lds);
       return ORBFE_ERR_INVALID;

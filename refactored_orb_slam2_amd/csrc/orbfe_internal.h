@@ -77,6 +77,7 @@ struct OctLevel {
   int kp_off, kp_cap;       // slice of the per-image level-keypoint array
   unsigned long long key_off;  // offset (entries) of this level's global key fallback inside one image's block
   int key_cap;
+  int ff_depth;             // subdivisions a level with its keys in HBM takes from count tables (octree_select_kernel); 0: none
 };
 
 struct OctParams {

@@ -284,13 +284,28 @@ def test_unusual_geometries(w, h, nf):
     ex.close()
 
 
-def test_dense_texture_spills_keys_to_hbm():
-    """white noise: tens of thousands of FAST candidates per level (> the LDS key budget) -> global-key path"""
+@pytest.mark.parametrize("kind", ["white_noise", "noise_block", "noisy_frame", "two_blocks"])
+def test_dense_texture_spills_keys_to_hbm(kind):
+    """More FAST candidates per level than the LDS key budget -> the keys live in HBM and the quadtree takes its first subdivisions
+    from count tables (octree_select_kernel's fast-forward).  white noise: tens of thousands of candidates, evenly spread -- the tree
+    is finished inside the tables; a block of noise in a flat frame / two blocks: the tree goes deeper than the tables inside the
+    block, so labels are written mid-way and the explicit rounds take over; synthetic frame + sensor noise: level 0 only"""
     rng = np.random.default_rng(0)
-    img = rng.integers(0, 256, (376, 1241), dtype=np.uint8)
+    h, w = 376, 1241
+    if kind == "white_noise":
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "noise_block":
+        img = np.full((h, w), 90, np.uint8)
+        img[60:300, 700:1100] = rng.integers(0, 256, (240, 400), dtype=np.uint8)
+    elif kind == "two_blocks":
+        img = synth.frame(w, h, seq=3, f=0).copy()
+        img[20:200, 30:330] = rng.integers(0, 256, (180, 300), dtype=np.uint8)
+        img[150:370, 800:1230] = rng.integers(0, 256, (220, 430), dtype=np.uint8)
+    else:
+        img = np.clip(synth.frame(w, h, seq=5, f=0).astype(np.int16) + rng.integers(-8, 9, (h, w)), 0, 255).astype(np.uint8)
     ex = ORBextractor(2000)
     k, d = ex(img)
-    assert len(ex.debug_candidates(0, 0)[0]) > 8000
+    assert len(ex.debug_candidates(0, 0)[0]) > (8000 if kind == "white_noise" else 1700)
     ok, od = ol.OracleExtractor(2000)(img)
     np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
     ex.close()

@@ -38,7 +38,7 @@ print("describe8: waves",waves/R,"keypoints",kps/R,"cycles/wave",tot/max(waves,1
 for nme,x in zip(["tables+bookkeeping","wait raw patch","moments","angle sincos","wait blurred patch","BRIEF+stores"],v[:6]): print(f"{nme:20s} {x/max(kps,1):9.0f} cycles/keypoint  {100*x/max(tot,1):5.1f}%")
 
 # ---- octree_select_kernel: cycles and subdivision iterations per level
-out64=(C.c_ulonglong*64)()
+out64=(C.c_ulonglong*256)()
 L.orbfe_debug_oct_profile(out64,1)
 for _ in range(R): ex.extract_batch_device(d,k,de,n)
 ex.sync()
