@@ -55,6 +55,28 @@ __device__ __forceinline__ int block_incl_scan_t(int v, int* tmp, int* total) {
   return s + off;
 }
 
+// The same with ONE barrier: consecutive calls alternate between two slots of `tmp` (2 * T / WAVE ints, used by nothing else), so a
+// call's writes cannot meet the reads of the call before it -- those lie in front of this call's predecessor's barrier.
+template <int T>
+__device__ __forceinline__ int block_incl_scan_alt(int v, int* tmp, int& slot, int* total) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1), wid = tid >> 6;
+  const int s = wave_incl_scan(v);
+  int* t = tmp + slot * (T / WAVE);
+  slot ^= 1;
+  if (lane == WAVE - 1) t[wid] = s;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < T / WAVE; i++) {
+    const int x = t[i];
+    if (i < wid) off += x;
+    tot += x;
+  }
+  *total = tot;
+  return s + off;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   if (len == 1) return 0;
   while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
@@ -1149,6 +1171,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 
   // 4. subdivision loop (:581-709)
   int phase = 1;
+  int scan_slot = 0;
   bool finish = (size == 0);
   const int N = L.N;
   while (!finish) {
@@ -1157,23 +1180,36 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
 #endif
     const int prev = size;   // cnt4 holds the quadrant counts of every multi-key leaf of nodeA (relabel_and_count)
 
-    // which leaves split, and in which order their children are created
+    // which leaves split, and in which order their children are created.  (The rounds are a chain of barriers -- ~10 k of a
+    // workgroup's ~20 k cycles per round whatever the level holds -- so phase 1 takes one packed scan for the children's and the
+    // staying leaves' positions, counts the next round's expandable leaves while it builds them, and every thread reads only
+    // entries it wrote itself until the barrier behind the build.)
     int K = 0;        // number of children created
+    int S = 0;        // leaves that stay
     int nsplit = 0;
+    if (tid == 0) { sh[2] = 0; sh[3] = 0; }   // multi-key children created this round (nToExpand) / a leaf below the tables; set behind a barrier
     if (phase == 1) {
       // every multi-key leaf splits, in list order (:592-643)
-      int run = 0;
+      int run_c = 0, run_s = 0;
       for (int base = 0; base < size; base += OCT_T) {
         const int p = base + tid;
         int c = 0;
         if (p < size && nodeA[p].cnt > 1)
           c = (cnt4[p * 4] > 0) + (cnt4[p * 4 + 1] > 0) + (cnt4[p * 4 + 2] > 0) + (cnt4[p * 4 + 3] > 0);
+        const int st = (p < size && c == 0) ? 1 : 0;   // a multi-key leaf has a non-empty quadrant
         int tot;
-        const int incl = block_incl_scan_t<OCT_T>(c, scan_tmp, &tot);
-        if (p < size) aux[p] = c > 0 ? run + incl - c : -1;  // childbase, -1 = stays
-        run += tot;
+        const int incl = block_incl_scan_alt<OCT_T>(c | (st << 16), scan_tmp + 8, scan_slot, &tot);
+        if (p < size) {
+          aux[p] = c > 0 ? run_c + (incl & 0xffff) - c : -1;  // childbase, -1 = stays
+          if (st) aux2[p] = run_s + (incl >> 16) - 1;          // rank among the leaves that stay
+        }
+        run_c += tot & 0xffff;
+        run_s += tot >> 16;
       }
-      K = run;
+      K = run_c;
+      S = run_s;
+      for (int p = tid; p < size; p += OCT_T)
+        if (aux[p] < 0) aux2[p] += K;   // after the K new children, old order preserved
     } else {
       // phase 2 (:651-707): expandable leaves sorted by (size, address) ascending, walked from the back:
       // larger first, among equal sizes the later-created (= smaller list position) first; stop as soon as
@@ -1236,26 +1272,24 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
       }
       __syncthreads();
       K = sh[1];
-    }
-    __syncthreads();
-
-    // positions of the leaves that stay: after the K new children, old order preserved
-    int S = 0;
-    for (int base = 0; base < size; base += OCT_T) {
-      const int p = base + tid;
-      const int st = (p < size && aux[p] < 0) ? 1 : 0;
-      int tot;
-      const int incl = block_incl_scan_t<OCT_T>(st, scan_tmp, &tot);
-      if (st) aux2[p] = K + S + incl - 1;
-      S += tot;
+      __syncthreads();
+      // positions of the leaves that stay: after the K new children, old order preserved
+      for (int base = 0; base < size; base += OCT_T) {
+        const int p = base + tid;
+        const int st = (p < size && aux[p] < 0) ? 1 : 0;
+        int tot;
+        const int incl = block_incl_scan_t<OCT_T>(st, scan_tmp, &tot);
+        if (st) aux2[p] = K + S + incl - 1;
+        S += tot;
+      }
     }
     const int newsize = K + S;
     if (newsize > M) {  // cannot happen: M >= max(N + 3, 4 * nIni)
       if (tid == 0) { atomicOr(P.err, 2); P.lvl_n[(size_t)img * ORBFE_MAX_LEVELS + level] = 0; }
       return;
     }
-    __syncthreads();
     // build the new leaf array: children pushed to the front in creation order => reversed
+    int n_multi = 0;
     for (int p = tid; p < size; p += OCT_T) {
       const OctNode nd = nodeA[p];
       if (aux[p] >= 0) {
@@ -1276,6 +1310,7 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
             nodeB[pos] = ch;
             childpos[p * 4 + q] = (uint16_t)pos;
             if (ff) infoB[pos] = (uint16_t)((((infoA[p] >> 12) + 1) << 12) | ((infoA[p] & 0xfffu) * 4 + q));
+            n_multi += cq > 1 ? 1 : 0;
             j++;
           }
         }
@@ -1284,13 +1319,20 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
         if (ff) infoB[aux2[p]] = infoA[p];
       }
     }
+    {   // one add per wave: 256 adds to one LDS word are 256 passes through an LDS pipeline that four workgroups share
+      const int wsum = wave_incl_scan(n_multi);
+      if ((tid & (WAVE - 1)) == WAVE - 1 && wsum) atomicAdd(&sh[2], wsum);
+    }
     __syncthreads();
+    const int n_expand = sh[2];   // read here: thread 0 clears it again at the top of the next round, two barriers on
     for (int i = tid; i < newsize * 4; i += OCT_T) cnt4[i] = 0;   // the build above was the last reader of this round's counts
     if (ff) {   // a multi-key leaf at depth D: its quadrant counts are not in the tables
       const bool last = newsize >= N || newsize == prev;   // the loop ends below: nobody reads the next round's counts
-      int deep = 0;
-      for (int p = tid; p < newsize; p += OCT_T) deep |= (nodeB[p].cnt > 1 && (infoB[p] >> 12) >= FD) ? 1 : 0;
-      deep = __syncthreads_or(deep);
+      // (no __syncthreads_or: it brings 256 bytes of static LDS, and the fourth workgroup no longer fits the compute unit)
+      for (int p = tid; p < newsize; p += OCT_T)
+        if (nodeB[p].cnt > 1 && (infoB[p] >> 12) >= FD) sh[3] = 1;
+      __syncthreads();
+      const int deep = sh[3];
       OCT_TP(3);
       if (last) {
       } else if (!deep) {
@@ -1315,18 +1357,9 @@ __global__ __launch_bounds__(ORBFE_OCT_THREADS) void octree_select_kernel(OctPar
     __syncthreads();
     OCT_TP(4);
 
-    if (phase == 1) {
-      // nToExpand = leaves with more than one key (all of them are new children)
-      int ne = 0;
-      for (int p = tid; p < size; p += OCT_T) ne += nodeA[p].cnt > 1 ? 1 : 0;
-      int tot;
-      block_incl_scan_t<OCT_T>(ne, scan_tmp, &tot);
-      if (size >= N || size == prev) finish = true;
-      else if (size + 3 * tot > N) phase = 2;
-    } else {
-      if (size >= N || size == prev) finish = true;
-    }
-    __syncthreads();
+    // nToExpand = leaves with more than one key: in phase 1 all of them are this round's children (:645-649)
+    if (size >= N || size == prev) finish = true;
+    else if (phase == 1 && size + 3 * n_expand > N) phase = 2;
   }
 
   OCT_TP(3);

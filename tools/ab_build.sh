@@ -2,6 +2,8 @@
 # A/B builds of liborbfe.so for kernel experiments: tools/ab_build.sh <name> "<extra -D flags>" [file.hip | file.cpp ...]
 # Recompiles the named .hip files (default: extract_kernels.hip) with the extra flags and links them with the objects of the
 # regular build into refactored_orb_slam2_amd/csrc/_ab/liborbfe_<name>.so (git-ignored; travels to the GPU box).
+# NOTE: runs `make` first -- called on a `git stash`ed tree it rebuilds liborbfe.so from the stashed sources; run `make` again after
+# `git stash pop` (an A/B of "old vs new" was once old vs old that way).
 # Select it with ORBFE_AB_LIB=<name> in tools/stage_times.py / bench.py --ab-lib (tools only; the product loads liborbfe.so).
 set -e
 cd "$(dirname "$0")/../refactored_orb_slam2_amd/csrc"

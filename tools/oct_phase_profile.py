@@ -8,7 +8,7 @@ if os.environ.get("ORBFE_AB_LIB"): _lib.LIB_PATH = os.path.join(_lib.CSRC, "_ab"
 from refactored_orb_slam2_amd import ORBextractor, synth
 L = _lib.lib()
 kind = sys.argv[1] if len(sys.argv) > 1 else "uniform_noise"
-W, H, NF, B = 1241, 376, 2000, 128
+W, H, NF, B = 1241, 376, 2000, int(os.environ.get("B", "128"))
 rng = np.random.default_rng(7)
 if kind == "uniform_noise":
     imgs = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(8)]
