@@ -335,8 +335,10 @@ def main():
     ap.add_argument("--blur-kind", type=int, default=0, choices=(0, 1, 2),
                     help="A/B of the level chain (orbfe_debug_blur_kernel): 0 fused level kernels (default), 1 resize chain + matrix-core blur, "
                          "2 resize chain + one LDS blur launch (rounds 1-4)")
-    ap.add_argument("--lr-streams", type=int, default=1, choices=(1, 2),
-                    help="2: left/right extractors on two HIP streams (the reference uses two threads); 1: one stream")
+    ap.add_argument("--lr-streams", type=int, default=2, choices=(1, 2),
+                    help="2 (default): left / right extractor on two HIP streams, as the reference runs them on two threads (Frame.cc:87-90): "
+                         "their launches overlap and fill each other's tails; 1: one stream, every kernel alone on the chip (the per-stage times "
+                         "of `roofline.stage_ms_per_batch` are always measured that way, in an untimed pass)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -442,8 +444,10 @@ def main():
     sM, sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     evL, evR = torch.cuda.Event(), torch.cuda.Event()
 
+    lr = {"n": args.lr_streams}   # the stage-time passes switch to one stream: a launch's event time is then the kernel's own
+
     def _step(cur, B):
-        if STEREO and args.lr_streams == 2:
+        if STEREO and lr["n"] == 2:
             sL.wait_stream(cur); sR.wait_stream(cur)
             exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90: two threads)
             exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)   # ORBextractor right
@@ -509,19 +513,37 @@ def main():
                 tot[k] = (a[0] + v[0], a[1] + v[1])
         return tot
 
+    lr["n"] = 1
     for e in extractors:
         e.profile(True); e.stage_times(reset=True)
     for _ in range(3):
         step()
     barrier()
+    lr["n"] = args.lr_streams
     stage_ms_all = {k: (v[0] / max(v[1] // 2 if k == "pyramid" else v[1], 1)) for k, v in stage_sums().items()}
     # the dominant KERNEL: the level chain ("pyramid") is eight launches, none of them as long as FAST's one
     dom = max((k for k in stage_ms_all if k != "pyramid"), key=lambda k: stage_ms_all[k])
     # the dominant kernel is bracketed by HIP events on every DOM_EVERY-th step of the timed region: an event record in front of and
     # behind a launch leaves ~6 us of idle GPU each (kernel trace), 24 us per stereo step if every launch were timed (0.8 %)
     DOM_EVERY = 8
+    # the dominant kernel alone on the chip, timed without event records around the other stages (those leave idle gaps in front of
+    # it: FAST then finds less of the pyramid in the Infinity Cache): eight one-stream steps
+    lr["n"] = 1
+    for e in extractors:
+        e.profile(True, [dom]); e.stage_times(reset=True)
+    for _ in range(8):
+        step()
+    barrier()
+    lr["n"] = args.lr_streams
+    _sd = stage_sums()[dom]
+    stage_ms_all[dom] = _sd[0] / max(_sd[1] // 2 if dom == "pyramid" else _sd[1], 1)
     for e in extractors:
         e.profile(False); e.stage_times(reset=True)
+    for _ in range(2):
+        step()           # back on the timed region's stream layout
+    barrier()
+    ref_ev = torch.cuda.Event(enable_timing=True)   # the clock of the dominant kernel's launch intervals (orbfe_stage_intervals)
+    ref_ev.record(sM)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -560,6 +582,24 @@ def main():
             ev1.record(sM)
         torch.cuda.synchronize()
         coll_ms = ev0.elapsed_time(ev1) / 3
+    # the dominant kernel's timed launches as intervals on one clock: with the two extractors on two streams a launch's own
+    # first-to-last-event time contains the other launch's share of the chip; the UNION of the intervals is the time the chip spent on
+    # the kernel, and the bytes of all those launches over that time its achieved rate
+    dom_iv = []
+    for e in extractors:
+        dom_iv += [(a, b) for (st, a, b) in e.stage_intervals(ref_ev) if st == dom]
+    dom_iv.sort()
+    dom_union, cur_a, cur_b = 0.0, None, None
+    for a, b in dom_iv:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                dom_union += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        dom_union += cur_b - cur_a
+    dom_own = sum(b - a for a, b in dom_iv)
     st_dom = stage_sums()[dom]
     for e in extractors:
         e.profile(False)
@@ -645,11 +685,13 @@ def main():
             try:
                 tl, tr = content_images(kind)
                 B0.dL_full.copy_(tl); B0.dR_full.copy_(tr)
+                lr["n"] = 1
                 for e in extractors:
                     e.profile(True); e.stage_times(reset=True)
                 for _ in range(3):
                     step()
                 barrier()
+                lr["n"] = args.lr_streams
                 for e in extractors:
                     e.device_status()
                 st = {k: round(v[0] / max(v[1] // 2 if k == "pyramid" else v[1], 1), 4) for k, v in stage_sums().items()}
@@ -702,10 +744,12 @@ def main():
             "blur": 0 if args.blur_kind == 0 else 2 * sumP,
             "describe": NFEAT * (749 + 512 + 60),
         }
-        per_launch_ms = dict(stage_ms_all)   # untimed 3-step pass (every stage)
+        per_launch_ms = dict(stage_ms_all)   # untimed 3-step pass on ONE stream (every stage, every kernel alone on the chip)
         cnt = st_dom[1] // 2 if dom == "pyramid" else st_dom[1]   # pyramid: two timed groups (level-0 copy, resize chain) per batch
-        per_launch_ms[dom] = st_dom[0] / max(cnt, 1)              # the dominant kernel: live, over the timed region
-        achieved = alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9
+        own_ms = st_dom[0] / max(cnt, 1)                          # the dominant kernel: live, over the timed region, first to last event of a launch
+        n_iv = max(len(dom_iv), 1)
+        chip_ms = (dom_union / n_iv) if dom_iv else own_ms        # the chip's time per launch: union of the launches' intervals / launches
+        achieved = alg[dom] * F / (max(chip_ms, 1e-9) * 1e-3) / 1e9
         # HBM-side traffic of the dominant kernel: FETCH_SIZE (x2 for 16-byte-per-lane streams on gfx950) + WRITE_SIZE from the
         # committed PMC pass of THIS kernel build (profiles/rNN_pmc_dominant.json, latest round), scaled to this launch's image count;
         # null when the pass covers another kernel or configuration
@@ -738,7 +782,13 @@ def main():
                        "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
+                         "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(own_ms, 4),
+                         "chip_ms_per_launch": round(chip_ms, 4), "alone_ms_per_launch": round(per_launch_ms[dom], 4), "launches_overlapping": round(dom_own / max(dom_union, 1e-9), 2) if dom_iv else 1.0,
+                         "timed_launches": len(dom_iv), "lr_streams": lr["n"] if STEREO else 1,
+                         "duration_note": "avg_launch_ms: a launch's own first-to-last-event time in the timed region (what rocprofv3 --stats "
+                                          "averages); with the left and right extractor on two streams two launches share the chip, so `achieved` "
+                                          "= bytes of the timed launches / the union of their intervals (chip_ms_per_launch = union / launches); "
+                                          "stage_ms_per_batch: every stage alone on the chip (untimed one-stream pass)",
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
         if gatherer is not None:

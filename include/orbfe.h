@@ -182,6 +182,12 @@ enum {
 };
 int orbfe_profile_enable(orbfe_extractor* e, int enable);  /* 0 = off, 1 = every stage, otherwise a bit mask: bit (1 + stage) */
 int orbfe_stage_times(orbfe_extractor* e, float* ms /*[ORBFE_STAGE_COUNT]*/, int32_t* launches, int reset);
+/* The same events as intervals: for every stage launch timed since the last orbfe_stage_times / orbfe_stage_intervals call, its
+ * stage index and the milliseconds from ref_event (a hipEvent_t the caller recorded earlier on the same device, timing enabled) to
+ * the launch's first and last event.  Two handles that run side by side on two streams (left and right extractor) stretch each
+ * other's launches; the union of their intervals is the time the chip spent on that kernel (bench.py's roofline).  The launches
+ * also enter the totals of orbfe_stage_times.  At most cap intervals are written, *n receives their number. */
+int orbfe_stage_intervals(orbfe_extractor* e, void* ref_event, int32_t* stage, float* start_ms, float* end_ms, int cap, int32_t* n);
 
 /* --------------------------------------------------------------------------------------- ORBmatcher */
 /* Work-space handle of the matcher kernels (scratch HBM + a HIP stream).  One handle serves one thread at

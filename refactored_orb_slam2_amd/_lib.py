@@ -94,7 +94,7 @@ EXPORTS = [
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_pyramid_level", "orbfe_pyramid_level_size", "orbfe_pyramid_levels",
     "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_device_pyramid", "orbfe_device_pyramid_layout", "orbfe_sync",
     "orbfe_device_status", "orbfe_debug_candidates", "orbfe_debug_blurred", "orbfe_debug_blur_kernel", "orbfe_debug_pyramid",
-    "orbfe_debug_level_keypoints", "orbfe_profile_enable", "orbfe_stage_times",
+    "orbfe_debug_level_keypoints", "orbfe_profile_enable", "orbfe_stage_times", "orbfe_stage_intervals",
     "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_matcher_sync", "orbfe_proj_match_batch_device",
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device", "orbfe_stereo_match",
@@ -163,6 +163,7 @@ def lib():
     L.orbfe_debug_level_keypoints.argtypes = [vp, ci, ci, vp, vp, vp, ci, pi]
     L.orbfe_profile_enable.argtypes = [vp, ci]
     L.orbfe_stage_times.argtypes = [vp, vp, vp, ci]
+    L.orbfe_stage_intervals.argtypes = [vp, vp, vp, vp, vp, ci, vp]
     L.orbfe_hamming_matrix_device.argtypes = [vp, ci, vp, ci, vp, vp]
     L.orbfe_hamming_bf_device.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, vp]
     L.orbfe_matcher_create.argtypes = [ci, C.POINTER(vp)]

@@ -1349,6 +1349,32 @@ extern "C" int orbfe_profile_enable(orbfe_extractor* e, int enable) {
   return ORBFE_OK;
 }
 
+// The timed stage launches since the last drain as intervals on ref_event's clock (see include/orbfe.h): what a caller needs
+// to tell how long a kernel ran from how long the chip worked on it when two handles' launches overlap.
+extern "C" int orbfe_stage_intervals(orbfe_extractor* e, void* ref_event, int32_t* stage, float* start_ms, float* end_ms, int cap,
+                                     int32_t* n) {
+  if (!e || !ref_event || !n || cap < 0 || (cap > 0 && (!stage || !start_ms || !end_ms))) return ORBFE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  hipEvent_t ref = (hipEvent_t)ref_event;
+  int cnt = 0;
+  for (auto& p : e->ev_pending) {
+    float ms = 0, ta = 0, tb = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      e->stage_ms[p.stage] += ms;
+      e->stage_launches[p.stage] += 1;
+      if (cnt < cap && hipEventElapsedTime(&ta, ref, p.a) == hipSuccess && hipEventElapsedTime(&tb, ref, p.b) == hipSuccess) {
+        stage[cnt] = p.stage; start_ms[cnt] = ta; end_ms[cnt] = tb;
+        cnt++;
+      }
+    }
+    e->ev_pool.push_back(p.a);
+    e->ev_pool.push_back(p.b);
+  }
+  e->ev_pending.clear();
+  *n = cnt;
+  return ORBFE_OK;
+}
+
 extern "C" int orbfe_stage_times(orbfe_extractor* e, float* ms, int32_t* launches, int reset) {
   if (!e) return ORBFE_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);

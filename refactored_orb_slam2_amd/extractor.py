@@ -185,6 +185,14 @@ class ORBextractor:
             code = sum(2 << STAGES.index(s) for s in stages)
         _lib.check(self._L.orbfe_profile_enable(self._h, code), "orbfe_profile_enable")
 
+    def stage_intervals(self, ref_event, cap: int = 4096):
+        """(stage name, start ms, end ms) of every stage launch timed since the last drain, on the clock of `ref_event` (a
+        torch.cuda.Event(enable_timing=True) recorded earlier): orbfe_stage_intervals."""
+        st = np.zeros(cap, np.int32); a = np.zeros(cap, np.float32); b = np.zeros(cap, np.float32); n = np.zeros(1, np.int32)
+        _lib.check(self._L.orbfe_stage_intervals(self._h, C.c_void_p(int(ref_event.cuda_event)), _lib.ptr(st), _lib.ptr(a), _lib.ptr(b),
+                                                 cap, _lib.ptr(n)), "orbfe_stage_intervals")
+        return [(STAGES[int(st[i])], float(a[i]), float(b[i])) for i in range(int(n[0]))]
+
     def stage_times(self, reset: bool = True):
         ms = np.zeros(len(STAGES), np.float32)
         launches = np.zeros(len(STAGES), np.int32)
