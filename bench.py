@@ -339,6 +339,10 @@ def main():
                     help="2 (default): left / right extractor on two HIP streams, as the reference runs them on two threads (Frame.cc:87-90): "
                          "their launches overlap and fill each other's tails; 1: one stream, every kernel alone on the chip (the per-stage times "
                          "of `roofline.stage_ms_per_batch` are always measured that way, in an untimed pass)")
+    ap.add_argument("--sets", type=int, default=2, choices=(1, 2),
+                    help="2 (default, with --lr-streams 2): two sets of handles and buffers take the steps in turn -- the extraction of step "
+                         "k + 1 runs beside the matching half of step k (stereo match, unproject, track queries, projection search), which has its "
+                         "own stream; every step still does all of its work inside the timed region.  1: a step starts when the one before it has ended")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -398,6 +402,17 @@ def main():
             if e._L.orbfe_debug_blur_kernel(e._h, args.blur_kind) != 0:
                 raise SystemExit("orbfe_debug_blur_kernel refused the kind")
     mt = Matcher(local)
+    # the second set (--sets 2): its own extractors (the matching half of a step reads their pyramids: the stereo SAD windows) and matcher
+    two_sets = args.sets == 2 and args.lr_streams == 2 and STEREO and cfg["match"] == "projection"
+    exL1 = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if two_sets else None
+    exR1 = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if two_sets else None
+    mt1 = Matcher(local) if two_sets else None
+    if two_sets:
+        extractors += [exL1, exR1]
+        if args.blur_kind:
+            for e in (exL1, exR1):
+                if e._L.orbfe_debug_blur_kernel(e._h, args.blur_kind) != 0:
+                    raise SystemExit("orbfe_debug_blur_kernel refused the kind")
     import atexit
 
     def _close_handles():  # release the library handles while the HIP runtime is still alive, also after an exception
@@ -405,7 +420,7 @@ def main():
             torch.cuda.synchronize()
         except Exception:
             pass
-        for hnd in extractors + [mt]:
+        for hnd in extractors + [mt] + ([mt1] if mt1 is not None else []):
             try:
                 hnd.close()
             except Exception:
@@ -472,9 +487,44 @@ def main():
         if gatherer is not None:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
             gatherer.launch(B.nl, B.kl, B.dl)
 
+    # ---- two sets in turn (--sets 2): extraction of set k & 1 on sL / sR as soon as the matching half that last read that set (two
+    #      steps back) has ended; the matching half on sM behind the two extractions
+    B1 = Buffers() if two_sets else None
+    pipe_sets = [(exL, exR, mt, B0, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()),
+                 (exL1, exR1, mt1, B1, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())] if two_sets else None
+    pipe_k = {"k": 0}
+    if two_sets:
+        for ps in pipe_sets:
+            ps[6].record(sM)
+
+    def _step_piped():
+        xl, xr, m, B, eL, eR, eT = pipe_sets[pipe_k["k"] & 1]
+        pipe_k["k"] += 1
+        sL.wait_event(eT); sR.wait_event(eT)
+        xl.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)
+        xr.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)
+        eL.record(sL); eR.record(sR)
+        sM.wait_event(eL); sM.wait_event(eR)
+        m.stereo_match(xl, xr, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], mb, B.ur, B.depth, B.n_stereo, stream=sM)
+        unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, t_cams, 1, B.pts, sM)
+        track_queries_batch(t_poses, B.pts, B.nl, 1, B.q, B.nq, sM)
+        B.blocked.zero_(); B.assigned.fill_(-1)
+        m.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked, B.assigned,
+                           B.n_track, stream=sM)
+        if gatherer is not None:
+            gatherer.launch(B.nl, B.kl, B.dl)
+        eT.record(sM)
+
     def step():
         with torch.cuda.stream(sM):
-            _step(sM, B0)
+            if two_sets and lr["n"] == 2:
+                _step_piped()
+            else:
+                if two_sets:
+                    sM.wait_stream(sL); sM.wait_stream(sR)   # (a one-stream pass behind pipelined steps ...
+                _step(sM, B0)
+                if two_sets:
+                    pipe_sets[0][6].record(sM)               #  ... and in front of the next ones: set 0 is free when this step has ended)
 
     gatherer = None
     if args.gather_impl == "cabi" and backend == "nccl":
@@ -496,7 +546,7 @@ def main():
     barrier()
     for e in extractors:
         e.device_status()
-    n_img = len(extractors) * F
+    n_img = (2 if STEREO else 1) * F   # images per step (a second set of handles takes every other step: not more images)
     n_kp = int(B0.nl.sum().item()) + (int(B0.nr.sum().item()) if STEREO else 0)
     n_st = int(B0.n_stereo.sum().item())
     n_tr = int(B0.n_track.sum().item()) if cfg["match"] == "projection" else int((B0.bf.view(torch.int32)[..., 0] >= 0).sum().item())
@@ -685,6 +735,8 @@ def main():
             try:
                 tl, tr = content_images(kind)
                 B0.dL_full.copy_(tl); B0.dR_full.copy_(tr)
+                if two_sets:
+                    B1.dL_full.copy_(tl); B1.dR_full.copy_(tr)
                 lr["n"] = 1
                 for e in extractors:
                     e.profile(True); e.stage_times(reset=True)
@@ -716,6 +768,8 @@ def main():
             pk_l = torch.from_numpy(np.stack([p[0] for p in data])).to(dev); pk_r = torch.from_numpy(np.stack([p[1] for p in data])).to(dev)
             keepL, keepR = B0.dL, B0.dR
             B0.dL, B0.dR = pk_l, pk_r
+            if two_sets:
+                B1.dL, B1.dR = pk_l, pk_r
             for _ in range(3):
                 step()
             barrier()
@@ -726,10 +780,14 @@ def main():
             content["synthetic_packed_rows"] = {"frames_per_s": round(F * args.content_steps / (time.perf_counter() - tc), 1),
                                                 "note": f"the headline's images in tightly packed rows ({W} bytes apart): level 0 is a pitched copy"}
             B0.dL, B0.dR = keepL, keepR
+            if two_sets:
+                B1.dL, B1.dR = B1.dL_full[:, :, :W], B1.dR_full[:, :, :W]
         except Exception as ex:
             content["synthetic_packed_rows"] = {"error": str(ex)[:200]}
         B0.dL_full.copy_(hL); B0.dR_full.copy_(hR)
-        step(); barrier()
+        if two_sets:
+            B1.dL_full.copy_(hL); B1.dR_full.copy_(hR)
+        step(); step(); barrier()
 
     if rank == 0:
         px = [exL.level_size(l, W, H) for l in range(NLEVELS)]
@@ -775,20 +833,25 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "input_layout": f"u8 images resident in HBM, rows {PITCH} bytes apart (16-byte aligned: level 0 of the pyramid in place)",
             "config": {"workload": cfg["label"], "name": args.config, "frames_per_gpu_per_step": F,
+                       "step_layout": ("left and right extractor on two HIP streams; two sets of handles and buffers take the steps in turn: the "
+                                       "extraction of step k + 1 runs beside the matching half of step k (third stream)") if two_sets else
+                                      (f"one set of handles; extractors on {args.lr_streams if STEREO else 1} stream(s), a step starts when the one before it has ended"),
                        "images_per_step": n_img * world, "parallelism": f"frame-shard x{world}",
                        "collective": ((f"{'RCCL through the C ABI (orbfe_gather_records)' if (args.gather_impl == 'cabi' and backend == 'nccl') else backend} "
                                        f"{'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {world}") if gatherer is not None else "none"),
                        "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
                        "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "frac_alone": round(alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(own_ms, 4),
                          "chip_ms_per_launch": round(chip_ms, 4), "alone_ms_per_launch": round(per_launch_ms[dom], 4), "launches_overlapping": round(dom_own / max(dom_union, 1e-9), 2) if dom_iv else 1.0,
-                         "timed_launches": len(dom_iv), "lr_streams": lr["n"] if STEREO else 1,
+                         "timed_launches": len(dom_iv), "lr_streams": lr["n"] if STEREO else 1, "handle_sets": 2 if two_sets else 1,
                          "duration_note": "avg_launch_ms: a launch's own first-to-last-event time in the timed region (what rocprofv3 --stats "
                                           "averages); with the left and right extractor on two streams two launches share the chip, so `achieved` "
                                           "= bytes of the timed launches / the union of their intervals (chip_ms_per_launch = union / launches); "
-                                          "stage_ms_per_batch: every stage alone on the chip (untimed one-stream pass)",
+                                          "stage_ms_per_batch / alone_ms_per_launch / frac_alone: every stage alone on the chip (untimed one-stream passes); with two handle "
+                                          "sets the matching half of the step before also shares the chip with the timed launches",
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
         if gatherer is not None:
