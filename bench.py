@@ -577,16 +577,17 @@ def main():
     # behind a launch leaves ~6 us of idle GPU each (kernel trace), 24 us per stereo step if every launch were timed (0.8 %)
     DOM_EVERY = 8
     # the dominant kernel alone on the chip, timed without event records around the other stages (those leave idle gaps in front of
-    # it: FAST then finds less of the pyramid in the Infinity Cache): eight one-stream steps
+    # it: FAST then finds less of the pyramid in the Infinity Cache): sixteen one-stream steps -- the `roofline` figure
     lr["n"] = 1
     for e in extractors:
         e.profile(True, [dom]); e.stage_times(reset=True)
-    for _ in range(8):
+    for _ in range(16):
         step()
     barrier()
     lr["n"] = args.lr_streams
     _sd = stage_sums()[dom]
-    stage_ms_all[dom] = _sd[0] / max(_sd[1] // 2 if dom == "pyramid" else _sd[1], 1)
+    dom_alone_launches = max(_sd[1] // 2 if dom == "pyramid" else _sd[1], 1)
+    stage_ms_all[dom] = _sd[0] / dom_alone_launches
     for e in extractors:
         e.profile(False); e.stage_times(reset=True)
     for _ in range(2):
@@ -808,6 +809,7 @@ def main():
         n_iv = max(len(dom_iv), 1)
         chip_ms = (dom_union / n_iv) if dom_iv else own_ms        # the chip's time per launch: union of the launches' intervals / launches
         achieved = alg[dom] * F / (max(chip_ms, 1e-9) * 1e-3) / 1e9
+        achieved_alone = alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9
         # HBM-side traffic of the dominant kernel: FETCH_SIZE (x2 for 16-byte-per-lane streams on gfx950) + WRITE_SIZE from the
         # committed PMC pass of THIS kernel build (profiles/rNN_pmc_dominant.json, latest round), scaled to this launch's image count;
         # null when the pass covers another kernel or configuration
@@ -841,17 +843,21 @@ def main():
                                        f"{'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {world}") if gatherer is not None else "none"),
                        "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
                        "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "frac_alone": round(alg[dom] * F / (max(per_launch_ms[dom], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(own_ms, 4),
-                         "chip_ms_per_launch": round(chip_ms, 4), "alone_ms_per_launch": round(per_launch_ms[dom], 4), "launches_overlapping": round(dom_own / max(dom_union, 1e-9), 2) if dom_iv else 1.0,
-                         "timed_launches": len(dom_iv), "lr_streams": lr["n"] if STEREO else 1, "handle_sets": 2 if two_sets else 1,
-                         "duration_note": "avg_launch_ms: a launch's own first-to-last-event time in the timed region (what rocprofv3 --stats "
-                                          "averages); with the left and right extractor on two streams two launches share the chip, so `achieved` "
-                                          "= bytes of the timed launches / the union of their intervals (chip_ms_per_launch = union / launches); "
-                                          "stage_ms_per_batch / alone_ms_per_launch / frac_alone: every stage alone on the chip (untimed one-stream passes); with two handle "
-                                          "sets the matching half of the step before also shares the chip with the timed launches",
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved_alone, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved_alone / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
+                         "measured": (f"HIP events on the launch stream around {dom_alone_launches} launches of the kernel in a one-stream pass of this run (every "
+                                      "kernel alone on the chip: the figure rocprofv3 --stats and the serialised --pmc passes can be compared with -- "
+                                      "profiles/rNN_kernel_stats.md, one-stream table).  In the TIMED region launches overlap by design (left | right "
+                                      "extractor on two streams, the matching half of the step before on a third), a launch's own duration there contains "
+                                      "the others' share of the chip: see timed_region"),
+                         "timed_region": {"avg_launch_ms": round(own_ms, 4), "chip_ms_per_launch": round(chip_ms, 4),
+                                          "launches_overlapping": round(dom_own / max(dom_union, 1e-9), 2) if dom_iv else 1.0,
+                                          "timed_launches": len(dom_iv), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                          "lr_streams": lr["n"] if STEREO else 1, "handle_sets": 2 if two_sets else 1,
+                                          "note": "HIP events around the kernel's launches on every 8th step of the timed region (orbfe_stage_intervals): "
+                                                  "avg_launch_ms = a launch's own first-to-last-event time; chip_ms_per_launch = union of the launches' "
+                                                  "intervals / launches; achieved = their algorithmic bytes / that union"},
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
         if gatherer is not None:

@@ -64,7 +64,7 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
         head = "bench line not parsed"
     with open(out_prefix + "_kernel_stats.md", "w") as f:
         f.write(f"# {os.path.basename(out_prefix)}: rocprofv3 kernel stats of the bench step\n\n"
-                "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0` "
+                "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0` (the default layout: overlapping launches, see below) "
                 f"(tools/profile_round.sh), times in microseconds per launch of 256 images; {head}.\n\n")
         f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
         for r in rows:
@@ -76,12 +76,34 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
                 "frames, one copy per image, before the first step) and result read-back; the kernel trace of a steady-state step holds none of "
                 "them (two `at::native` fills of the match buffers excepted).  Percentages are of the whole profiled process.\n")
     avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+    one = glob.glob(os.path.join(tag_dir, "**", "stats1_kernel_stats.csv"), recursive=True)
+    if one:   # the one-stream pass: every kernel alone on the chip -- the durations the PMC tables go with
+        rows1 = list(csv.DictReader(open(one[0])))
+        avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows1}
+        l1 = [l for l in open(os.path.join(tag_dir, "stats1.log")).read().split("\n") if l.startswith("{")]
+        try:
+            b1 = json.loads(l1[-1])
+            head1 = f"{b1['value']:.0f} {b1['unit']} under the profiler ({b1['ms_per_step']:.3f} ms per step)"
+        except Exception:
+            head1 = "bench line not parsed"
+        with open(out_prefix + "_kernel_stats.md", "a") as f:
+            f.write("\n## One stream, one set of handles: every kernel alone on the chip\n\n"
+                    "`... bench.py --steps 10 --warmup 2 ... --lr-streams 1 --sets 1`: a step starts when the one before it has ended, left and right "
+                    f"extractor on the same stream; {head1}.  In the default run above the left and right extractor's launches overlap (two streams) and the "
+                    "matching half of the step before runs beside them (two handle sets in turn), so a launch's own duration there contains the other "
+                    "launches' share of the chip; `bench.py` reports both (`roofline.avg_launch_ms` = this table, `roofline.timed_region.avg_launch_ms` = a launch's own duration inside the overlapped timed region; under the profiler the launches interleave differently than in a plain run, so the table above is not that figure).\n\n")
+            f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
+            for r in rows1:
+                if float(r["Percentage"]) < 0.05:
+                    continue
+                f.write(f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | "
+                        f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
     cs = counters(tag_dir)
     with open(out_prefix + "_pmc_counters.md", "w") as f:
         f.write(f"# {os.path.basename(out_prefix)}: PMC counters per kernel launch (256 KITTI images / stereo frames per launch)\n\n"
                 "Separate `rocprofv3 --kernel-trace --pmc <set>` passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0` "
                 "(tools/profile_round.sh: two SQ sets, FETCH_SIZE, WRITE_SIZE, TCC hit/miss, GRBM_GUI_ACTIVE), averaged over the later launches of "
-                "each kernel; durations from the `--stats` pass of the same build.  FETCH / WRITE are KB as rocprofv3 reports them; FETCH is doubled "
+                "each kernel (rocprofv3 serialises kernels in counter passes); durations from the one-stream `--stats` pass of the same build.  FETCH / WRITE are KB as rocprofv3 reports them; FETCH is doubled "
                 "(x2) for kernels whose bulk reads are coalesced 16-byte-per-lane loads, which gfx950 tallies at half their bytes "
                 "(MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted, so read them as fabric-side traffic.  SQ_WAVE_CYCLES, "
                 "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles summed over waves.  `VALU busy` = SQ_ACTIVE_INST_VALU x 4 clocks / (1024 SIMDs x kernel "

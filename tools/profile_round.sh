@@ -1,12 +1,16 @@
 #!/bin/bash
 # Raw data behind profiles/rNN_*: tools/profile_round.sh <tag> [bench args, e.g. --config tum_bow]   (run through gpurun from the repo root)
-#   one rocprofv3 --kernel-trace --stats pass of bench.py, then separate --pmc passes (never combined with other trace
+#   one rocprofv3 --kernel-trace --stats pass of bench.py as it runs by default (extractors on two streams, two handle sets in turn: launches
+#   overlap), one with --lr-streams 1 --sets 1 (every kernel alone on the chip), then separate --pmc passes (rocprofv3 serialises kernels there) (never combined with other trace
 #   domains): two SQ sets, FETCH_SIZE, WRITE_SIZE, TCC hit/miss, the fabric requests by size (TCC_EA0_RDREQ / _32B / _128B, TCC_EA0_WRREQ / _64B).  tools/profile_report.py turns gpurun_out/<tag>/ into
 #   the markdown / json files committed under profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; shift; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
 tail -1 $OUT/stats.log | cut -c1-200
+# the same with every kernel alone on the chip (one stream, one set of handles): the per-kernel durations of the PMC tables
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats1 -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 --lr-streams 1 --sets 1 "$@" > $OUT/stats1.log 2>&1 || { echo "one-stream stats pass failed"; tail -3 $OUT/stats1.log; exit 1; }
+tail -1 $OUT/stats1.log | cut -c1-200
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
