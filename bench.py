@@ -339,10 +339,11 @@ def main():
                     help="2 (default): left / right extractor on two HIP streams, as the reference runs them on two threads (Frame.cc:87-90): "
                          "their launches overlap and fill each other's tails; 1: one stream, every kernel alone on the chip (the per-stage times "
                          "of `roofline.stage_ms_per_batch` are always measured that way, in an untimed pass)")
-    ap.add_argument("--sets", type=int, default=2, choices=(1, 2),
-                    help="2 (default, with --lr-streams 2): two sets of handles and buffers take the steps in turn -- the extraction of step "
+    ap.add_argument("--sets", type=int, default=3, choices=(1, 2, 3, 4),
+                    help="S > 1 (default 3, with --lr-streams 2): S sets of handles and buffers take the steps in turn -- the extraction of step "
                          "k + 1 runs beside the matching half of step k (stereo match, unproject, track queries, projection search), which has its "
-                         "own stream; every step still does all of its work inside the timed region.  1: a step starts when the one before it has ended")
+                         "own stream, and waits only for the matching half that last read ITS set, S steps back; every step still does all of its "
+                         "work inside the timed region.  1: a step starts when the one before it has ended")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -403,14 +404,15 @@ def main():
                 raise SystemExit("orbfe_debug_blur_kernel refused the kind")
     mt = Matcher(local)
     # the second set (--sets 2): its own extractors (the matching half of a step reads their pyramids: the stereo SAD windows) and matcher
-    two_sets = args.sets == 2 and args.lr_streams == 2 and STEREO and cfg["match"] == "projection"
-    exL1 = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if two_sets else None
-    exR1 = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if two_sets else None
-    mt1 = Matcher(local) if two_sets else None
-    if two_sets:
-        extractors += [exL1, exR1]
+    two_sets = args.sets >= 2 and args.lr_streams == 2 and STEREO and cfg["match"] == "projection"
+    n_sets = args.sets if two_sets else 1
+    more_ex, more_mt = [], []
+    for _ in range(n_sets - 1):
+        more_ex.append((ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local), ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)))
+        more_mt.append(Matcher(local))
+        extractors += list(more_ex[-1])
         if args.blur_kind:
-            for e in (exL1, exR1):
+            for e in more_ex[-1]:
                 if e._L.orbfe_debug_blur_kernel(e._h, args.blur_kind) != 0:
                     raise SystemExit("orbfe_debug_blur_kernel refused the kind")
     import atexit
@@ -420,7 +422,7 @@ def main():
             torch.cuda.synchronize()
         except Exception:
             pass
-        for hnd in extractors + [mt] + ([mt1] if mt1 is not None else []):
+        for hnd in extractors + [mt] + more_mt:
             try:
                 hnd.close()
             except Exception:
@@ -489,16 +491,17 @@ def main():
 
     # ---- two sets in turn (--sets 2): extraction of set k & 1 on sL / sR as soon as the matching half that last read that set (two
     #      steps back) has ended; the matching half on sM behind the two extractions
-    B1 = Buffers() if two_sets else None
-    pipe_sets = [(exL, exR, mt, B0, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()),
-                 (exL1, exR1, mt1, B1, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())] if two_sets else None
+    more_B = [Buffers() for _ in range(n_sets - 1)]
+    pipe_sets = ([(exL, exR, mt, B0, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())] +
+                 [(more_ex[i][0], more_ex[i][1], more_mt[i], more_B[i], torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+                  for i in range(n_sets - 1)]) if two_sets else None
     pipe_k = {"k": 0}
     if two_sets:
         for ps in pipe_sets:
             ps[6].record(sM)
 
     def _step_piped():
-        xl, xr, m, B, eL, eR, eT = pipe_sets[pipe_k["k"] & 1]
+        xl, xr, m, B, eL, eR, eT = pipe_sets[pipe_k["k"] % n_sets]
         pipe_k["k"] += 1
         sL.wait_event(eT); sR.wait_event(eT)
         xl.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)
@@ -590,7 +593,7 @@ def main():
     stage_ms_all[dom] = _sd[0] / dom_alone_launches
     for e in extractors:
         e.profile(False); e.stage_times(reset=True)
-    for _ in range(2):
+    for _ in range(max(n_sets, 2)):
         step()           # back on the timed region's stream layout
     barrier()
     ref_ev = torch.cuda.Event(enable_timing=True)   # the clock of the dominant kernel's launch intervals (orbfe_stage_intervals)
@@ -736,8 +739,8 @@ def main():
             try:
                 tl, tr = content_images(kind)
                 B0.dL_full.copy_(tl); B0.dR_full.copy_(tr)
-                if two_sets:
-                    B1.dL_full.copy_(tl); B1.dR_full.copy_(tr)
+                for Bx in more_B:
+                    Bx.dL_full.copy_(tl); Bx.dR_full.copy_(tr)
                 lr["n"] = 1
                 for e in extractors:
                     e.profile(True); e.stage_times(reset=True)
@@ -769,8 +772,8 @@ def main():
             pk_l = torch.from_numpy(np.stack([p[0] for p in data])).to(dev); pk_r = torch.from_numpy(np.stack([p[1] for p in data])).to(dev)
             keepL, keepR = B0.dL, B0.dR
             B0.dL, B0.dR = pk_l, pk_r
-            if two_sets:
-                B1.dL, B1.dR = pk_l, pk_r
+            for Bx in more_B:
+                Bx.dL, Bx.dR = pk_l, pk_r
             for _ in range(3):
                 step()
             barrier()
@@ -781,14 +784,16 @@ def main():
             content["synthetic_packed_rows"] = {"frames_per_s": round(F * args.content_steps / (time.perf_counter() - tc), 1),
                                                 "note": f"the headline's images in tightly packed rows ({W} bytes apart): level 0 is a pitched copy"}
             B0.dL, B0.dR = keepL, keepR
-            if two_sets:
-                B1.dL, B1.dR = B1.dL_full[:, :, :W], B1.dR_full[:, :, :W]
+            for Bx in more_B:
+                Bx.dL, Bx.dR = Bx.dL_full[:, :, :W], Bx.dR_full[:, :, :W]
         except Exception as ex:
             content["synthetic_packed_rows"] = {"error": str(ex)[:200]}
         B0.dL_full.copy_(hL); B0.dR_full.copy_(hR)
-        if two_sets:
-            B1.dL_full.copy_(hL); B1.dR_full.copy_(hR)
-        step(); step(); barrier()
+        for Bx in more_B:
+            Bx.dL_full.copy_(hL); Bx.dR_full.copy_(hR)
+        for _ in range(n_sets):
+            step()
+        barrier()
 
     if rank == 0:
         px = [exL.level_size(l, W, H) for l in range(NLEVELS)]
@@ -835,7 +840,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "input_layout": f"u8 images resident in HBM, rows {PITCH} bytes apart (16-byte aligned: level 0 of the pyramid in place)",
             "config": {"workload": cfg["label"], "name": args.config, "frames_per_gpu_per_step": F,
-                       "step_layout": ("left and right extractor on two HIP streams; two sets of handles and buffers take the steps in turn: the "
+                       "step_layout": (f"left and right extractor on two HIP streams; {n_sets} sets of handles and buffers take the steps in turn: the "
                                        "extraction of step k + 1 runs beside the matching half of step k (third stream)") if two_sets else
                                       (f"one set of handles; extractors on {args.lr_streams if STEREO else 1} stream(s), a step starts when the one before it has ended"),
                        "images_per_step": n_img * world, "parallelism": f"frame-shard x{world}",
@@ -854,7 +859,7 @@ def main():
                          "timed_region": {"avg_launch_ms": round(own_ms, 4), "chip_ms_per_launch": round(chip_ms, 4),
                                           "launches_overlapping": round(dom_own / max(dom_union, 1e-9), 2) if dom_iv else 1.0,
                                           "timed_launches": len(dom_iv), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
-                                          "lr_streams": lr["n"] if STEREO else 1, "handle_sets": 2 if two_sets else 1,
+                                          "lr_streams": lr["n"] if STEREO else 1, "handle_sets": n_sets,
                                           "note": "HIP events around the kernel's launches on every 8th step of the timed region (orbfe_stage_intervals): "
                                                   "avg_launch_ms = a launch's own first-to-last-event time; chip_ms_per_launch = union of the launches' "
                                                   "intervals / launches; achieved = their algorithmic bytes / that union"},

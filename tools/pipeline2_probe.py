@@ -33,7 +33,8 @@ class Set:
         self.pts, self.q, self.nq = z(F, cap, 60), z(F, cap, 68), z(F, dt=torch.int32)
         self.evL, self.evR, self.evT = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
-sets = [Set(), Set()]
+NSETS = int(os.environ.get("NSETS", "2"))
+sets = [Set() for _ in range(NSETS)]
 cams_np, poses_np = bench.camera_records(F, sets[0].exL.GetScaleFactors(), cfg)
 t_cams = torch.from_numpy(cams_np.view(np.uint8).reshape(F, -1)).to(dev)
 t_poses = torch.from_numpy(poses_np.view(np.uint8).reshape(F, -1)).to(dev)
@@ -63,9 +64,29 @@ def plain(k):      # bench.py: the next extraction waits for the whole step befo
     extract(S); tail(S)
 
 def piped(k):      # the next extraction only waits for the matching half that last read ITS set (two steps back)
-    S = sets[k & 1]
+    S = sets[k % NSETS]
     sL.wait_event(S.evT); sR.wait_event(S.evT)
     extract(S); tail(S)
+
+# fully independent sets: each has its own three streams and runs its steps back to back; the chip sees NSETS steps in flight
+own = [(torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)) for _ in range(NSETS)]
+
+def indep(k):
+    S = sets[k % NSETS]
+    m, l, r = own[k % NSETS]
+    l.wait_event(S.evT); r.wait_event(S.evT)
+    S.exL.extract_batch_device(dL, S.kl, S.dl, S.nl, stream=l)
+    S.exR.extract_batch_device(dR, S.kr, S.dr, S.nr, stream=r)
+    S.evL.record(l); S.evR.record(r)
+    with torch.cuda.stream(m):
+        m.wait_event(S.evL); m.wait_event(S.evR)
+        S.mt.stereo_match(S.exL, S.exR, S.kl, S.dl, S.nl, S.kr, S.dr, S.nr, cfg["bf"], mb, S.ur, S.depth, S.n_stereo, stream=m)
+        unproject_stereo_batch(S.kl, S.dl, S.nl, S.depth, t_cams, 1, S.pts, m)
+        track_queries_batch(t_poses, S.pts, S.nl, 1, S.q, S.nq, m)
+        S.blocked.zero_(); S.assigned.fill_(-1)
+        S.mt.proj_match_batch(S.kl, S.dl, S.nl, S.ur, (0.0, float(W), 0.0, float(H)), S.q, S.nq, 1, 0.9, True, S.blocked, S.assigned,
+                              S.n_track, stream=m)
+        S.evT.record(m)
 
 def run(fn, K):
     for k in range(4): fn(k)
@@ -78,7 +99,7 @@ def run(fn, K):
 K = int(os.environ.get("K", "100"))
 for S in sets: S.evT.record(sM)
 res = {}
-for name, fn in (("plain", plain), ("piped", piped), ("plain2", plain), ("piped2", piped)):
+for name, fn in (("plain", plain), ("piped", piped), ("indep", indep), ("piped2", piped), ("indep2", indep)):
     res[name] = round(run(fn, K), 1)
 res["n_track"] = [int(S.n_track.sum().item()) for S in sets]
 print(json.dumps(res))
