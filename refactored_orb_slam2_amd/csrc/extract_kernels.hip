@@ -1594,27 +1594,26 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
       const int tiles_y = (h + 7) >> 3, tiles_x = pitch >> 4;
       const uint32_t tstep = (uint32_t)tiles_x << 7;
       // piece -> (tile row, tile column, row inside the tile): eight (three) consecutive lanes share a tile
+      // (integer forms of / 3 and / 6 for the small arguments here: (x * 43) >> 7 and >> 8; the mapping is computed once and kept --
+      //  recomputing it for the stores was a tenth of the kernel's vector instructions)
       auto piece = [&](int pid, int& tyi, int& txi, int& rr) {
-        if (pid < N_TOP) { txi = (int)((pid + 0.5f) * (1.0f / 3.0f)); rr = 5 + pid - 3 * txi; tyi = 0; }
-        else if (pid < N_TOP + N_MID) { const int q = pid - N_TOP, tl = q >> 3; rr = q & 7; tyi = (int)((tl + 0.5f) * (1.0f / 6.0f)); txi = tl - 6 * tyi; tyi += 1; }
-        else { const int q = pid - N_TOP - N_MID; txi = (int)((q + 0.5f) * (1.0f / 3.0f)); rr = q - 3 * txi; tyi = 8; }
+        if (pid < N_TOP) { txi = (pid * 43) >> 7; rr = 5 + pid - 3 * txi; tyi = 0; }
+        else if (pid < N_TOP + N_MID) { const int q = pid - N_TOP, tl = q >> 3; rr = q & 7; tyi = (tl * 43) >> 8; txi = tl - 6 * tyi; tyi += 1; }
+        else { const int q = pid - N_TOP - N_MID; txi = (q * 43) >> 7; rr = q - 3 * txi; tyi = 8; }
       };
       uint4 pv[NP];
+      uint32_t lds_at[NP];
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         int tyi, txi, rr;
         piece(min(tid + k * THREADS, N_ALL - 1), tyi, txi, rr);
         const int tr = min(max(ty0 + tyi, 0), tiles_y - 1), tc = min(max(tx0 + txi, 0), tiles_x - 1);   // clamped: a valid address in any case
         pv[k] = *reinterpret_cast<const uint4*>(S + (uint32_t)tr * tstep + ((uint32_t)tc << 7) + (uint32_t)(rr * 16));
+        lds_at[k] = (uint32_t)((tyi * 8 + rr - 5) * BT_INP + 16 * txi);   // window row (ty0 + tyi) * 8 + rr - (oy - 3)
       }
 #pragma unroll
-      for (int k = 0; k < NP; k++) {
-        int tyi, txi, rr;
-        const int pid = tid + k * THREADS;
-        piece(min(pid, N_ALL - 1), tyi, txi, rr);
-        const int wr = tyi * 8 + rr - 5;   // = (ty0 + tyi) * 8 + rr - (oy - 3)
-        if (pid < N_ALL) *reinterpret_cast<uint4*>(in + wr * BT_INP + 16 * txi) = pv[k];
-      }
+      for (int k = 0; k < NP; k++)
+        if (tid + k * THREADS < N_ALL) *reinterpret_cast<uint4*>(in + lds_at[k]) = pv[k];
       if (!interior) {
         // REFLECT_101 at the level's edges, inside LDS: what the passes read outside the level is within three pixels of it, and
         // the pixels those reflect to lie inside the window.  Columns first (rows inside the level), then whole rows.
