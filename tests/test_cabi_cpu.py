@@ -80,6 +80,8 @@ def test_argument_validation_without_compute(L):
     assert L.orbfe_extractor_create(C.byref(bad), -1, C.byref(h)) == _lib.ERR_INVALID
     assert L.orbfe_extractor_destroy(None) == 0 and L.orbfe_matcher_destroy(None) == 0
     assert L.orbfe_sync(None) == _lib.ERR_INVALID
+    n = C.c_int32(7)
+    assert L.orbfe_stage_intervals(None, None, None, None, None, 0, C.byref(n)) == _lib.ERR_INVALID and n.value == 7
 
 
 def test_pipeline_handle_validates_and_has_no_cpu_fallback(L):

@@ -120,6 +120,44 @@ def test_batch_equals_single_and_is_idempotent():
     ex.close()
 
 
+def test_stage_intervals_share_one_clock():
+    """orbfe_stage_intervals: the timed stage launches of two handles that run side by side on two streams, as intervals on the clock of
+    one caller-recorded event -- ordered inside a handle, overlapping across the handles, and adding up to orbfe_stage_times' totals"""
+    import torch
+    w, h, nf, B = 1241, 376, 2000, 32
+    imgs = torch.from_numpy(np.stack(synth.sequence(w, h, B, seq=9))).cuda()
+    exs = [ORBextractor(nf), ORBextractor(nf)]
+    cap = exs[0].max_keypoints(w, h)
+    outs = [(torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+             torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in exs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for e, o, s in zip(exs, outs, streams):
+        e.extract_batch_device(imgs, *o, stream=s)       # warm-up (plan, buffers)
+    torch.cuda.synchronize()
+    ref = torch.cuda.Event(enable_timing=True)
+    ref.record(streams[0])
+    torch.cuda.synchronize()
+    for e in exs:
+        e.profile(True); e.stage_times(reset=True)
+    for _ in range(3):
+        for e, o, s in zip(exs, outs, streams):
+            e.extract_batch_device(imgs, *o, stream=s)
+    torch.cuda.synchronize()
+    ivs = [e.stage_intervals(ref) for e in exs]
+    for e, iv in zip(exs, ivs):
+        assert len(iv) >= 3 * 5 and all(b > a >= 0 for _, a, b in iv)
+        assert all(iv[i][1] >= iv[i - 1][2] - 1e-3 for i in range(1, len(iv)))          # one stream: launch after launch
+        tot = e.stage_times()
+        for st in ("fast", "describe"):
+            assert abs(sum(b - a for s_, a, b in iv if s_ == st) - tot[st][0]) < 1e-2 and tot[st][1] == 3
+        assert e.stage_intervals(ref) == []                                              # drained
+    lo = max(iv[0][1] for iv in ivs); hi = min(iv[-1][2] for iv in ivs)
+    assert lo < hi                                                                       # the two handles' spans overlap
+    np.testing.assert_array_equal(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy())
+    for e in exs:
+        e.profile(False); e.close()
+
+
 def test_aligned_device_images_are_level0_in_place():
     """Device images whose rows start on 16-byte boundaries (pitch 1280 for a 1241-pixel row) are used as pyramid level 0 without
     the pitched copy: results, the level-0 plane seen through orbfe_device_pyramid / debug_pyramid, and a stereo match on the
