@@ -62,42 +62,46 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
         head = f"{b['value']:.0f} {b['unit']} under the profiler ({b['ms_per_step']:.3f} ms per step of {b['config']['frames_per_gpu_per_step']} stereo frames)"
     except Exception:
         head = "bench line not parsed"
-    with open(out_prefix + "_kernel_stats.md", "w") as f:
-        f.write(f"# {os.path.basename(out_prefix)}: rocprofv3 kernel stats of the bench step\n\n"
-                "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0` (the default layout: overlapping launches, see below) "
-                f"(tools/profile_round.sh), times in microseconds per launch of 256 images; {head}.\n\n")
-        f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
-        for r in rows:
+    def table(rws):
+        out = "| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n"
+        for r in rws:
             if float(r["Percentage"]) < 0.05:
                 continue
-            f.write(f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | "
+            out += (f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | "
                     f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-        f.write("\n`__amd_rocclr_copyBuffer` / `fillBufferAligned` and the `at::native` kernels belong to bench.py's set-up (uploading the synthetic "
-                "frames, one copy per image, before the first step) and result read-back; the kernel trace of a steady-state step holds none of "
-                "them (two `at::native` fills of the match buffers excepted).  Percentages are of the whole profiled process.\n")
+        return out
+
+    foot = ("\n`__amd_rocclr_copyBuffer` / `fillBufferAligned` and the `at::native` kernels belong to bench.py's set-up (uploading the synthetic "
+            "frames, one copy per image, before the first step) and result read-back; the kernel trace of a steady-state step holds none of "
+            "them (two `at::native` fills of the match buffers excepted).  Percentages are of the whole profiled process.\n")
+    cmd = "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0"
     avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
     one = glob.glob(os.path.join(tag_dir, "**", "stats1_kernel_stats.csv"), recursive=True)
-    if one:   # the one-stream pass: every kernel alone on the chip -- the durations the PMC tables go with
-        rows1 = list(csv.DictReader(open(one[0])))
-        avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows1}
-        l1 = [l for l in open(os.path.join(tag_dir, "stats1.log")).read().split("\n") if l.startswith("{")]
-        try:
-            b1 = json.loads(l1[-1])
-            head1 = f"{b1['value']:.0f} {b1['unit']} under the profiler ({b1['ms_per_step']:.3f} ms per step)"
-        except Exception:
-            head1 = "bench line not parsed"
-        with open(out_prefix + "_kernel_stats.md", "a") as f:
-            f.write("\n## One stream, one set of handles: every kernel alone on the chip\n\n"
-                    "`... bench.py --steps 10 --warmup 2 ... --lr-streams 1 --sets 1`: a step starts when the one before it has ended, left and right "
-                    f"extractor on the same stream; {head1}.  In the default run above the left and right extractor's launches overlap (two streams) and the "
-                    "matching half of the step before runs beside them (two handle sets in turn), so a launch's own duration there contains the other "
-                    "launches' share of the chip; `bench.py` reports both (`roofline.avg_launch_ms` = this table, `roofline.timed_region.avg_launch_ms` = a launch's own duration inside the overlapped timed region; under the profiler the launches interleave differently than in a plain run, so the table above is not that figure).\n\n")
-            f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
-            for r in rows1:
-                if float(r["Percentage"]) < 0.05:
-                    continue
-                f.write(f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | "
-                        f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    with open(out_prefix + "_kernel_stats.md", "w") as f:
+        f.write(f"# {os.path.basename(out_prefix)}: rocprofv3 kernel stats of the bench step\n\n")
+        if one:   # the one-stream pass: every kernel alone on the chip -- the durations the PMC tables and `roofline.avg_launch_ms` go with
+            rows1 = list(csv.DictReader(open(one[0])))
+            avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows1}
+            l1 = [l for l in open(os.path.join(tag_dir, "stats1.log")).read().split("\n") if l.startswith("{")]
+            try:
+                b1 = json.loads(l1[-1])
+                head1 = f"{b1['value']:.0f} {b1['unit']} under the profiler ({b1['ms_per_step']:.3f} ms per step)"
+            except Exception:
+                head1 = "bench line not parsed"
+            f.write("Two passes of the same build (tools/profile_round.sh), times in microseconds per launch of 256 images: first every kernel alone on "
+                    "the chip (what `roofline.avg_launch_ms`, the PMC tables and earlier rounds' tables show), then the default layout, in which launches "
+                    "overlap by design.\n\n## Every kernel alone on the chip (one stream, one set of handles): the per-kernel figures\n\n"
+                    f"{cmd} --lr-streams 1 --sets 1`: a step starts when the one before it has ended, left and right extractor on the same stream; {head1}.\n\n")
+            f.write(table(rows1))
+            f.write("\n## Default layout: overlapping launches (left | right extractor on two streams, handle sets in turn)\n\n"
+                    f"{cmd}`; {head}.  The left and right extractor's launches overlap and the matching half of the step before runs beside them, so a "
+                    "launch's own duration here contains the other launches' share of the chip, and under the profiler the launches interleave "
+                    "differently than in a plain run (`roofline.timed_region` in bench.py's line is measured there).\n\n")
+            f.write(table(rows))
+        else:
+            f.write(f"{cmd}` (tools/profile_round.sh), times in microseconds per launch of 256 images; {head}.\n\n")
+            f.write(table(rows))
+        f.write(foot)
     cs = counters(tag_dir)
     with open(out_prefix + "_pmc_counters.md", "w") as f:
         f.write(f"# {os.path.basename(out_prefix)}: PMC counters per kernel launch (256 KITTI images / stereo frames per launch)\n\n"
