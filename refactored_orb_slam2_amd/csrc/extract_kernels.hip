@@ -1668,9 +1668,10 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
       const uint32_t* trow = reinterpret_cast<const uint32_t*>(in + (base & ~3));
       auto hrow = [&](uint32_t row_off, uint32_t (&hh)[4]) {
         const uint32_t* p = trow + row_off;
-        const uint32_t* p2 = p + 2;
-        asm("" : "+v"(p2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow)
-        const uint32_t w0 = p[0], w1 = p[1], w2 = *p2;
+        uint32_t o2 = row_off + 2;
+        asm("" : "+v"(o2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow).  The barrier sits on the
+                              // OFFSET: on the pointer it erased the address space, and the third dword became a flat_load_dword
+        const uint32_t w0 = p[0], w1 = p[1], w2 = trow[o2];
         const uint32_t W0 = __builtin_amdgcn_alignbyte(w1, w0, sh), W1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
