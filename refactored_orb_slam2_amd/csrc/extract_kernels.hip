@@ -1519,7 +1519,8 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
   // the resize taps: this thread's dword column J (pixels 4J .. 4J + 3) in registers; the vertical taps of the tile's (at most 48)
   // destination rows go through LDS -- a thread's rows are THREADS / 16 apart, held in registers they cost a wave of occupancy
   const int J = t.j0 + (tid & (ORBFE_FUSE_DWORDS - 1));
-  __shared__ uint4 ytap[16 * ORBFE_FUSE_ROWS];   // per destination row: dword offsets of its two source rows in the window, the two weights << 12
+  __shared__ uint4 ytap[16 * ORBFE_FUSE_ROWS];   // per destination row: byte offsets of its two source rows in the window, the two weights << 12
+  __shared__ uint32_t ydst[16 * ORBFE_FUSE_ROWS];   // ... and the byte offset of the row (of its tile row and row inside it) in level + 1
   uint2 txr[4], tyl = make_uint2(0u, 0u);
   if constexpr (RESIZE) {
 #pragma unroll
@@ -1645,7 +1646,9 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
   if constexpr (RESIZE)
     if (tid < 16 * ORBFE_FUSE_ROWS) {
       const int ra = (int)(int16_t)(tyl.x & 0xffff) - (oy - 3), rb = (int)(int16_t)(tyl.x >> 16) - (oy - 3);
-      ytap[tid] = make_uint4((uint32_t)(ra * (BT_INP / 4)), (uint32_t)(rb * (BT_INP / 4)), (tyl.y & 0xffffu) << 12, (tyl.y >> 16) << 12);
+      ytap[tid] = make_uint4((uint32_t)(ra * BT_INP), (uint32_t)(rb * BT_INP), (tyl.y & 0xffffu) << 12, (tyl.y >> 16) << 12);
+      const int yd = t.r0 + tid;
+      ydst[tid] = rz.dst_tiled ? (uint32_t)(yd >> 3) * ((uint32_t)(rz.dpitch >> 4) << 7) + (uint32_t)((yd & 7) * 16) : (uint32_t)yd * (uint32_t)rz.dpitch;
     }
   __syncthreads();
   if constexpr (RESIZE) {
@@ -1665,33 +1668,41 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
         sel[i] = o | 0x0c000c00u | ((o + 1) << 16);
         cp[i] = txr[i].y;                                                         // c0 | c1 << 16
       }
-      const uint32_t* trow = reinterpret_cast<const uint32_t*>(in + (base & ~3));
-      auto hrow = [&](uint32_t row_off, uint32_t (&hh)[4]) {
-        const uint32_t* p = trow + row_off;
-        uint32_t o2 = row_off + 2;
-        asm("" : "+v"(o2));   // keep the third dword a separate ds_read_b32 (a 4-byte aligned ds_read_b96 is slow).  The barrier sits on the
-                              // OFFSET: on the pointer it erased the address space, and the third dword became a flat_load_dword
-        const uint32_t w0 = p[0], w1 = p[1], w2 = trow[o2];
-        const uint32_t W0 = __builtin_amdgcn_alignbyte(w1, w0, sh), W1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+      const uint32_t trow = (uint32_t)(uintptr_t)(in + (base & ~3));   // LDS byte address of the window column the taps start in
+      // the three dwords of BOTH source rows in one block of LDS reads (ds_read2_b32 + ds_read_b32 off one address register per row:
+      // a 4-byte aligned ds_read_b96 is slow, and every way of keeping the compiler from forming one -- an asm barrier on the pointer, a
+      // volatile access -- turned the third dword into a flat_load_dword with a wait of its own)
+      auto hrow2 = [&](uint32_t off_a, uint32_t off_b, uint32_t (&ha)[4], uint32_t (&hb)[4]) {
+        unsigned long long a01, b01;
+        uint32_t a2, b2;
+        asm volatile("ds_read2_b32 %0, %4 offset1:1\n\t"
+                     "ds_read_b32 %1, %4 offset:8\n\t"
+                     "ds_read2_b32 %2, %5 offset1:1\n\t"
+                     "ds_read_b32 %3, %5 offset:8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(a01), "=&v"(a2), "=&v"(b01), "=&v"(b2)
+                     : "v"(trow + off_a), "v"(trow + off_b)
+                     : "memory");
+        const uint32_t A0 = __builtin_amdgcn_alignbyte((uint32_t)(a01 >> 32), (uint32_t)a01, sh), A1 = __builtin_amdgcn_alignbyte(a2, (uint32_t)(a01 >> 32), sh);
+        const uint32_t B0w = __builtin_amdgcn_alignbyte((uint32_t)(b01 >> 32), (uint32_t)b01, sh), B1w = __builtin_amdgcn_alignbyte(b2, (uint32_t)(b01 >> 32), sh);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const uint32_t u = __builtin_amdgcn_perm(W1, W0, sel[i]);
-          hh[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, u), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
+          const uint32_t ua = __builtin_amdgcn_perm(A1, A0, sel[i]), ub = __builtin_amdgcn_perm(B1w, B0w, sel[i]);
+          ha[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, ua), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
+          hb[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, ub), __builtin_bit_cast(us2, cp[i]), 0u, false) & ~15u;
         }
       };
       // rows t.r0 + (tid >> 4), + THREADS / 16, ...: the row groups of a wave take consecutive rows
       // level + 1 is written in 16 x 8 tiles (orbfe_internal.h; row-major where a stand-alone kernel reads it next): the dword's
       // place inside its row / tile row is the thread's, the row's is the loop's
-      uint8_t* N0 = rz.dst + (size_t)img * rz.dimg + (rz.dst_tiled ? (((uint32_t)((4 * J) >> 4) << 7) + (uint32_t)((4 * J) & 15)) : (uint32_t)(4 * J));
-      const uint32_t ntile = (uint32_t)(rz.dpitch >> 4) << 7;
+      uint8_t* Nimg = rz.dst + (size_t)img * rz.dimg;   // wave-uniform base; the offsets below are 32-bit (a plane is < 2^25 bytes)
+      const uint32_t ncol = rz.dst_tiled ? (((uint32_t)((4 * J) >> 4) << 7) + (uint32_t)((4 * J) & 15)) : (uint32_t)(4 * J);
       for (int yi = tid >> 4; yi < t.r1 - t.r0; yi += THREADS / 16) {
-        const int yd = t.r0 + yi;
-        uint8_t* N = N0 + (rz.dst_tiled ? (uint32_t)(yd >> 3) * ntile + (uint32_t)((yd & 7) * 16) : (uint32_t)yd * (uint32_t)rz.dpitch);
+        uint8_t* N = Nimg + (ncol + ydst[yi]);
         {
           const uint4 ty = ytap[yi];
           uint32_t h0[4], h1[4];
-          hrow(ty.x, h0);
-          hrow(ty.y, h1);
+          hrow2(ty.x, ty.y, h0, h1);
           const uint32_t B0 = ty.z, B1 = ty.w;
           uint32_t sm[4];
 #pragma unroll
