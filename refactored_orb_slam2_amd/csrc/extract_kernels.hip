@@ -2296,15 +2296,21 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint8_t* bc = dsc + 18 * DSC_PITCH + (cx - ax_d);
+    // cvRound of the rotated coordinates (L/src/ORBextractor.cc:119-121) by the magic-number addition: v + 1.5 * 2^23 rounds |v| < 2^22
+    // to nearest-even in the mantissa's low bits -- one v_add_f32 where v_rndne_f32 + v_cvt_i32_f32 were two.  The integers are never
+    // separated from the magic word: in 32-bit wrap-around arithmetic (M + ry) * PITCH + (M + rx) is the patch index plus a constant
+    // that goes into the wave-uniform base
+    const float MAGIC = 12582912.0f;
+    const uint32_t MB = 0x4B400000u;   // its bit pattern
+    const uint32_t bc0 = (uint32_t)(18 * DSC_PITCH + (cx - ax_d)) - (MB * (uint32_t)DSC_PITCH + MB);
     uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
-      const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
-      const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
-      const int t0 = bc[ry0 * DSC_PITCH + rx0];
-      const int t1 = bc[ry1 * DSC_PITCH + rx1];
+      const uint32_t ry0 = __float_as_uint((x0 * b + y0 * a) + MAGIC), rx0 = __float_as_uint((x0 * a - y0 * b) + MAGIC);
+      const uint32_t ry1 = __float_as_uint((x1 * b + y1 * a) + MAGIC), rx1 = __float_as_uint((x1 * a - y1 * b) + MAGIC);
+      const int t0 = dsc[bc0 + ry0 * (uint32_t)DSC_PITCH + rx0];
+      const int t1 = dsc[bc0 + ry1 * (uint32_t)DSC_PITCH + rx1];
       const unsigned long long bits = __ballot(t0 < t1);
       if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = bits;
     }
