@@ -26,14 +26,15 @@
 //   usage: stereo_kitti <sequence_dir> [--features 2000] [--max-frames N] [--dump file.bin] [--bf 386.1448] [--fx 718.856]
 //                       [--fy 718.856] [--cx 607.1928] [--cy 185.2157] [--th 7] [--decode-threads 8] [--prefetch 16]
 //                       [--prepare 1] [--gpus 1] [--gather none|root|all] [--gather-dump file.bin]
-//                       [--batch F] [--slots 3] [--preload 0|1] [--repeat R]
+//                       [--batch F] [--slots 3] [--preload 0|1|2|3] [--repeat R]
 //
 // --batch F is the batched pipeline from a C++ host (include/orbfe.h: orbfe_pipeline_*): chunks of F pairs go through the device
 // batch API -- decode pool -> the pipeline's pinned pitched input -> H2D -> 2 x ORBextractor -> ComputeStereoMatches ->
 // UnprojectStereo -> SearchByProjection(cur, last) -> D2H -- with --slots buffer sets, so that decoding, the copies and the kernels
 // of neighbouring chunks overlap; per frame the same records as the loop above (--dump writes the same format).  --preload 1
 // decodes the whole sequence into host memory before the clock starts (what is timed then: one host copy per frame into the pinned
-// slots, PCIe, the kernels); --preload 2 leaves the frames resident in the pinned slots after the first chunks (no host work per
+// slots, PCIe, the kernels); --preload 3 leaves them in the slots' DEVICE input blocks after the first chunks (orbfe_pipeline_submit_resident:
+// the handle at its kernels' rate, what a device-side producer gets); --preload 2 leaves the frames resident in the pinned slots after the first chunks (no host work per
 // frame: the rate of the pipeline itself, PCIe included; results are not those of the sequence order: no --dump with it);
 // --repeat R walks the sequence R times (steady-state rates from a short directory).  With --gpus N every GPU thread runs one
 // pipeline on its chunk of the frame range and the left records of every chunk are gathered straight from HBM
@@ -513,7 +514,7 @@ static void RunShardBatched(const Options& o, const std::vector<std::string>& vs
   ChunkFeeder feeder;
   feeder.F = F; feeder.S = S; feeder.w = w0; feeder.h = h0; feeder.begin = sh.begin; feeder.end = sh.end; feeder.nReal = nReal;
   feeder.left = &vstrImageLeft; feeder.right = &vstrImageRight; feeder.preL = preL; feeder.preR = preR;
-  feeder.pinnedResident = o.preload == 2;
+  feeder.pinnedResident = o.preload >= 2;
   feeder.in.resize((size_t)S);
   for (int s = 0; s < S; s++) orbfe_pipeline_input(pl, s, &feeder.in[(size_t)s]);
   const auto tSequence = std::chrono::steady_clock::now();
@@ -597,7 +598,9 @@ static void RunShardBatched(const Options& o, const std::vector<std::string>& vs
     }
     tSubmit[(size_t)k] = std::chrono::steady_clock::now();
     // a chunk whose images failed to load is still submitted (with no frames): the collective below needs every rank
-    if (orbfe_pipeline_submit(pl, k % S, sh.rc ? 0 : n, k > 0) != ORBFE_OK) { fprintf(stderr, "orbfe_pipeline_submit: %s\n", orbfe_last_error()); sh.rc = 3; }
+    // --preload 3: after the first S chunks the frames are where their uploads put them, in the slots' DEVICE input blocks
+    const bool resident = o.preload == 3 && k >= S;
+    if ((resident ? orbfe_pipeline_submit_resident(pl, k % S, sh.rc ? 0 : n, k > 0) : orbfe_pipeline_submit(pl, k % S, sh.rc ? 0 : n, k > 0)) != ORBFE_OK) { fprintf(stderr, "orbfe_pipeline_submit: %s\n", orbfe_last_error()); sh.rc = 3; }
     if (gp.comm) {
       const auto tg = std::chrono::steady_clock::now();
       if (orbfe_pipeline_gather(pl, k % S, gp.comm, gp.mode, (int32_t*)an[(size_t)(k % S)], (orbfe_keypoint*)ak[(size_t)(k % S)],
@@ -650,7 +653,7 @@ int main(int argc, char** argv) {
     else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 64; }
   }
   if (o.gather == "default") o.gather = o.gpus > 1 ? "root" : "none";
-  if (o.preload == 2 && (!o.dumpPath.empty() || !o.gatherDump.empty())) { fprintf(stderr, "--preload 2 re-submits resident frames: no --dump / --gather-dump\n"); return 64; }
+  if (o.preload >= 2 && (!o.dumpPath.empty() || !o.gatherDump.empty())) { fprintf(stderr, "--preload 2 / 3 re-submit resident frames: no --dump / --gather-dump\n"); return 64; }
   if (o.gather != "none" && o.gather != "root" && o.gather != "all") { fprintf(stderr, "--gather none|root|all\n"); return 64; }
   std::vector<std::string> vstrImageLeft, vstrImageRight;
   std::vector<double> vTimestamps;
@@ -889,7 +892,8 @@ int main(int argc, char** argv) {
   for (auto& v : tPhase) std::sort(v.begin(), v.end());
   if (o.batch > 0)
     printf("batched pipeline: chunks of %d pairs, %d buffer sets, %s; tracking times above are a chunk's submit-to-results time divided by its frames\n",
-           o.batch, o.slots, o.preload == 2 ? "frames decoded before the clock started and resident in the pinned slots after the first chunks" :
+           o.batch, o.slots, o.preload == 3 ? "frames decoded before the clock started and resident in HBM (the slots' device input blocks) after the first chunks" :
+           o.preload == 2 ? "frames decoded before the clock started and resident in the pinned slots after the first chunks" :
            o.preload ? "frames decoded before the clock started" : "PNGs decoded inside the clock");
   else
     printf("median per phase [ms]: ORBextractor x2 (two threads) %.4f, ComputeStereoMatches %.4f, SearchByProjection(cur,last) %.4f\n",

@@ -581,7 +581,9 @@ int orbfe_frontend_prepare(orbfe_extractor* left, orbfe_extractor* right, int w,
  * `examples/stereo_kitti.py` / `bench.py` -- images H2D, ORBextractor left + right (L/src/ORBextractor.cc:978-1039), Frame::
  * ComputeStereoMatches (L/src/Frame.cc:477-646), Frame::UnprojectStereo of every stereo point (:668-679), its projection into the
  * next frame and SearchByProjection(cur, last) (L/src/ORBmatcher.cc:1247-1383), results D2H -- behind one handle that owns the
- * two extractors, the matcher, `slots` sets of pinned host and device buffers and three streams (copy in, compute, copy out):
+ * extractors and matchers (one set per slot), `slots` sets of pinned host and device buffers and its streams -- copy in, left extractor,
+ * right extractor (two streams, as the reference's two threads), the matching half (stereo match ... projection search), copy out; the
+ * extraction of chunk k + 1 runs beside the matching half of chunk k (DESIGN lesson 47):
  *     orbfe_pipeline_input(p, s, &in)     pinned, pitched host images of slot s (+ the per-frame camera / pose records, pre-filled
  *                                         with the identity pose and the configured intrinsics); the host decodes into them
  *     orbfe_pipeline_submit(p, s, n, hp)  enqueues the chunk (n <= batch frames; hp = 0: frame 0 has no predecessor) and returns
@@ -626,6 +628,12 @@ int orbfe_pipeline_input(orbfe_pipeline* p, int slot, orbfe_pipeline_input_view*
 int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n_frames, int has_predecessor);
 int orbfe_pipeline_wait(orbfe_pipeline* p, int slot);
 int orbfe_pipeline_output(orbfe_pipeline* p, int slot, orbfe_pipeline_output_view* out);
+/* For producers that already are on the device (a decoder on the GPU, frames from a neighbour over xGMI): the slot's DEVICE image
+ * blocks (n-th image at + n * image_bytes, rows `pitch` bytes apart; write them on a stream of your own and synchronise it before the
+ * submit, and not before orbfe_pipeline_wait of the slot's previous chunk), and a submit that leaves them as they are -- only the
+ * camera / pose records go host to device.  Also what a host uses to run the handle at its kernels' rate on frames uploaded once. */
+int orbfe_pipeline_device_input(orbfe_pipeline* p, int slot, uint8_t** d_left, uint8_t** d_right, int* pitch, size_t* image_bytes);
+int orbfe_pipeline_submit_resident(orbfe_pipeline* p, int slot, int n_frames, int has_predecessor);
 /* DEVICE pointers of slot s's left records ([batch] counts -- rows behind n_frames are zero --, [batch][cap] keypoints and
  * descriptors), valid from the slot's submit until its next submit, ordered on orbfe_pipeline_stream */
 int orbfe_pipeline_device_records(orbfe_pipeline* p, int slot, const int32_t** d_n, const orbfe_keypoint** d_kps,

@@ -11,6 +11,7 @@
 //      (L/src/ORBmatcher.cc:1247-1383)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -67,7 +68,12 @@ struct Slot {
   orbfe_keypoint* d_kps_r = nullptr;
   uint8_t* d_desc_r = nullptr;
   uint8_t* d_blocked = nullptr;
-  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr, ev_gather = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr, ev_gather = nullptr, ev_l = nullptr, ev_r = nullptr;
+  // the slot's own extractors and matcher: the matching half of a chunk reads the pyramids its extractors left in HBM (the stereo SAD
+  // windows), so the NEXT chunk's extraction can only run beside it on other handles (DESIGN lesson 47)
+  orbfe_extractor* ex_l = nullptr;
+  orbfe_extractor* ex_r = nullptr;
+  orbfe_matcher* mt = nullptr;
   bool pending = false;        // submitted, results not yet waited for
   bool gathering = false;      // a record gather of this slot has been enqueued and not yet waited for
   int frames = 0;
@@ -79,12 +85,10 @@ struct orbfe_pipeline {
   int device = 0, cap = 0, pitch = 0;
   size_t image_bytes = 0, in_left = 0, in_right = 0, in_cams = 0, in_poses = 0, in_bytes = 0;
   OutLayout lay{};
-  orbfe_extractor* ex_l = nullptr;
-  orbfe_extractor* ex_r = nullptr;
-  orbfe_matcher* mt = nullptr;
-  hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr, s_gat = nullptr;
+  // copy in | left extractor | right extractor | matching half (stereo match ... projection search) | copy out | record gather
+  hipStream_t s_in = nullptr, s_l = nullptr, s_r = nullptr, s_cmp = nullptr, s_out = nullptr, s_gat = nullptr;
   std::vector<Slot> slots;
-  // shared by the chunks (one compute stream: strictly ordered): the stereo points of the chunk's frames behind the carried
+  // shared by the chunks (the matching halves run on ONE stream, strictly ordered): the stereo points of the chunk's frames behind the carried
   // last frame of the previous chunk (row 0), and the queries projected from them
   orbfe_last_point* d_pts = nullptr;   // [batch + 1][cap]
   int32_t* d_npts = nullptr;           // [batch + 1]
@@ -96,22 +100,22 @@ struct orbfe_pipeline {
 static void pipeline_free(orbfe_pipeline* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  for (hipStream_t s : {p->s_in, p->s_cmp, p->s_out, p->s_gat})
+  for (hipStream_t s : {p->s_in, p->s_l, p->s_r, p->s_cmp, p->s_out, p->s_gat})
     if (s) (void)hipStreamSynchronize(s);
   for (Slot& s : p->slots) {
+    if (s.mt) (void)orbfe_matcher_destroy(s.mt);
+    if (s.ex_l) (void)orbfe_extractor_destroy(s.ex_l);
+    if (s.ex_r) (void)orbfe_extractor_destroy(s.ex_r);
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.h_out) (void)hipHostFree(s.h_out);
     for (void* d : {(void*)s.d_in, (void*)s.d_out, (void*)s.d_kps_r, (void*)s.d_desc_r, (void*)s.d_blocked})
       if (d) (void)hipFree(d);
-    for (hipEvent_t e : {s.ev_in, s.ev_done, s.ev_out, s.ev_gather})
+    for (hipEvent_t e : {s.ev_in, s.ev_done, s.ev_out, s.ev_gather, s.ev_l, s.ev_r})
       if (e) (void)hipEventDestroy(e);
   }
   for (void* d : {(void*)p->d_pts, (void*)p->d_npts, (void*)p->d_q, (void*)p->d_nq})
     if (d) (void)hipFree(d);
-  if (p->mt) (void)orbfe_matcher_destroy(p->mt);
-  if (p->ex_l) (void)orbfe_extractor_destroy(p->ex_l);
-  if (p->ex_r) (void)orbfe_extractor_destroy(p->ex_r);
-  for (hipStream_t s : {p->s_in, p->s_cmp, p->s_out, p->s_gat})
+  for (hipStream_t s : {p->s_in, p->s_l, p->s_r, p->s_cmp, p->s_out, p->s_gat})
     if (s) (void)hipStreamDestroy(s);
   delete p;
 }
@@ -119,10 +123,13 @@ static void pipeline_free(orbfe_pipeline* p) {
 static int pipeline_build(orbfe_pipeline* p) {
   const orbfe_pipeline_config& c = p->cfg;
   const int F = c.batch;
-  RCHK(orbfe_extractor_create(&c.extractor, p->device, &p->ex_l));
-  RCHK(orbfe_extractor_create(&c.extractor, p->device, &p->ex_r));
-  RCHK(orbfe_matcher_create(p->device, &p->mt));
-  RCHK(orbfe_extractor_max_keypoints(p->ex_l, c.width, c.height, &p->cap));
+  p->slots.resize((size_t)c.slots);
+  for (Slot& s : p->slots) {
+    RCHK(orbfe_extractor_create(&c.extractor, p->device, &s.ex_l));
+    RCHK(orbfe_extractor_create(&c.extractor, p->device, &s.ex_r));
+    RCHK(orbfe_matcher_create(p->device, &s.mt));
+  }
+  RCHK(orbfe_extractor_max_keypoints(p->slots[0].ex_l, c.width, c.height, &p->cap));
   const int cap = p->cap;
   p->pitch = (c.width + 63) & ~63;
   p->image_bytes = (size_t)p->pitch * c.height;
@@ -132,15 +139,20 @@ static int pipeline_build(orbfe_pipeline* p) {
   p->in_poses = p->in_cams + up256(sizeof(orbfe_unproject_cam) * F);
   p->in_bytes = p->in_poses + up256(sizeof(orbfe_track_pose) * F);
   p->lay.build(F, cap);
-  // The copy streams get a priority of their own: HIP maps streams onto a handful of hardware queues (four by default) in creation
-  // order, and a copy stream that lands on the compute stream's queue waits behind that chunk's kernels -- measured: H2D of chunk
-  // k + 1 started only when chunk k's kernels had finished (33 k frames/s instead of the PCIe rate).  Queues are per priority level.
+  // Stream -> hardware queue: HIP maps streams onto a handful of hardware queues per priority level (three levels: 1, 0, -1) in
+  // creation order, and streams that share a queue run one after the other.  Measured on this handle (tools/pipeline_rate.py, 256-frame
+  // chunks, upload / resident frames/s): copy streams at -1 and compute streams at 1: 55.0 k / 80.2 k (round 5's first layout; with one
+  // compute stream the H2D copy of chunk k + 1 had started only when chunk k's kernels were done: 33 k); everything at 0: 33.7 k /
+  // 75.9 k; compute at 0, copies at -1: 37.4 k / 67.8 k; ALL SIX at -1 with the copy streams created first: 56.0 k / 89.0 k -- the
+  // layout below; the same with the compute streams created first: 56.2 k / 75.5 k.  (GPU_MAX_HW_QUEUES = 8 instead of 4: 83 k.)
   int prio_low = 0, prio_high = 0;
   PCHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_high));
   PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_high));
   PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_low));
+  PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
+  PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
+  PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
   PCHK(hipMalloc((void**)&p->d_pts, sizeof(orbfe_last_point) * (size_t)(F + 1) * cap));
   PCHK(hipMalloc((void**)&p->d_npts, sizeof(int32_t) * (F + 1)));
   PCHK(hipMalloc((void**)&p->d_q, sizeof(orbfe_query) * (size_t)F * cap));
@@ -148,8 +160,7 @@ static int pipeline_build(orbfe_pipeline* p) {
   PCHK(hipMemset(p->d_npts, 0, sizeof(int32_t) * (F + 1)));
   PCHK(hipMemset(p->d_pts, 0, sizeof(orbfe_last_point) * (size_t)(F + 1) * cap));
   float sf[ORBFE_MAX_LEVELS] = {0};
-  RCHK(orbfe_extractor_scale_factors(p->ex_l, sf));
-  p->slots.resize((size_t)c.slots);
+  RCHK(orbfe_extractor_scale_factors(p->slots[0].ex_l, sf));
   for (Slot& s : p->slots) {
     PCHK(hipHostMalloc((void**)&s.h_in, p->in_bytes, hipHostMallocDefault));
     PCHK(hipHostMalloc((void**)&s.h_out, p->lay.bytes, hipHostMallocDefault));
@@ -166,6 +177,8 @@ static int pipeline_build(orbfe_pipeline* p) {
     PCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     PCHK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
     PCHK(hipEventCreateWithFlags(&s.ev_gather, hipEventDisableTiming));
+    PCHK(hipEventCreateWithFlags(&s.ev_l, hipEventDisableTiming));
+    PCHK(hipEventCreateWithFlags(&s.ev_r, hipEventDisableTiming));
     // the records the examples use: identity pose (the constant-velocity prediction with zero velocity: Tcw = Tlw, expressed in
     // the last camera's frame), the configured intrinsics
     orbfe_unproject_cam* cams = reinterpret_cast<orbfe_unproject_cam*>(s.h_in + p->in_cams);
@@ -200,11 +213,21 @@ static int pipeline_build(orbfe_pipeline* p) {
           rr[x > 12 ? x - 12 : 0] = (uint8_t)v;
         }
       }
-    int rc = orbfe_pipeline_submit(p, 0, F, 0);
-    if (rc == ORBFE_OK) rc = orbfe_pipeline_wait(p, 0);
-    if (rc != ORBFE_OK) return rc;
-    memset(s.h_in + p->in_left, 0, p->image_bytes * F);
-    memset(s.h_in + p->in_right, 0, p->image_bytes * F);
+    // every slot's handles: the same chunk through each of them
+    for (int k = 0; k < c.slots; k++) {
+      Slot& sk = p->slots[(size_t)k];
+      if (k > 0) {
+        memcpy(sk.h_in + p->in_left, s.h_in + p->in_left, p->image_bytes * F);
+        memcpy(sk.h_in + p->in_right, s.h_in + p->in_right, p->image_bytes * F);
+      }
+      int rc = orbfe_pipeline_submit(p, k, F, 0);
+      if (rc == ORBFE_OK) rc = orbfe_pipeline_wait(p, k);
+      if (rc != ORBFE_OK) return rc;
+    }
+    for (Slot& sk : p->slots) {
+      memset(sk.h_in + p->in_left, 0, p->image_bytes * F);
+      memset(sk.h_in + p->in_right, 0, p->image_bytes * F);
+    }
     PCHK(hipMemset(p->d_npts, 0, sizeof(int32_t) * (F + 1)));   // the warm-up chunk is nobody's predecessor
   }
   return ORBFE_OK;
@@ -292,7 +315,10 @@ extern "C" int orbfe_pipeline_device_records(orbfe_pipeline* p, int slot, const 
 
 extern "C" void* orbfe_pipeline_stream(orbfe_pipeline* p) { return p ? (void*)p->s_cmp : nullptr; }
 
-extern "C" int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n, int has_predecessor) {
+// One chunk through a slot.  Streams: copy in -> left | right extractor (two streams, as the reference's two threads) -> matching half
+// (stereo match, unproject, track queries, projection search; ONE stream for all chunks: the carried last frame orders them) -> copy out.
+// The extraction of this chunk runs beside the matching half of the chunk before it, which works on another slot's handles.
+static int submit_chunk(orbfe_pipeline* p, int slot, int n, int has_predecessor, bool resident) {
   if (!p || slot < 0 || slot >= (int)p->slots.size() || n < 0 || n > p->cfg.batch) return ORBFE_ERR_INVALID;
   std::lock_guard<std::mutex> lk(p->mu);
   PCHK(hipSetDevice(p->device));
@@ -303,19 +329,23 @@ extern "C" int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n, int has
   if (s.pending) PCHK(hipEventSynchronize(s.ev_out));   // the caller did not wait: the host block is about to be overwritten
   s.pending = true;
   s.frames = n;
-  // ---- copy in: behind the kernels that still read this slot's images (level 0 of their pyramids in place)
+  // ---- copy in: behind the kernels that still read this slot's images (level 0 of their pyramids in place) and its pyramids
   PCHK(hipStreamWaitEvent(p->s_in, s.ev_done, 0));
   if (n > 0) {
-    PCHK(hipMemcpyAsync(s.d_in + p->in_left, s.h_in + p->in_left, p->image_bytes * n, hipMemcpyHostToDevice, p->s_in));
-    PCHK(hipMemcpyAsync(s.d_in + p->in_right, s.h_in + p->in_right, p->image_bytes * n, hipMemcpyHostToDevice, p->s_in));
+    if (!resident) {
+      PCHK(hipMemcpyAsync(s.d_in + p->in_left, s.h_in + p->in_left, p->image_bytes * n, hipMemcpyHostToDevice, p->s_in));
+      PCHK(hipMemcpyAsync(s.d_in + p->in_right, s.h_in + p->in_right, p->image_bytes * n, hipMemcpyHostToDevice, p->s_in));
+    }
     PCHK(hipMemcpyAsync(s.d_in + p->in_cams, s.h_in + p->in_cams, p->in_bytes - p->in_cams, hipMemcpyHostToDevice, p->s_in));
   }
   PCHK(hipEventRecord(s.ev_in, p->s_in));
-  // ---- compute: behind the copy in, and behind the copy out of this slot's previous results
+  // ---- every compute stream: behind the copy in, behind the copy out of this slot's previous results and a gather that still reads them
   hipStream_t cs = p->s_cmp;
-  PCHK(hipStreamWaitEvent(cs, s.ev_in, 0));
-  PCHK(hipStreamWaitEvent(cs, s.ev_out, 0));
-  PCHK(hipStreamWaitEvent(cs, s.ev_gather, 0));   // a gather of this slot's previous records still reads them
+  for (hipStream_t st : {p->s_l, p->s_r, cs}) {
+    PCHK(hipStreamWaitEvent(st, s.ev_in, 0));
+    PCHK(hipStreamWaitEvent(st, s.ev_out, 0));
+    PCHK(hipStreamWaitEvent(st, s.ev_gather, 0));
+  }
   int32_t* d_nl = reinterpret_cast<int32_t*>(s.d_out + L.n_left);
   int32_t* d_nr = reinterpret_cast<int32_t*>(s.d_out + L.n_right);
   int32_t* d_nst = reinterpret_cast<int32_t*>(s.d_out + L.n_stereo);
@@ -334,11 +364,15 @@ extern "C" int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n, int has
   if (n > 0) {
     const orbfe_unproject_cam* d_cams = reinterpret_cast<const orbfe_unproject_cam*>(s.d_in + p->in_cams);
     const orbfe_track_pose* d_poses = reinterpret_cast<const orbfe_track_pose*>(s.d_in + p->in_poses);
-    RCHK(orbfe_extract_batch_device(p->ex_l, s.d_in + p->in_left, n, c.width, c.height, p->pitch, p->image_bytes, d_kl, d_dl, cap,
-                                    d_nl, cs));
-    RCHK(orbfe_extract_batch_device(p->ex_r, s.d_in + p->in_right, n, c.width, c.height, p->pitch, p->image_bytes, s.d_kps_r,
-                                    s.d_desc_r, cap, d_nr, cs));
-    RCHK(orbfe_stereo_match_device(p->mt, p->ex_l, p->ex_r, n, d_kl, d_dl, d_nl, s.d_kps_r, s.d_desc_r, d_nr, cap, c.bf,
+    RCHK(orbfe_extract_batch_device(s.ex_l, s.d_in + p->in_left, n, c.width, c.height, p->pitch, p->image_bytes, d_kl, d_dl, cap,
+                                    d_nl, p->s_l));
+    PCHK(hipEventRecord(s.ev_l, p->s_l));
+    RCHK(orbfe_extract_batch_device(s.ex_r, s.d_in + p->in_right, n, c.width, c.height, p->pitch, p->image_bytes, s.d_kps_r,
+                                    s.d_desc_r, cap, d_nr, p->s_r));
+    PCHK(hipEventRecord(s.ev_r, p->s_r));
+    PCHK(hipStreamWaitEvent(cs, s.ev_l, 0));
+    PCHK(hipStreamWaitEvent(cs, s.ev_r, 0));
+    RCHK(orbfe_stereo_match_device(s.mt, s.ex_l, s.ex_r, n, d_kl, d_dl, d_nl, s.d_kps_r, s.d_desc_r, d_nr, cap, c.bf,
                                    c.bf / c.fx, d_ur, d_depth, d_nst, cs));
     // the stereo points of frame j go to row j + 1; frame j is searched with the points of row j (row 0: the previous chunk's last)
     RCHK(orbfe_unproject_stereo_device(n, d_kl, d_dl, d_nl, d_depth, cap, d_cams, 1, p->d_pts + (size_t)cap, cs));
@@ -346,7 +380,7 @@ extern "C" int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n, int has
     RCHK(orbfe_track_queries_device(n, d_poses, p->d_pts, p->d_npts, cap, 0, p->d_q, p->d_nq, cs));
     PCHK(hipMemsetAsync(s.d_blocked, 0, (size_t)n * cap, cs));
     PCHK(hipMemsetAsync(d_assigned, 0xff, sizeof(int32_t) * (size_t)n * cap, cs));
-    RCHK(orbfe_proj_match_batch_device(p->mt, n, d_kl, d_dl, d_nl, d_ur, cap, 0.0f, (float)c.width, 0.0f, (float)c.height, p->d_q,
+    RCHK(orbfe_proj_match_batch_device(s.mt, n, d_kl, d_dl, d_nl, d_ur, cap, 0.0f, (float)c.width, 0.0f, (float)c.height, p->d_q,
                                        p->d_nq, cap, 1, 0.9f, c.check_orientation, s.d_blocked, d_assigned, d_ntr, cs));
     if (!has_predecessor) {   // the first frame of a sequence (or of a rank's shard) is searched against nothing
       PCHK(hipMemsetAsync(d_ntr, 0, sizeof(int32_t), cs));
@@ -364,6 +398,25 @@ extern "C" int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n, int has
   return ORBFE_OK;
 }
 
+extern "C" int orbfe_pipeline_submit(orbfe_pipeline* p, int slot, int n, int has_predecessor) {
+  return submit_chunk(p, slot, n, has_predecessor, false);
+}
+
+extern "C" int orbfe_pipeline_submit_resident(orbfe_pipeline* p, int slot, int n, int has_predecessor) {
+  return submit_chunk(p, slot, n, has_predecessor, true);
+}
+
+extern "C" int orbfe_pipeline_device_input(orbfe_pipeline* p, int slot, uint8_t** d_left, uint8_t** d_right, int* pitch,
+                                           size_t* image_bytes) {
+  if (!p || slot < 0 || slot >= (int)p->slots.size()) return ORBFE_ERR_INVALID;
+  Slot& s = p->slots[(size_t)slot];
+  if (d_left) *d_left = s.d_in + p->in_left;
+  if (d_right) *d_right = s.d_in + p->in_right;
+  if (pitch) *pitch = p->pitch;
+  if (image_bytes) *image_bytes = p->image_bytes;
+  return ORBFE_OK;
+}
+
 extern "C" int orbfe_pipeline_wait(orbfe_pipeline* p, int slot) {
   if (!p || slot < 0 || slot >= (int)p->slots.size()) return ORBFE_ERR_INVALID;
   std::lock_guard<std::mutex> lk(p->mu);
@@ -373,8 +426,8 @@ extern "C" int orbfe_pipeline_wait(orbfe_pipeline* p, int slot) {
   PCHK(hipEventSynchronize(s.ev_out));
   s.pending = false;
   // an internal table overflow of either extractor (ORBFE_ERR_CAPACITY) surfaces here
-  int rc = orbfe_device_status(p->ex_l);
-  if (rc == ORBFE_OK) rc = orbfe_device_status(p->ex_r);
+  int rc = orbfe_device_status(s.ex_l);
+  if (rc == ORBFE_OK) rc = orbfe_device_status(s.ex_r);
   return rc;
 }
 

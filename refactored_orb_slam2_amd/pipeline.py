@@ -49,6 +49,8 @@ class StereoPipeline:
         self._L.orbfe_pipeline_output.argtypes = [C.c_void_p, C.c_int, C.POINTER(_OutputView)]
         self._L.orbfe_pipeline_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         self._L.orbfe_pipeline_wait.argtypes = [C.c_void_p, C.c_int]
+        self._L.orbfe_pipeline_submit_resident.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self._L.orbfe_pipeline_device_input.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
         self.cfg = PipelineConfig(_lib.Params(n_features, scale_factor, n_levels, ini_th, min_th), width, height, batch, slots,
                                   fx, fy, cx, cy, bf, th, int(check_orientation))
         self._h = C.c_void_p(None)
@@ -77,6 +79,16 @@ class StereoPipeline:
 
     def submit(self, slot: int, n_frames: int, has_predecessor: bool):
         _lib.check(self._L.orbfe_pipeline_submit(self._h, slot, n_frames, int(has_predecessor)), "orbfe_pipeline_submit")
+
+    def submit_resident(self, slot: int, n_frames: int, has_predecessor: bool):
+        """The chunk whose images already are in the slot's DEVICE input blocks (an earlier submit's, or a device-side producer's)."""
+        _lib.check(self._L.orbfe_pipeline_submit_resident(self._h, slot, n_frames, int(has_predecessor)), "orbfe_pipeline_submit_resident")
+
+    def device_input(self, slot: int):
+        """(device pointer of the left images, of the right images, row pitch, bytes per image) of slot `slot`."""
+        dl, dr, pitch, ib = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_size_t()
+        _lib.check(self._L.orbfe_pipeline_device_input(self._h, slot, C.byref(dl), C.byref(dr), C.byref(pitch), C.byref(ib)), "orbfe_pipeline_device_input")
+        return dl.value, dr.value, pitch.value, ib.value
 
     def wait(self, slot: int):
         _lib.check(self._L.orbfe_pipeline_wait(self._h, slot), "orbfe_pipeline_wait")

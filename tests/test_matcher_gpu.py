@@ -1154,3 +1154,26 @@ def test_pipeline_handle_equals_the_oracle_across_chunks():
             assert g[4] == e[4], (i, g[4], e[4])
             np.testing.assert_array_equal(g[5], e[5], err_msg=f"tracked assignment of frame {i}")
         assert exp[4][4] > 300
+        # without waiting in between: chunk (3, 4, 5) in slot 1 while chunk (0, 1, 2) still runs in slot 0 -- the extraction of the
+        # second beside the matching half of the first, each slot on its own handles -- and then both again with the images left where
+        # the uploads put them (orbfe_pipeline_submit_resident), a host frame overwritten to prove nothing is uploaded
+        for s, idx in ((0, [0, 1, 2]), (1, [3, 4, 5])):
+            for j, i in enumerate(idx):
+                p.left(s)[j, :, :W] = pairs[i][0]; p.right(s)[j, :, :W] = pairs[i][1]
+        p.submit(0, 3, has_predecessor=False); p.submit(1, 3, has_predecessor=True)
+        p.wait(0); p.wait(1)
+        first = [{k: np.array(v, copy=True) for k, v in p.output(s).items()} for s in (0, 1)]
+        p.left(0)[1, :, :W] = 0; p.right(1)[2, :, :W] = 255
+        p.submit_resident(0, 3, has_predecessor=False); p.submit_resident(1, 3, has_predecessor=True)
+        p.wait(0); p.wait(1)
+        for s, idx in ((0, [0, 1, 2]), (1, [3, 4, 5])):
+            out = p.output(s)
+            for key in ("n_left", "kps_left", "desc_left", "u_right", "depth", "n_tracked", "assigned"):
+                np.testing.assert_array_equal(np.asarray(out[key]), first[s][key], err_msg=f"resident resubmit, slot {s}, {key}")
+            for j, i in enumerate(idx):
+                n = int(out["n_left"][j])
+                np.testing.assert_array_equal(out["kps_left"][j, :n], exp[i][0]); np.testing.assert_array_equal(out["depth"][j, :n], exp[i][3])
+                if i > 0:
+                    assert int(out["n_tracked"][j]) == exp[i][4]
+        dl, dr, pitch, ib = p.device_input(1)
+        assert dl and dr and dr > dl and pitch >= W and ib == pitch * H
