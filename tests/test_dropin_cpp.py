@@ -1,5 +1,6 @@
 """The C++ drop-in classes (csrc/host/): build everywhere, behave without a GPU, parity on the GPU."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -199,6 +200,15 @@ def test_cpp_sequence_driver_on_kitti_layout(tmp_path):
     assert rr.returncode == 0, rr.stdout + rr.stderr
     assert "Images in the sequence: 8" in rr.stdout and "frames decoded before the clock started" in rr.stdout, rr.stdout
     check_dump(dumpr, exp2)
+    # frames resident in the pinned slots (--preload 2) / in the slots' device blocks (--preload 3: orbfe_pipeline_submit_resident) after
+    # the first chunks: no dump (the results are those of the resident frames); the same keypoint and stereo statistics as the plain run
+    stats = re.search(r"keypoints/left image: ([0-9.]+), stereo matches/frame: ([0-9.]+)", rr.stdout)
+    for pre, what in (("2", "resident in the pinned slots"), ("3", "resident in HBM")):
+        rq = subprocess.run([exe, str(seq), "--batch", "4", "--slots", "2", "--preload", pre, "--repeat", "4"], capture_output=True, text=True, timeout=150)
+        assert rq.returncode == 0, rq.stdout + rq.stderr
+        assert what in rq.stdout and "Images in the sequence: 16" in rq.stdout, rq.stdout
+        sq = re.search(r"keypoints/left image: ([0-9.]+), stereo matches/frame: ([0-9.]+)", rq.stdout)
+        assert stats and sq and sq.group(1) == stats.group(1) and sq.group(2) == stats.group(2), (rq.stdout, rr.stdout)
     # the report: every frame counts (the front end was prepared before frame 0), tail latencies, the end-to-end rate
     for key in ("mean tracking time", "p95 tracking time", "p99 tracking time", "max tracking time", "frames/s end to end", "front end prepared in"):
         assert key in r.stdout, key
