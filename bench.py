@@ -313,6 +313,240 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+class StepRig:
+    """Everything one rank's step needs -- synthetic frames resident in HBM, `n_sets` sets of {two extractors, matcher, buffers}, the
+    HIP streams -- and the step itself.  `bench.py` times `step()`; `tests/test_bench_layout_gpu.py` runs the SAME object at the
+    same batch size and stream layout and compares what it leaves in the buffers with the oracle (round-5 review: the layout the
+    bench times had no parity test).  Layout of a step (lr_streams = 2, n_sets > 1): left | right extractor on two streams as the
+    reference runs them on two threads (L/src/Frame.cc:87-90), the matching half (Frame::ComputeStereoMatches L/src/Frame.cc:477-646,
+    UnprojectStereo, the projection of L/src/ORBmatcher.cc:1270-1308, SearchByProjection(cur, last) :1247-1383) on a third; the sets
+    take the steps in turn."""
+
+    def __init__(self, cfg, F, local=0, rank=0, n_sets=3, lr_streams=2, blur_kind=0):
+        import torch
+        from refactored_orb_slam2_amd import ORBextractor, synth
+        from refactored_orb_slam2_amd.matcher import Matcher
+        self.cfg, self.F, self.local = cfg, F, local
+        W, H, NFEAT, STEREO = cfg["w"], cfg["h"], cfg["nfeat"], cfg["stereo"]
+        self.W, self.H, self.NFEAT, self.STEREO = W, H, NFEAT, STEREO
+        self.dev = dev = torch.device("cuda", local)
+        # ---- synthetic input (each rank its own sequence), resident in HBM before the timed region; the pinned host copy
+        #      feeds the PCIe-inclusive measurement
+        #      Images live in buffers whose rows are PITCH = ceil64(W) bytes apart (what hipMemcpy2D / a decoder delivers): rows that
+        #      start on 16-byte boundaries are used as pyramid level 0 in place (include/orbfe.h); tightly packed odd-width rows would
+        #      cost one pitched copy per image first
+        self.data = data = synth.sequence(W, H, F, seq=rank, stereo=STEREO)
+        self.PITCH = PITCH = (W + 63) // 64 * 64
+
+        def pitched_host(imgs):
+            t = torch.zeros((F, H, PITCH), dtype=torch.uint8).pin_memory()
+            t[:, :, :W] = torch.from_numpy(np.stack(imgs))
+            return t
+
+        self.hL = pitched_host([p[0] for p in data] if STEREO else data)
+        self.hR = pitched_host([p[1] for p in data]) if STEREO else None
+        mkex = lambda: ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
+        self.exL = mkex()
+        self.exR = mkex() if STEREO else None
+        self.extractors = [e for e in (self.exL, self.exR) if e is not None]
+        self.mt = Matcher(local)
+        # more sets (--sets S): their own extractors (the matching half of a step reads their pyramids: the stereo SAD windows) and matcher
+        self.two_sets = n_sets >= 2 and lr_streams == 2 and STEREO and cfg["match"] == "projection"
+        self.n_sets = n_sets if self.two_sets else 1
+        self.more_ex, self.more_mt = [], []
+        for _ in range(self.n_sets - 1):
+            self.more_ex.append((mkex(), mkex()))
+            self.more_mt.append(Matcher(local))
+            self.extractors += list(self.more_ex[-1])
+        if blur_kind:
+            for e in self.extractors:
+                if e._L.orbfe_debug_blur_kernel(e._h, blur_kind) != 0:
+                    raise SystemExit("orbfe_debug_blur_kernel refused the kind")
+        self.cap = self.exL.max_keypoints(W, H)
+        self.cams_np, self.poses_np = camera_records(F, self.exL.GetScaleFactors(), cfg)
+        self.t_cams = torch.from_numpy(self.cams_np.view(np.uint8).reshape(F, -1)).to(dev)
+        self.t_poses = torch.from_numpy(self.poses_np.view(np.uint8).reshape(F, -1)).to(dev)
+        self.mb = cfg["bf"] / cfg["fx"]
+        self.B0 = self.Buffers()
+        # explicit HIP streams: torch's default stream is the NULL stream, which the C ABI reads as "use the handle's own
+        # stream"; the whole step therefore runs on named streams ordered by events
+        self.sM, self.sL, self.sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        self.evL, self.evR = torch.cuda.Event(), torch.cuda.Event()
+        self.lr = {"n": lr_streams}   # the stage-time passes switch to one stream: a launch's event time is then the kernel's own
+        # ---- the sets in turn: extraction of set k % S on sL / sR as soon as the matching half that last read that set (S
+        #      steps back) has ended; the matching half on sM behind the two extractions
+        self.more_B = [self.Buffers() for _ in range(self.n_sets - 1)]
+        ev = torch.cuda.Event
+        self.pipe_sets = ([(self.exL, self.exR, self.mt, self.B0, ev(), ev(), ev())] +
+                          [(self.more_ex[i][0], self.more_ex[i][1], self.more_mt[i], self.more_B[i], ev(), ev(), ev())
+                           for i in range(self.n_sets - 1)]) if self.two_sets else None
+        self.pipe_k = 0
+        if self.two_sets:
+            for ps in self.pipe_sets:
+                ps[6].record(self.sM)
+        self.gatherer = None
+        self.world = 1
+        self._dist = None
+
+    def Buffers(self):
+        return _Buffers(self)
+
+    def all_buffers(self):
+        return [self.B0] + self.more_B
+
+    def close(self):   # release the library handles while the HIP runtime is still alive, also after an exception
+        import torch
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        for hnd in self.extractors + [self.mt] + self.more_mt:
+            try:
+                hnd.close()
+            except Exception:
+                pass
+
+    def _step(self, cur, B):
+        from refactored_orb_slam2_amd.matcher import track_queries_batch, unproject_stereo_batch
+        cfg, W, H, STEREO = self.cfg, self.W, self.H, self.STEREO
+        exL, exR, mt, sL, sR = self.exL, self.exR, self.mt, self.sL, self.sR
+        if STEREO and self.lr["n"] == 2:
+            sL.wait_stream(cur); sR.wait_stream(cur)
+            exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90: two threads)
+            exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)   # ORBextractor right
+            self.evL.record(sL); self.evR.record(sR)
+            cur.wait_event(self.evL); cur.wait_event(self.evR)
+        else:
+            exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=cur)
+            if STEREO:
+                exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=cur)
+        if STEREO:
+            mt.stereo_match(exL, exR, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], self.mb, B.ur, B.depth, B.n_stereo, stream=cur)
+        if cfg["match"] == "projection":
+            unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, self.t_cams, 1, B.pts, cur)   # Frame::UnprojectStereo per keypoint with depth
+            track_queries_batch(self.t_poses, B.pts, B.nl, 1, B.q, B.nq, cur)               # projected into the next frame (:1270-1308)
+            B.blocked.zero_(); B.assigned.fill_(-1)
+            mt.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked,
+                                B.assigned, B.n_track, stream=cur)                    # SearchByProjection(cur, last, th)
+        else:
+            # SearchByBoW's brute force: frame f against frame f-1 (slices of the same buffers: no copies), grouped by node id
+            B.grp.copy_(node_ids(B.dl))
+            mt.hamming_bf_batch(B.dl[1:], B.nl[1:], B.dl[:-1], B.nl[:-1], B.grp[1:], B.grp[:-1], B.bf[1:], stream=cur)
+        if self.gatherer is not None:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
+            self.gatherer.launch(B.nl, B.kl, B.dl)
+
+    def _step_piped(self):
+        from refactored_orb_slam2_amd.matcher import track_queries_batch, unproject_stereo_batch
+        cfg, W, H, sM, sL, sR = self.cfg, self.W, self.H, self.sM, self.sL, self.sR
+        xl, xr, m, B, eL, eR, eT = self.pipe_sets[self.pipe_k % self.n_sets]
+        self.pipe_k += 1
+        sL.wait_event(eT); sR.wait_event(eT)
+        xl.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)
+        xr.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)
+        eL.record(sL); eR.record(sR)
+        sM.wait_event(eL); sM.wait_event(eR)
+        m.stereo_match(xl, xr, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], self.mb, B.ur, B.depth, B.n_stereo, stream=sM)
+        unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, self.t_cams, 1, B.pts, sM)
+        track_queries_batch(self.t_poses, B.pts, B.nl, 1, B.q, B.nq, sM)
+        B.blocked.zero_(); B.assigned.fill_(-1)
+        m.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked, B.assigned,
+                           B.n_track, stream=sM)
+        if self.gatherer is not None:
+            self.gatherer.launch(B.nl, B.kl, B.dl)
+        eT.record(sM)
+
+    def step(self):
+        import torch
+        sM = self.sM
+        with torch.cuda.stream(sM):
+            if self.two_sets and self.lr["n"] == 2:
+                self._step_piped()
+            else:
+                if self.two_sets:
+                    sM.wait_stream(self.sL); sM.wait_stream(self.sR)   # (a one-stream pass behind pipelined steps ...
+                self._step(sM, self.B0)
+                if self.two_sets:
+                    self.pipe_sets[0][6].record(sM)               #  ... and in front of the next ones: set 0 is free when this step has ended)
+
+    def barrier(self):
+        import torch
+        if self.gatherer is not None:
+            with torch.cuda.stream(self.sM):
+                self.gatherer.wait()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self._dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- self-check of the timed layout (config.self_check): every set's outputs hashed on the device side's host copy
+    OUT_FIELDS = ("nl", "kl", "dl", "nr", "kr", "dr", "ur", "depth", "n_stereo", "n_track", "assigned")
+
+    def output_digest(self, B):
+        """SHA-256 over every field a step leaves in `B` (counts, keypoints, descriptors of both eyes, mvuRight / mvDepth, stereo and
+        tracked counts, the tracked assignment).  Rows behind a frame's count are whatever earlier steps left: only the first n
+        entries of a row are hashed."""
+        import hashlib
+        import torch
+        h = hashlib.sha256()
+        torch.cuda.synchronize()
+        nl = B.nl.cpu().numpy()
+        nr = B.nr.cpu().numpy() if self.STEREO else None
+        h.update(nl.tobytes())
+
+        def rows(t, n):
+            a = t.cpu().numpy()
+            m = np.arange(a.shape[1])[None, :] < n[:, None]
+            h.update(np.ascontiguousarray(a[m]).tobytes())
+
+        rows(B.kl, nl); rows(B.dl, nl)
+        if self.STEREO:
+            h.update(nr.tobytes()); rows(B.kr, nr); rows(B.dr, nr); rows(B.ur, nl); rows(B.depth, nl)
+            h.update(B.n_stereo.cpu().numpy().tobytes())
+        if self.cfg["match"] == "projection":
+            h.update(B.n_track.cpu().numpy().tobytes()); rows(B.assigned, nl)
+        return h.hexdigest()
+
+    def self_check(self):
+        """After steps on the timed layout: every set's outputs equal each other and equal what a ONE-stream, one-set step leaves
+        (every kernel alone on the chip, the layout the stage parity tests run)."""
+        digs = [self.output_digest(B) for B in self.all_buffers()]
+        keep = self.lr["n"]
+        self.lr["n"] = 1
+        self.step(); self.barrier()
+        one = self.output_digest(self.B0)
+        self.lr["n"] = keep
+        for _ in range(self.n_sets):   # back on the timed layout, every set written once more
+            self.step()
+        self.barrier()
+        again = [self.output_digest(B) for B in self.all_buffers()]
+        return {"sets_equal": len(set(digs)) == 1 and len(set(again)) == 1, "equals_one_stream": all(d == one for d in digs + again),
+                "sets": len(digs), "sha256_16": one[:16]}
+
+
+class _Buffers:
+    """One set of device inputs and outputs of a step (two sets double-buffer the PCIe-inclusive run)."""
+
+    def __init__(self, rig):
+        import torch
+        F, cap, dev, STEREO, W = rig.F, rig.cap, rig.dev, rig.STEREO, rig.W
+        z = lambda *s, dt=torch.uint8: torch.zeros(s, dtype=dt, device=dev)
+        self.dL_full = rig.hL.to(dev)                       # (F, H, PITCH); the extractor sees the (F, H, W) view
+        self.dR_full = rig.hR.to(dev) if STEREO else None
+        self.dL = self.dL_full[:, :, :W]
+        self.dR = self.dR_full[:, :, :W] if STEREO else None
+        self.kl, self.dl, self.nl = z(F, cap, 28), z(F, cap, 32), z(F, dt=torch.int32)
+        if STEREO:
+            self.kr, self.dr, self.nr = z(F, cap, 28), z(F, cap, 32), z(F, dt=torch.int32)
+        self.ur = z(F, cap, dt=torch.float32) if STEREO else None
+        self.depth = z(F, cap, dt=torch.float32) if STEREO else torch.full((F, cap), MONO_DEPTH, dtype=torch.float32, device=dev)
+        self.n_stereo = z(F, dt=torch.int32)
+        self.blocked, self.assigned, self.n_track = z(F, cap), z(F, cap, dt=torch.int32), z(F, dt=torch.int32)
+        self.pts, self.q, self.nq = z(F, cap, 60), z(F, cap, 68), z(F, dt=torch.int32)   # orbfe_last_point / orbfe_query
+        self.bf = z(F, cap, 12)                                                          # orbfe_bf_match records
+        self.grp = z(F, cap, dt=torch.int32)
+
+
+
 def main():
     if os.environ.get("ORBFE_BENCH_WATCHDOG"):  # debugging aid: dump all stacks and exit if the run exceeds N seconds
         import faulthandler
@@ -383,170 +617,20 @@ def main():
             dist.init_process_group(backend)
 
     F = args.frames
-    # ---- synthetic input (each rank its own sequence), resident in HBM before the timed region; the pinned host copy
-    #      feeds the PCIe-inclusive measurement
-    #      Images live in buffers whose rows are PITCH = ceil64(W) bytes apart (what hipMemcpy2D / a decoder delivers): rows that
-    #      start on 16-byte boundaries are used as pyramid level 0 in place (include/orbfe.h); tightly packed odd-width rows would
-    #      cost one pitched copy per image first
-    data = synth.sequence(W, H, F, seq=rank, stereo=STEREO)
-    PITCH = (W + 63) // 64 * 64
-
-    def pitched_host(imgs):
-        t = torch.zeros((F, H, PITCH), dtype=torch.uint8).pin_memory()
-        t[:, :, :W] = torch.from_numpy(np.stack(imgs))
-        return t
-
-    hL = pitched_host([p[0] for p in data] if STEREO else data)
-    hR = pitched_host([p[1] for p in data]) if STEREO else None
-
-    exL = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
-    exR = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local) if STEREO else None
-    extractors = [e for e in (exL, exR) if e is not None]
-    if args.blur_kind:
-        for e in extractors:
-            if e._L.orbfe_debug_blur_kernel(e._h, args.blur_kind) != 0:
-                raise SystemExit("orbfe_debug_blur_kernel refused the kind")
-    mt = Matcher(local)
-    # the second set (--sets 2): its own extractors (the matching half of a step reads their pyramids: the stereo SAD windows) and matcher
-    two_sets = args.sets >= 2 and args.lr_streams == 2 and STEREO and cfg["match"] == "projection"
-    n_sets = args.sets if two_sets else 1
-    more_ex, more_mt = [], []
-    for _ in range(n_sets - 1):
-        more_ex.append((ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local), ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)))
-        more_mt.append(Matcher(local))
-        extractors += list(more_ex[-1])
-        if args.blur_kind:
-            for e in more_ex[-1]:
-                if e._L.orbfe_debug_blur_kernel(e._h, args.blur_kind) != 0:
-                    raise SystemExit("orbfe_debug_blur_kernel refused the kind")
+    rig = StepRig(cfg, F, local=local, rank=rank, n_sets=args.sets, lr_streams=args.lr_streams, blur_kind=args.blur_kind)
     import atexit
-
-    def _close_handles():  # release the library handles while the HIP runtime is still alive, also after an exception
-        try:
-            torch.cuda.synchronize()
-        except Exception:
-            pass
-        for hnd in extractors + [mt] + more_mt:
-            try:
-                hnd.close()
-            except Exception:
-                pass
-
-    atexit.register(_close_handles)
-    cap = exL.max_keypoints(W, H)
-    cams_np, poses_np = camera_records(F, exL.GetScaleFactors(), cfg)
-    t_cams = torch.from_numpy(cams_np.view(np.uint8).reshape(F, -1)).to(dev)
-    t_poses = torch.from_numpy(poses_np.view(np.uint8).reshape(F, -1)).to(dev)
-    mb = cfg["bf"] / cfg["fx"]
-
-    class Buffers:
-        """One set of device inputs and outputs of a step (two sets double-buffer the PCIe-inclusive run)."""
-
-        def __init__(self):
-            z = lambda *s, dt=torch.uint8: torch.zeros(s, dtype=dt, device=dev)
-            self.dL_full = hL.to(dev)                       # (F, H, PITCH); the extractor sees the (F, H, W) view
-            self.dR_full = hR.to(dev) if STEREO else None
-            self.dL = self.dL_full[:, :, :W]
-            self.dR = self.dR_full[:, :, :W] if STEREO else None
-            self.kl, self.dl, self.nl = z(F, cap, 28), z(F, cap, 32), z(F, dt=torch.int32)
-            if STEREO:
-                self.kr, self.dr, self.nr = z(F, cap, 28), z(F, cap, 32), z(F, dt=torch.int32)
-            self.ur = z(F, cap, dt=torch.float32) if STEREO else None
-            self.depth = z(F, cap, dt=torch.float32) if STEREO else torch.full((F, cap), MONO_DEPTH, dtype=torch.float32, device=dev)
-            self.n_stereo = z(F, dt=torch.int32)
-            self.blocked, self.assigned, self.n_track = z(F, cap), z(F, cap, dt=torch.int32), z(F, dt=torch.int32)
-            self.pts, self.q, self.nq = z(F, cap, 60), z(F, cap, 68), z(F, dt=torch.int32)   # orbfe_last_point / orbfe_query
-            self.bf = z(F, cap, 12)                                                          # orbfe_bf_match records
-            self.grp = z(F, cap, dt=torch.int32)
-
-    B0 = Buffers()
-    # explicit HIP streams: torch's default stream is the NULL stream, which the C ABI reads as "use the handle's own
-    # stream"; the whole step therefore runs on named streams ordered by events
-    sM, sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    evL, evR = torch.cuda.Event(), torch.cuda.Event()
-
-    lr = {"n": args.lr_streams}   # the stage-time passes switch to one stream: a launch's event time is then the kernel's own
-
-    def _step(cur, B):
-        if STEREO and lr["n"] == 2:
-            sL.wait_stream(cur); sR.wait_stream(cur)
-            exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)   # ORBextractor left  (Frame.cc:87-90: two threads)
-            exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)   # ORBextractor right
-            evL.record(sL); evR.record(sR)
-            cur.wait_event(evL); cur.wait_event(evR)
-        else:
-            exL.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=cur)
-            if STEREO:
-                exR.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=cur)
-        if STEREO:
-            mt.stereo_match(exL, exR, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], mb, B.ur, B.depth, B.n_stereo, stream=cur)
-        if cfg["match"] == "projection":
-            unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, t_cams, 1, B.pts, cur)   # Frame::UnprojectStereo per keypoint with depth
-            track_queries_batch(t_poses, B.pts, B.nl, 1, B.q, B.nq, cur)               # projected into the next frame (:1270-1308)
-            B.blocked.zero_(); B.assigned.fill_(-1)
-            mt.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked,
-                                B.assigned, B.n_track, stream=cur)                    # SearchByProjection(cur, last, th)
-        else:
-            # SearchByBoW's brute force: frame f against frame f-1 (slices of the same buffers: no copies), grouped by node id
-            B.grp.copy_(node_ids(B.dl))
-            mt.hamming_bf_batch(B.dl[1:], B.nl[1:], B.dl[:-1], B.nl[:-1], B.grp[1:], B.grp[:-1], B.bf[1:], stream=cur)
-        if gatherer is not None:  # the path's only exchange: gather of the per-frame keypoint records (overlaps the next step)
-            gatherer.launch(B.nl, B.kl, B.dl)
-
-    # ---- two sets in turn (--sets 2): extraction of set k & 1 on sL / sR as soon as the matching half that last read that set (two
-    #      steps back) has ended; the matching half on sM behind the two extractions
-    more_B = [Buffers() for _ in range(n_sets - 1)]
-    pipe_sets = ([(exL, exR, mt, B0, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())] +
-                 [(more_ex[i][0], more_ex[i][1], more_mt[i], more_B[i], torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
-                  for i in range(n_sets - 1)]) if two_sets else None
-    pipe_k = {"k": 0}
-    if two_sets:
-        for ps in pipe_sets:
-            ps[6].record(sM)
-
-    def _step_piped():
-        xl, xr, m, B, eL, eR, eT = pipe_sets[pipe_k["k"] % n_sets]
-        pipe_k["k"] += 1
-        sL.wait_event(eT); sR.wait_event(eT)
-        xl.extract_batch_device(B.dL, B.kl, B.dl, B.nl, stream=sL)
-        xr.extract_batch_device(B.dR, B.kr, B.dr, B.nr, stream=sR)
-        eL.record(sL); eR.record(sR)
-        sM.wait_event(eL); sM.wait_event(eR)
-        m.stereo_match(xl, xr, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], mb, B.ur, B.depth, B.n_stereo, stream=sM)
-        unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, t_cams, 1, B.pts, sM)
-        track_queries_batch(t_poses, B.pts, B.nl, 1, B.q, B.nq, sM)
-        B.blocked.zero_(); B.assigned.fill_(-1)
-        m.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked, B.assigned,
-                           B.n_track, stream=sM)
-        if gatherer is not None:
-            gatherer.launch(B.nl, B.kl, B.dl)
-        eT.record(sM)
-
-    def step():
-        with torch.cuda.stream(sM):
-            if two_sets and lr["n"] == 2:
-                _step_piped()
-            else:
-                if two_sets:
-                    sM.wait_stream(sL); sM.wait_stream(sR)   # (a one-stream pass behind pipelined steps ...
-                _step(sM, B0)
-                if two_sets:
-                    pipe_sets[0][6].record(sM)               #  ... and in front of the next ones: set 0 is free when this step has ended)
-
+    atexit.register(rig.close)
+    rig.world, rig._dist = world, dist
+    data, PITCH, hL, hR = rig.data, rig.PITCH, rig.hL, rig.hR
+    exL, exR, extractors, mt = rig.exL, rig.exR, rig.extractors, rig.mt
+    two_sets, n_sets, more_B, B0, Buffers = rig.two_sets, rig.n_sets, rig.more_B, rig.B0, rig.Buffers
+    sM, sL, sR, lr = rig.sM, rig.sL, rig.sR, rig.lr
+    _step, step, barrier = rig._step, rig.step, rig.barrier
     gatherer = None
     if args.gather_impl == "cabi" and backend == "nccl":
-        gatherer = CabiAsyncGather(B0.nl, B0.kl, B0.dl, rank, world, local, mode=args.gather)
+        rig.gatherer = gatherer = CabiAsyncGather(B0.nl, B0.kl, B0.dl, rank, world, local, mode=args.gather)
     elif world > 1:
-        gatherer = AsyncGather(B0.nl, B0.kl, B0.dl, mode=args.gather)
-
-    def barrier():
-        if gatherer is not None:
-            with torch.cuda.stream(sM):
-                gatherer.wait()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        rig.gatherer = gatherer = AsyncGather(B0.nl, B0.kl, B0.dl, mode=args.gather)
 
     for _ in range(max(args.warmup, 1) if args.warmup >= 0 else 0):
         step()
@@ -661,6 +745,10 @@ def main():
     st_dom = stage_sums()[dom]
     for e in extractors:
         e.profile(False)
+    # ---- self-check of the layout that was just timed (after the clock stopped): what the last steps left in every set's buffers
+    #      is identical across the sets and identical to a one-stream, one-set step (the layout the stage parity tests cover);
+    #      tests/test_bench_layout_gpu.py compares the same object's outputs with the oracle
+    self_check = rig.self_check()
 
     # ---- PCIe-inclusive rate (N = 1): pinned host images in, host keypoints / descriptors / match results out, two buffer
     #      sets: the H2D copy of step i+1 and the D2H copy of step i-1 run beside the kernels of step i
@@ -851,7 +939,7 @@ def main():
                        "collective": ((f"{'RCCL through the C ABI (orbfe_gather_records)' if (args.gather_impl == 'cabi' and backend == 'nccl') else backend} "
                                        f"{'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {world}") if gatherer is not None else "none"),
                        "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
-                       "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3)},
+                       "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3), "self_check": self_check},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved_alone, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved_alone / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
@@ -893,6 +981,8 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
         print(json.dumps(out), flush=True)
+    if not (self_check["sets_equal"] and self_check["equals_one_stream"]):
+        raise SystemExit(f"rank {rank}: the timed layout's outputs differ between the handle sets or from the one-stream step: {self_check}")
     if world > 1:
         # the gathered records of the last step == every rank's own records at its slot (the collective moved the right bytes)
         res = gatherer.result()
