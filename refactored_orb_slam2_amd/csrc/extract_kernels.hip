@@ -464,7 +464,19 @@ __device__ __forceinline__ int arc9_maxmin_pk(const uint32_t (&P)[8], uint32_t V
 //           per lane); kept pixels set bits, one 32-bit word per tested row.  Cells whose list was recycled (> 256 survivors)
 //           walk the bitmap instead (lane = word)
 //   C       row-major emission from the bitmap, one packed wave scan for the output offsets
+#ifndef FC_LIST_CAP
 #define FC_LIST_CAP 384
+#endif
+#ifndef FC_LDS_PAD
+#define FC_LDS_PAD 0     // experiment: unused bytes per wave slice (what the kernel's LDS footprint does to its neighbours on the CU)
+#endif
+#ifndef FC_T2_QUEUE
+#define FC_T2_QUEUE 1    // tier 2 of the quick test over QUEUED tier-1 survivors, 64 pairs at a time (0: in place, wave-uniform branch: rounds 3-5)
+#endif
+#define FC_Q1_CAP 128    // the ring holds < 64 entries between rounds and an iteration adds <= 64
+#ifndef FC_T1_ASM
+#define FC_T1_ASM 1      // the tier-1 loop as one block of assembly (0: the compiler's loop)
+#endif
 #ifndef FC_TIMING
 #define FC_TIMING 0
 #endif
@@ -494,7 +506,7 @@ extern "C" int orbfe_debug_fc_profile(unsigned long long* out, int reset) {
 #endif
 // LDS bytes of one wave's slice: byte tile, score plane, bitmap of scored pixels (nbw words), survivor list
 __host__ __device__ inline int fc_wave_lds(int rows_max, int pb, int sc_bytes, int nbw) {
-  return rows_max * pb + sc_bytes + nbw * 4 + FC_LIST_CAP * 2;
+  return rows_max * pb + sc_bytes + nbw * 4 + FC_LIST_CAP * 2 + (FC_T2_QUEUE ? FC_Q1_CAP * 2 : 0) + FC_LDS_PAD;
 }
 template <int PB, int NLD>   // PB: bytes per staged row (64 or 96); NLD: load rounds of 64 lanes x 16 bytes per cell
 __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
@@ -508,6 +520,9 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
   uint8_t* sc = tile + rows_max * PB;
   uint32_t* scb = reinterpret_cast<uint32_t*>(sc + sc_bytes);   // bitmap of scored pixels, row-major over the tested region
   uint16_t* list = reinterpret_cast<uint16_t*>(scb + nbw);      // quick-test survivors (tile index | polarity)
+#if FC_T2_QUEUE
+  uint16_t* q1 = list + FC_LIST_CAP;                            // ring of tier-1 survivors: tile index of a lane's pixel pair
+#endif
   int img = blockIdx.y;
   const int nblk = (n_runs + 3) >> 2;
   const int q = blockIdx.x >> 3;
@@ -716,15 +731,252 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
         const int x = c_lo + 2 * pl;                   // even: the pair (x, x + 1) starts at byte 0 or 2 of its dword
         const bool odd2 = (x & 2) != 0;
         const uint32_t selV = odd2 ? 0x0c030c02u : 0x0c010c00u;    // (x, x+1) and (x, x+1) of rows +-3
+#if !FC_T2_QUEUE
         const uint32_t selX = odd2 ? 0x0c010c00u : 0x0c030c02u;    // (x+-2, x+-2+1)
+#endif
         const uint32_t selM = odd2 ? 0x0c040c03u : 0x0c020c01u;    // (x-3, x-2) out of dwords {D(x)-1, D(x)}
         const uint32_t selP = odd2 ? 0x0c020c01u : 0x0c040c03u;    // (x+3, x+4) out of dwords {D(x+2), D(x+2)+1}
         // addresses of row (y - 3): a0 = the dword of x minus one dword (the centre row reads {D-1, D}); a1 = the dword of
         // x - 2, which is also the dword of x + 2 minus one dword (x = 4k: D(x) - 1; x = 4k + 2: D(x))
         uint32_t a0 = tile_a + rl * PB + ((x >> 2) << 2) - 4;
         uint32_t a1 = a0 + (odd2 ? 4u : 0u);
+#if !(FC_T2_QUEUE && FC_T1_ASM)
         const uint32_t ec = (uint32_t)(3 * PB + 4 + (x & 3)) - tile_a;   // byte index of the pair's first pixel = a0 + ec
         int rows_left = lane_ok ? th - rl : 0;         // lane active while rows_left > 0
+#endif
+#if FC_T2_QUEUE && FC_T1_ASM
+        // Tier 1 runs over all the cell's pixels; the lanes that pass it (a fifth of the 64 on a triggered iteration) used to take the
+        // whole wave through tier 2 and the survivor push (35 vector instructions at ~20 % lane use).  Here they only queue their
+        // pair (`q1`, first in first out = row-major order: the LDS address of the pair's window | its column parity); tier 2 + push
+        // run over 64 QUEUED pairs at a time: whenever the queue holds a wave's worth, and once at the end of the cell (the tile is
+        // restaged for the next one).
+        // The tier-1 loop itself is one block of assembly: measured on this kernel a scalar instruction costs what a vector
+        // instruction costs (eight s_add per iteration: + 3.1 % alone, + 1.1 % on the step; eight v_add: + 3.5 % / + 1.3 %), and the
+        // compiler's loop carried ~20 of them per iteration (loop-carried conditions materialised as 64-bit masks, exec save /
+        // restore around the queue store, a branch per condition).  Per iteration here: 3 LDS reads, 19 vector, 8 scalar
+        // instructions, + 4 / 4 / 1 on the 57 % of the iterations in which a lane passes.
+        const unsigned long long m_full = __ballot(lane_ok), m_last = __ballot(lane_ok && rl < th - (n_it - 1) * RI);
+        const uint32_t oddbit = odd2 ? 1u : 0u;
+        const uint32_t q_base = (uint32_t)(uintptr_t)q1, q_limit = q_base + 2u * WAVE;
+        uint32_t q_addr = q_base;
+        int it = 0;
+        for (int phase = 0; phase < 2; phase++) {
+          const unsigned long long actm = phase ? m_last : m_full;
+          const int nit = __builtin_amdgcn_readfirstlane(phase ? n_it : n_it - 1);   // (uniform values the compiler keeps in vector registers)
+          const int step = __builtin_amdgcn_readfirstlane(RI * PB);
+          for (;;) {
+            if (it < nit) {
+              uint32_t tV, tA, tB, tC, tD, tE;
+              uint32_t sc_;
+              asm volatile(
+                  "1:\n\t"
+                  "ds_read2_b32 v[64:65], %[a0] offset0:1 offset1:%[K61]\n\t"
+                  "ds_read2_b32 v[66:67], %[a0] offset0:%[K30] offset1:%[K31]\n\t"
+                  "ds_read2_b32 v[68:69], %[a1] offset0:%[K31] offset1:%[K32]\n\t"
+                  "s_add_u32 %[it], %[it], 1\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "v_perm_b32 %[tV], 0, v67, %[selV]\n\t"          // V: the centre pair
+                  "v_perm_b32 %[tA], 0, v64, %[selV]\n\t"          // Q8 (row y - 3)
+                  "v_perm_b32 %[tB], 0, v65, %[selV]\n\t"          // Q0 (row y + 3)
+                  "v_perm_b32 %[tC], v67, v66, %[selM]\n\t"        // Q12 (x - 3, x - 2)
+                  "v_perm_b32 %[tD], v69, v68, %[selP]\n\t"        // Q4 (x + 3, x + 4)
+                  "v_pk_min_u16 %[tE], %[tB], %[tA]\n\t"           // min(Q0, Q8)
+                  "v_pk_max_u16 %[tA], %[tB], %[tA]\n\t"           // max(Q0, Q8)
+                  "v_pk_min_u16 %[tB], %[tD], %[tC]\n\t"           // min(Q4, Q12)
+                  "v_pk_max_u16 %[tC], %[tD], %[tC]\n\t"           // max(Q4, Q12)
+                  "v_pk_max_u16 %[tE], %[tE], %[tB]\n\t"           // lo
+                  "v_pk_min_u16 %[tA], %[tA], %[tC]\n\t"           // hi
+                  "v_add_u32 %[tB], %[C], %[tV]\n\t"               // AD = V + C
+                  "v_sub_u32 %[tC], %[C], %[tV]\n\t"               // AB = C - V
+                  "v_sub_u32 %[tB], %[tB], %[tE]\n\t"              // AD - lo
+                  "v_add_u32 %[tC], %[tA], %[tC]\n\t"              // hi + AB
+                  "v_bitop3_b32 %[tB], %[tB], %[M], %[tC] bitop3:0xc8\n\t"   // (dark | bright) & 0x80008000
+                  "v_cmp_ne_u32 vcc, 0, %[tB]\n\t"
+                  "s_and_b64 vcc, vcc, %[actm]\n\t"
+                  "s_cbranch_scc0 2f\n\t"
+                  "v_mbcnt_lo_u32_b32 %[tA], vcc_lo, 0\n\t"
+                  "v_mbcnt_hi_u32_b32 %[tA], vcc_hi, %[tA]\n\t"
+                  "v_or_b32 %[tC], %[a0], %[odd]\n\t"
+                  "v_lshl_add_u32 %[tA], %[tA], 1, %[qa]\n\t"
+                  "s_mov_b64 exec, vcc\n\t"
+                  "ds_write_b16 %[tA], %[tC]\n\t"
+                  "s_mov_b64 exec, -1\n\t"
+                  "s_bcnt1_i32_b64 %[sc], vcc\n\t"
+                  "s_lshl1_add_u32 %[qa], %[sc], %[qa]\n\t"
+                  "2:\n\t"
+                  "v_add_u32 %[a0], %[step], %[a0]\n\t"
+                  "v_add_u32 %[a1], %[step], %[a1]\n\t"
+                  "s_cmp_ge_u32 %[qa], %[ql]\n\t"
+                  "s_cbranch_scc1 3f\n\t"
+                  "s_cmp_lt_i32 %[it], %[nit]\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "3:"
+                  : [a0] "+v"(a0), [a1] "+v"(a1), [it] "+s"(it), [qa] "+s"(q_addr), [tV] "=&v"(tV), [tA] "=&v"(tA), [tB] "=&v"(tB),
+                    [tC] "=&v"(tC), [tD] "=&v"(tD), [tE] "=&v"(tE), [sc] "=&s"(sc_)
+                  : [selV] "v"(selV), [selM] "v"(selM), [selP] "v"(selP), [odd] "v"(oddbit), [C] "s"(C), [M] "s"(0x80008000u),
+                    [actm] "s"(actm), [step] "s"(step), [ql] "s"(q_limit), [nit] "s"(nit),
+                    [K61] "n"(6 * PB / 4 + 1), [K30] "n"(3 * PB / 4), [K31] "n"(3 * PB / 4 + 1), [K32] "n"(3 * PB / 4 + 2)
+                  : "memory", "vcc", "scc", "v64", "v65", "v66", "v67", "v68", "v69");
+            }
+            const int qn = (int)(q_addr - q_base) >> 1;
+            if (qn < WAVE && !(phase == 1 && it >= nit && qn > 0)) break;   // wave-uniform: no round due
+            // ---- a round of tier 2 over the first min(qn, 64) queued pairs: lane = pair
+            const bool on = lane < qn;
+            uint32_t ev = q1[lane];
+            ev = on ? ev : tile_a;            // idle lanes test the tile's first window and push nothing
+            if (qn > WAVE) {                    // what is left moves to the front of the queue
+              const uint32_t rest = q1[WAVE + min(lane, qn - WAVE - 1)];
+              if (lane < qn - WAVE) q1[lane] = (uint16_t)rest;
+            }
+            q_addr = q_base + 2u * (uint32_t)(qn > WAVE ? qn - WAVE : 0);
+            const uint32_t o1 = ev & 1u, b0 = ev - o1, b1 = b0 + 4u * o1, k2 = o1 * 0x00020002u;
+            const uint32_t e2 = b0 - tile_a + (uint32_t)(3 * PB + 4) + 2u * o1;   // tile index of the pair's first pixel
+            const uint32_t sV = 0x0c010c00u + k2, sX = 0x0c030c02u - k2, sM = 0x0c020c01u + k2, sP = 0x0c040c03u - k2;
+            unsigned long long p08, pc, pp, p62, p1014;
+            asm volatile(
+                "ds_read2_b32 %0, %5 offset0:1 offset1:%7\n\t"
+                "ds_read2_b32 %1, %5 offset0:%8 offset1:%9\n\t"
+                "ds_read2_b32 %2, %6 offset0:%9 offset1:%10\n\t"
+                "ds_read2_b32 %3, %6 offset0:%11 offset1:%12\n\t"
+                "ds_read2_b32 %4, %6 offset0:%13 offset1:%14\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(p08), "=&v"(pc), "=&v"(pp), "=&v"(p62), "=&v"(p1014)
+                : "v"(b0), "v"(b1), "n"(6 * PB / 4 + 1), "n"(3 * PB / 4), "n"(3 * PB / 4 + 1), "n"(3 * PB / 4 + 2),
+                  "n"(PB / 4 + 1), "n"(5 * PB / 4 + 1), "n"(PB / 4), "n"(5 * PB / 4)
+                : "memory");
+            {
+              const uint32_t D0 = (uint32_t)(pc >> 32), Dm = (uint32_t)pc;
+              const uint32_t V = __builtin_amdgcn_perm(0u, D0, sV);
+              const uint32_t Q8 = __builtin_amdgcn_perm(0u, (uint32_t)p08, sV), Q0 = __builtin_amdgcn_perm(0u, (uint32_t)(p08 >> 32), sV);
+              const uint32_t Q12 = __builtin_amdgcn_perm(D0, Dm, sM);
+              const uint32_t Q4 = __builtin_amdgcn_perm((uint32_t)(pp >> 32), (uint32_t)pp, sP);
+              const uint32_t Q6 = __builtin_amdgcn_perm(0u, (uint32_t)p62, sX), Q2 = __builtin_amdgcn_perm(0u, (uint32_t)(p62 >> 32), sX);
+              const uint32_t Q10 = __builtin_amdgcn_perm(0u, (uint32_t)p1014, sX), Q14 = __builtin_amdgcn_perm(0u, (uint32_t)(p1014 >> 32), sX);
+              const uint32_t AD = V + C, AB = C - V;
+              const uint32_t lo = pkmax(pkmax(pkmin(Q0, Q8), pkmin(Q4, Q12)), pkmax(pkmin(Q2, Q10), pkmin(Q6, Q14)));
+              const uint32_t hi = pkmin(pkmin(pkmax(Q0, Q8), pkmax(Q4, Q12)), pkmin(pkmax(Q2, Q10), pkmax(Q6, Q14)));
+              const uint32_t dark = AD - lo, brt = hi + AB;
+              const uint32_t G = on ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
+              const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
+              // the list stays in row-major order (the queue is first in, first out; a lane's two pixels are neighbours): the NMS
+              // below emits straight from it
+              const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
+              const int c0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
+              const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)c0));
+              const int i1 = i0 + (has0 ? 1 : 0);
+              if (has0) list[i0] = (uint16_t)((G & 0xC000u) | e2);
+              if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (e2 + 1));
+              wcnt += __popcll(m0) + __popcll(m1);
+            }
+            if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
+              FC_T(2);
+              if (!flushed)
+                for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
+              flushed = true;
+              score_list(wcnt, true, th_cur);
+              FC_T(3);
+              wcnt = 0;
+            }
+          }
+        }
+#elif FC_T2_QUEUE
+        // Tier 1 runs over all the cell's pixels; the lanes that pass it (a fifth of the 64 on a triggered iteration) used to take the
+        // whole wave through tier 2 and the survivor push (35 vector instructions at ~20 % lane use).  Here they only queue the
+        // position of their pair (ring `q1`, FIFO = row-major order); tier 2 + push run over 64 QUEUED pairs at a time: whenever the
+        // ring holds a wave's worth, and once at the end of the cell (the tile is restaged for the next one).  Every pass of the loop
+        // below is one tier-1 iteration followed by at most one such round; the extra last pass is the drain.
+        int q1h = 0, q1t = 0;
+        for (int it = 0; it <= n_it; it++) {
+          if (it < n_it) {
+            // inactive lanes read in-range garbage: rows < rows_max + RI
+            const unsigned long long actm = __builtin_amdgcn_sicmp(rows_left, 0, 38 /* ICMP_SGT */);
+            unsigned long long p08, pc, pp;
+            asm volatile(
+                "ds_read2_b32 %0, %3 offset0:1 offset1:%5\n\t"
+                "ds_read2_b32 %1, %3 offset0:%6 offset1:%7\n\t"
+                "ds_read2_b32 %2, %4 offset0:%7 offset1:%8\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(p08), "=&v"(pc), "=&v"(pp)
+                : "v"(a0), "v"(a1), "n"(6 * PB / 4 + 1), "n"(3 * PB / 4), "n"(3 * PB / 4 + 1), "n"(3 * PB / 4 + 2)
+                : "memory");
+            const uint32_t D0 = (uint32_t)(pc >> 32), Dm = (uint32_t)pc;
+            const uint32_t V = __builtin_amdgcn_perm(0u, D0, selV);
+            const uint32_t Q8 = __builtin_amdgcn_perm(0u, (uint32_t)p08, selV), Q0 = __builtin_amdgcn_perm(0u, (uint32_t)(p08 >> 32), selV);
+            const uint32_t Q12 = __builtin_amdgcn_perm(D0, Dm, selM);
+            const uint32_t Q4 = __builtin_amdgcn_perm((uint32_t)(pp >> 32), (uint32_t)pp, selP);
+            const uint32_t AD = V + C, AB = C - V;
+            // one of every antipodal pair is darker than v - t  <=>  max over the pairs of the pair minimum is; same for brighter.
+            // First tier: the pairs (0, 8) and (4, 12) alone.
+            const uint32_t lo = pkmax(pkmin(Q0, Q8), pkmin(Q4, Q12));
+            const uint32_t hi = pkmin(pkmax(Q0, Q8), pkmax(Q4, Q12));
+            const uint32_t t1 = ((AD - lo) | (hi + AB)) & 0x80008000u;
+            const unsigned long long m1 = __builtin_amdgcn_uicmp(t1, 0u, 33 /* ICMP_NE */) & actm;   // v_cmp + s_and: no lane mask round trip
+            if (m1 != 0ull) {   // wave-uniform
+              const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)q1t));
+              if ((t1 != 0u) & (rows_left > 0)) q1[r & (FC_Q1_CAP - 1)] = (uint16_t)(a0 + ec);
+              q1t += __popcll(m1);
+            }
+            a0 += RI * PB; a1 += RI * PB; rows_left -= RI;
+          }
+          const int qn = q1t - q1h;
+          if (it < n_it ? qn < WAVE : qn == 0) continue;   // wave-uniform
+          // ---- a round of tier 2 over the first min(qn, 64) queued pairs: lane = pair
+          const bool on = lane < qn;
+          uint32_t e2 = q1[(q1h + lane) & (FC_Q1_CAP - 1)];
+          e2 = on ? e2 : (uint32_t)(3 * PB + 4);   // idle lanes test a valid position and push nothing
+          q1h += qn < WAVE ? qn : WAVE;
+          const uint32_t xx = PB == 64 ? (e2 & 63u) : e2 - (uint32_t)((int)((e2 + 0.5f) * (1.0f / PB))) * (uint32_t)PB;
+          const uint32_t o2 = xx & 2u, k2 = o2 * 0x00010001u;
+          const uint32_t sV = 0x0c010c00u + k2, sX = 0x0c030c02u - k2, sM = 0x0c020c01u + k2, sP = 0x0c040c03u - k2;
+          const uint32_t b0 = tile_a + e2 - (uint32_t)(3 * PB + 4) - (xx & 3u);
+          const uint32_t b1 = b0 + 2u * o2;
+          unsigned long long p08, pc, pp, p62, p1014;
+          asm volatile(
+              "ds_read2_b32 %0, %5 offset0:1 offset1:%7\n\t"
+              "ds_read2_b32 %1, %5 offset0:%8 offset1:%9\n\t"
+              "ds_read2_b32 %2, %6 offset0:%9 offset1:%10\n\t"
+              "ds_read2_b32 %3, %6 offset0:%11 offset1:%12\n\t"
+              "ds_read2_b32 %4, %6 offset0:%13 offset1:%14\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(p08), "=&v"(pc), "=&v"(pp), "=&v"(p62), "=&v"(p1014)
+              : "v"(b0), "v"(b1), "n"(6 * PB / 4 + 1), "n"(3 * PB / 4), "n"(3 * PB / 4 + 1), "n"(3 * PB / 4 + 2),
+                "n"(PB / 4 + 1), "n"(5 * PB / 4 + 1), "n"(PB / 4), "n"(5 * PB / 4)
+              : "memory");
+          {
+            const uint32_t D0 = (uint32_t)(pc >> 32), Dm = (uint32_t)pc;
+            const uint32_t V = __builtin_amdgcn_perm(0u, D0, sV);
+            const uint32_t Q8 = __builtin_amdgcn_perm(0u, (uint32_t)p08, sV), Q0 = __builtin_amdgcn_perm(0u, (uint32_t)(p08 >> 32), sV);
+            const uint32_t Q12 = __builtin_amdgcn_perm(D0, Dm, sM);
+            const uint32_t Q4 = __builtin_amdgcn_perm((uint32_t)(pp >> 32), (uint32_t)pp, sP);
+            const uint32_t Q6 = __builtin_amdgcn_perm(0u, (uint32_t)p62, sX), Q2 = __builtin_amdgcn_perm(0u, (uint32_t)(p62 >> 32), sX);
+            const uint32_t Q10 = __builtin_amdgcn_perm(0u, (uint32_t)p1014, sX), Q14 = __builtin_amdgcn_perm(0u, (uint32_t)(p1014 >> 32), sX);
+            const uint32_t AD = V + C, AB = C - V;
+            const uint32_t lo = pkmax(pkmax(pkmin(Q0, Q8), pkmin(Q4, Q12)), pkmax(pkmin(Q2, Q10), pkmin(Q6, Q14)));
+            const uint32_t hi = pkmin(pkmin(pkmax(Q0, Q8), pkmax(Q4, Q12)), pkmin(pkmax(Q2, Q10), pkmax(Q6, Q14)));
+            const uint32_t dark = AD - lo, brt = hi + AB;
+            const uint32_t G = on ? ((dark & 0x80008000u) | ((brt >> 1) & 0x40004000u)) : 0u;
+            const bool has0 = (G & 0xC000u) != 0, has1 = (G >> 30) != 0;
+            // the list stays in row-major order (the ring is first in, first out; a lane's two pixels are neighbours): the NMS below
+            // emits straight from it
+            const unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
+            const int c0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)wcnt));
+            const int i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)c0));
+            const int i1 = i0 + (has0 ? 1 : 0);
+            if (has0) list[i0] = (uint16_t)((G & 0xC000u) | e2);
+            if (has1) list[i1] = (uint16_t)(((G >> 16) & 0xC000u) | (e2 + 1));
+            wcnt += __popcll(m0) + __popcll(m1);
+          }
+          if (wcnt > FC_LIST_CAP - 2 * WAVE) {   // wave-uniform
+            FC_T(2);
+            if (!flushed)
+              for (int i = lane; i < nbw; i += WAVE) scb[i] = 0;
+            flushed = true;
+            score_list(wcnt, true, th_cur);
+            FC_T(3);
+            wcnt = 0;
+          }
+        }
+#else
         for (int it = 0; it < n_it; it++, a0 += RI * PB, a1 += RI * PB, rows_left -= RI) {
           // inactive lanes read in-range garbage: rows < rows_max + RI
           const unsigned long long actm = __builtin_amdgcn_sicmp(rows_left, 0, 38 /* ICMP_SGT */);
@@ -784,6 +1036,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
             wcnt = 0;
           }
         }
+#endif
         FC_T(2);
         score_list(wcnt, flushed, th_cur);
         FC_T(3);
