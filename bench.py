@@ -247,6 +247,9 @@ def per_frame_latency(cfg, n_frames: int):
         rp = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "1", "--repeat", "16"], capture_output=True, text=True, timeout=600)
         rq = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "2", "--repeat", "24"], capture_output=True, text=True, timeout=600)
         rd = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "48"], capture_output=True, text=True, timeout=600)
+        # the same with orbfe_pipeline_config.output_mask: only the tracked assignments (+ the counts), only the counts copied to the host
+        rdm = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "48", "--outputs", "matches"], capture_output=True, text=True, timeout=600)
+        rdc = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "48", "--outputs", "counts"], capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         return {"error": f"stereo_kitti exited with {r.returncode}: " + (r.stderr or r.stdout)[-300:]}
     med = re.search(r"median tracking time: ([0-9.eE+-]+)", r.stdout)
@@ -259,6 +262,8 @@ def per_frame_latency(cfg, n_frames: int):
     sqb, sqp = (re.search(seq_re, rb.stdout) if rb.returncode == 0 else None), (re.search(seq_re, rp.stdout) if rp.returncode == 0 else None)
     sqq = re.search(seq_re, rq.stdout) if rq.returncode == 0 else None
     sqd = re.search(seq_re, rd.stdout) if rd.returncode == 0 else None
+    sqdm = re.search(seq_re, rdm.stdout) if rdm.returncode == 0 else None
+    sqdc = re.search(seq_re, rdc.stdout) if rdc.returncode == 0 else None
     prep = re.search(r"front end prepared in ([0-9.]+) ms", r.stdout)
     sequence = None
     if sq:
@@ -278,7 +283,11 @@ def per_frame_latency(cfg, n_frames: int):
                     "batched_pinned_resident_note": "--preload 2: the slots keep their frames after the first chunks, no host work per frame: the C++ pipeline's own rate with PCIe both ways (what e2e_frames_per_s measures from Python)",
                     "frames_per_s_batched_device_resident": float(sqd.group(3)) if sqd else None,
                     "batched_device_resident_note": "--preload 3: after the first chunks the frames stay in the slots' DEVICE input blocks (orbfe_pipeline_submit_resident): the C++ "
-                                                    "pipeline handle at its kernels' rate, results still copied to the host -- what a device-side producer of frames gets",
+                                                    "pipeline handle at its kernels' rate, every result block still copied to the host (37 MB per chunk) -- what a device-side producer of frames gets",
+                    "frames_per_s_batched_device_resident_matches": float(sqdm.group(3)) if sqdm else None,
+                    "frames_per_s_batched_device_resident_counts": float(sqdc.group(3)) if sqdc else None,
+                    "batched_device_resident_outputs_note": "--outputs matches / counts (orbfe_pipeline_config.output_mask): only the tracked assignments + counts (2.3 MB per "
+                                                            "chunk) / only the per-frame counts go to the host; everything stays readable in HBM (orbfe_pipeline_device_records)",
                     "input": "synthetic KITTI-layout sequence written as 8-bit grey PNGs (zlib level 6, filter 0), decoded by orbfe_png_read_gray"}
     return {"median_ms": round(float(med.group(1)) * 1e3, 4), "mean_ms": round(float(mean.group(1)) * 1e3, 4),
             **{k + "_ms": (round(float(m.group(1)) * 1e3, 4) if m else None) for k, m in tail.items()},
@@ -288,6 +297,67 @@ def per_frame_latency(cfg, n_frames: int):
             "median_ms_by_phase": ({"extract_x2": float(ph.group(1)), "stereo": float(ph.group(2)), "search_by_projection": float(ph.group(3))} if ph else None),
             "path": "examples/stereo_kitti.cc: C++ ORBextractor x2 on two threads + orbfe_host::ComputeStereoMatches + "
                     "ORBmatcher::SearchByProjection(cur,last), host images in, host keypoints / matches out, one pair at a time"}
+
+
+def cabi_driver(rig, steps: int, output_mask: int, slots: int = 3):
+    """The step driven through the C ABI's pipeline handle (orbfe_pipeline_*: what a C / C++ host calls; no torch in the loop): the rig's
+    frames uploaded once into the slots' device blocks, then `steps` chunks by orbfe_pipeline_submit_resident in a ring of `slots`
+    slots.  Returns the rate and a self-check: a second handle that copies every block out must reproduce, byte for byte, what the
+    torch-driven step left in the rig's buffers (which tests/test_bench_layout_gpu.py compares with the oracle)."""
+    import torch
+    from refactored_orb_slam2_amd._lib import KP_DTYPE
+    from refactored_orb_slam2_amd.pipeline import StereoPipeline
+    cfg, F, W, H = rig.cfg, rig.F, rig.W, rig.H
+
+    def make(mask):
+        p = StereoPipeline(W, H, F, cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], cfg["bf"], cfg["th"], n_features=rig.NFEAT, slots=slots,
+                           output_mask=mask)
+        for s in range(slots):
+            p.poses(s)["cx"] = np.float32(cfg["cx"]) + np.float32(SHIFT_X)
+            p.left(s)[:] = rig.hL.numpy(); p.right(s)[:] = rig.hR.numpy()
+        for s in range(slots):
+            p.submit(s, F, has_predecessor=s > 0)
+        for s in range(slots):
+            p.wait(s)
+        return p
+
+    torch.cuda.synchronize()
+    with make(output_mask) as p:
+        for k in range(slots):   # warm: every slot once from its resident images
+            p.wait(k); p.submit_resident(k, F, has_predecessor=True)
+        for s in range(slots):
+            p.wait(s)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            s = k % slots
+            p.wait(s)
+            p.submit_resident(s, F, has_predecessor=True)
+        for s in range(slots):
+            p.wait(s)
+        dt = time.perf_counter() - t0
+        n_tr = int(np.asarray(p.output(0)["n_tracked"]).sum())
+    # ---- self-check against the torch-driven step (one chunk per slot through a handle that copies everything out)
+    rig.step(); rig.barrier()
+    B = rig.B0
+    ref = {k: getattr(B, k).cpu().numpy() for k in ("nl", "nr", "n_stereo", "n_track", "kl", "dl", "ur", "depth", "assigned")}
+    ok = True
+    with make(0) as p:
+        for s in range(slots):
+            p.wait(s); p.submit_resident(s, F, has_predecessor=True)
+        for s in range(slots):
+            p.wait(s)
+            o = p.output(s)
+            cap = min(o["kps_left"].shape[1], ref["kl"].shape[1])
+            m = np.arange(cap)[None, :] < ref["nl"][:, None]
+            rk = ref["kl"].reshape(F, -1).view(KP_DTYPE).reshape(F, -1)
+            ok = ok and all(np.array_equal(np.asarray(o[a]), ref[b]) for a, b in (("n_left", "nl"), ("n_right", "nr"), ("n_stereo", "n_stereo"), ("n_tracked", "n_track")))
+            ok = ok and o["kps_left"][:, :cap][m].tobytes() == rk[:, :cap][m].tobytes() and o["desc_left"][:, :cap][m].tobytes() == ref["dl"][:, :cap][m].tobytes()
+            ok = ok and o["u_right"][:, :cap][m].tobytes() == ref["ur"][:, :cap][m].tobytes() and o["depth"][:, :cap][m].tobytes() == ref["depth"][:, :cap][m].tobytes()
+            ok = ok and o["assigned"][:, :cap][m].tobytes() == ref["assigned"][:, :cap][m].tobytes()
+    return {"frames_per_s": round(F * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "slots": slots,
+            "output_mask": output_mask, "tracked_per_frame": round(n_tr / F, 1), "equals_torch_driven_step": bool(ok),
+            "path": "orbfe_pipeline_submit_resident / orbfe_pipeline_wait in a ring of slots (ctypes; frames resident in the slots' device blocks); "
+                    "output_mask 8 = tracked assignments + counts copied to the host per chunk, 16 = counts only, 0 = every block (37 MB)"}
 
 
 def spawn_ranks(n: int) -> int:
@@ -573,6 +643,13 @@ def main():
     ap.add_argument("--blur-kind", type=int, default=0, choices=(0, 1, 2),
                     help="A/B of the level chain (orbfe_debug_blur_kernel): 0 fused level kernels (default), 1 resize chain + matrix-core blur, "
                          "2 resize chain + one LDS blur launch (rounds 1-4)")
+    ap.add_argument("--driver", choices=("torch", "cabi"), default="torch",
+                    help="what drives the timed step: torch streams / events around the C ABI's device entry points (default), or the C ABI's "
+                         "own pipeline handle (orbfe_pipeline_submit_resident: no torch in the loop, what a C++ host runs).  At N = 1 the line "
+                         "carries both (config.cabi_driver); with `cabi`, `value` is the handle's rate")
+    ap.add_argument("--cabi-outputs", type=int, default=8, help="orbfe_pipeline_config.output_mask of the C-ABI driver (8: tracked assignments + counts, "
+                                                                 "16: counts only, 0: every block)")
+    ap.add_argument("--cabi-steps", type=int, default=120, help="chunks timed through the C-ABI driver (0 = skip)")
     ap.add_argument("--lr-streams", type=int, default=2, choices=(1, 2),
                     help="2 (default): left / right extractor on two HIP streams, as the reference runs them on two threads (Frame.cc:87-90): "
                          "their launches overlap and fill each other's tails; 1: one stream, every kernel alone on the chip (the per-stage times "
@@ -749,6 +826,15 @@ def main():
     #      is identical across the sets and identical to a one-stream, one-set step (the layout the stage parity tests cover);
     #      tests/test_bench_layout_gpu.py compares the same object's outputs with the oracle
     self_check = rig.self_check()
+    # ---- the same step driven through the C ABI's pipeline handle (N = 1, STEREO + projection only: what the handle implements)
+    cabi = None
+    if world == 1 and STEREO and cfg["match"] == "projection" and (args.cabi_steps > 0 or args.driver == "cabi"):
+        try:
+            cabi = cabi_driver(rig, args.steps if args.driver == "cabi" else args.cabi_steps, args.cabi_outputs, slots=max(n_sets, 2))
+        except Exception as ex:
+            if args.driver == "cabi":
+                raise
+            cabi = {"error": str(ex)[:300]}
 
     # ---- PCIe-inclusive rate (N = 1): pinned host images in, host keypoints / descriptors / match results out, two buffer
     #      sets: the H2D copy of step i+1 and the D2H copy of step i-1 run beside the kernels of step i
@@ -925,10 +1011,14 @@ def main():
         except Exception:
             pass
         value = world * F * args.steps / dt
+        ms_step = dt / args.steps * 1e3
+        if args.driver == "cabi":   # the C ABI's handle is the measured step; the torch-driven figure stays in config.torch_driver
+            torch_driver = {"frames_per_s": round(value, 2), "ms_per_step": round(ms_step, 4)}
+            value, ms_step = cabi["frames_per_s"], cabi["ms_per_step"]
         out = {
             "metric": "frames/s (extract+match) at KITTI 1241×376, 2000 feat; 1/2/4/8 GPU + CPU ref",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "input_layout": f"u8 images resident in HBM, rows {PITCH} bytes apart (16-byte aligned: level 0 of the pyramid in place)",
             "config": {"workload": cfg["label"], "name": args.config, "frames_per_gpu_per_step": F,
@@ -957,6 +1047,11 @@ def main():
                                                   "intervals / launches; achieved = their algorithmic bytes / that union"},
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
+        out["config"]["driver"] = args.driver
+        if cabi is not None:
+            out["config"]["cabi_driver"] = cabi
+        if args.driver == "cabi":
+            out["config"]["torch_driver"] = torch_driver
         if gatherer is not None:
             out["config"]["gather"] = dict(gather_traffic(B0.nl, B0.kl, B0.dl, world, args.gather), impl=args.gather_impl if backend == "nccl" else "torch",
                                            own_slot_equal_rank0=gather_check,
@@ -981,6 +1076,8 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
         print(json.dumps(out), flush=True)
+    if cabi is not None and cabi.get("equals_torch_driven_step") is False:
+        raise SystemExit(f"rank {rank}: the C-ABI pipeline handle's results differ from the torch-driven step's")
     if not (self_check["sets_equal"] and self_check["equals_one_stream"]):
         raise SystemExit(f"rank {rank}: the timed layout's outputs differ between the handle sets or from the one-stream step: {self_check}")
     if world > 1:

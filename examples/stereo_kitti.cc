@@ -26,7 +26,7 @@
 //   usage: stereo_kitti <sequence_dir> [--features 2000] [--max-frames N] [--dump file.bin] [--bf 386.1448] [--fx 718.856]
 //                       [--fy 718.856] [--cx 607.1928] [--cy 185.2157] [--th 7] [--decode-threads 8] [--prefetch 16]
 //                       [--prepare 1] [--gpus 1] [--gather none|root|all] [--gather-dump file.bin]
-//                       [--batch F] [--slots 3] [--preload 0|1|2|3] [--repeat R]
+//                       [--batch F] [--slots 3] [--preload 0|1|2|3] [--repeat R] [--outputs all|matches|counts]
 //
 // --batch F is the batched pipeline from a C++ host (include/orbfe.h: orbfe_pipeline_*): chunks of F pairs go through the device
 // batch API -- decode pool -> the pipeline's pinned pitched input -> H2D -> 2 x ORBextractor -> ComputeStereoMatches ->
@@ -167,7 +167,7 @@ static double seconds_since(std::chrono::steady_clock::time_point a) {
 
 struct Options {
   int nFeatures = 2000, maxFrames = 0, decodeThreads = 8, prefetch = 16, prepare = 1, gpus = 1;
-  int batch = 0, slots = 3, preload = 0, repeat = 1;
+  int batch = 0, slots = 3, preload = 0, repeat = 1, outputs = 0;   // outputs: orbfe_pipeline_config.output_mask
   float bf = 386.1448f, fx = 718.856f, fy = 718.856f, cx = 607.1928f, cy = 185.2157f, th = 7.0f;   // KITTI00-02.yaml
   std::string dumpPath, gather = "default", gatherDump;
 };
@@ -490,6 +490,7 @@ static void RunShardBatched(const Options& o, const std::vector<std::string>& vs
   cfg.extractor.ini_th_fast = 20; cfg.extractor.min_th_fast = 7;
   cfg.width = w0; cfg.height = h0; cfg.batch = F; cfg.slots = S;
   cfg.fx = o.fx; cfg.fy = o.fy; cfg.cx = o.cx; cfg.cy = o.cy; cfg.bf = o.bf; cfg.th = o.th; cfg.check_orientation = 1;
+  cfg.output_mask = o.outputs;
   orbfe_pipeline* pl = nullptr;
   const auto tp = std::chrono::steady_clock::now();
   if (orbfe_pipeline_create(&cfg, sh.device, &pl) != ORBFE_OK) {
@@ -650,11 +651,20 @@ int main(int argc, char** argv) {
     else if (k == "--slots") o.slots = std::min(4, std::max(1, atoi(v)));
     else if (k == "--preload") o.preload = atoi(v);
     else if (k == "--repeat") o.repeat = std::max(1, atoi(v));
+    else if (k == "--outputs") {   // what a chunk copies back to the host besides the per-frame counts
+      const std::string w = v;
+      if (w == "all") o.outputs = 0;
+      else if (w == "matches") o.outputs = ORBFE_PIPE_OUT_ASSIGNED;
+      else if (w == "counts") o.outputs = ORBFE_PIPE_OUT_COUNTS;
+      else { fprintf(stderr, "--outputs all|matches|counts\n"); return 64; }
+    }
     else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 64; }
   }
   if (o.gather == "default") o.gather = o.gpus > 1 ? "root" : "none";
+  if (o.outputs != 0 && !o.dumpPath.empty()) { fprintf(stderr, "--dump needs --outputs all\n"); return 64; }
   if (o.preload >= 2 && (!o.dumpPath.empty() || !o.gatherDump.empty())) { fprintf(stderr, "--preload 2 / 3 re-submit resident frames: no --dump / --gather-dump\n"); return 64; }
   if (o.gather != "none" && o.gather != "root" && o.gather != "all") { fprintf(stderr, "--gather none|root|all\n"); return 64; }
+  if (o.gather != "none" && o.outputs != 0) { fprintf(stderr, "the gather's self-check compares with the host records: --outputs all\n"); return 64; }
   std::vector<std::string> vstrImageLeft, vstrImageRight;
   std::vector<double> vTimestamps;
   if (!LoadImages(argv[1], vstrImageLeft, vstrImageRight, vTimestamps)) {

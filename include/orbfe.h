@@ -603,7 +603,16 @@ typedef struct orbfe_pipeline_config {
   float fx, fy, cx, cy, bf;        /* Camera.fx .. Camera.bf of the settings file (bf = baseline x fx) */
   float th;                        /* SearchByProjection window factor (7 for stereo, L/src/Tracking.cc:793-798) */
   int32_t check_orientation;       /* ORBmatcher(0.9, true) */
+  int32_t output_mask;             /* which blocks of a chunk's results are copied to the slot's pinned host block: 0 = all of them, else
+                                      an OR of ORBFE_PIPE_OUT_*; the per-frame counts (n_left, n_right, n_stereo, n_tracked) always are.
+                                      A consumer that reads only the matches pays for 4 bytes per keypoint row instead of 72 (37 MB per
+                                      256-frame KITTI chunk otherwise); everything stays available in HBM (orbfe_pipeline_device_records) */
 } orbfe_pipeline_config;
+#define ORBFE_PIPE_OUT_KEYPOINTS 1
+#define ORBFE_PIPE_OUT_DESCRIPTORS 2
+#define ORBFE_PIPE_OUT_STEREO 4        /* u_right, depth */
+#define ORBFE_PIPE_OUT_ASSIGNED 8
+#define ORBFE_PIPE_OUT_COUNTS 16       /* nothing but the counts */
 typedef struct orbfe_pipeline_input_view {
   uint8_t* left; uint8_t* right;   /* frame f at + f * image_bytes, rows `pitch` bytes apart (pitch = width rounded up to 64) */
   int32_t pitch; size_t image_bytes;
@@ -639,6 +648,9 @@ int orbfe_pipeline_submit_resident(orbfe_pipeline* p, int slot, int n_frames, in
 int orbfe_pipeline_device_records(orbfe_pipeline* p, int slot, const int32_t** d_n, const orbfe_keypoint** d_kps,
                                   const uint8_t** d_desc, int* cap);
 void* orbfe_pipeline_stream(orbfe_pipeline* p);   /* the compute stream (a hipStream_t) */
+/* A/B knob of tools/pipeline_rate.py: which stream -> priority level / creation order layout the NEXT orbfe_pipeline_create uses
+ * (0 .. 4, see csrc/pipeline.cpp:pipeline_build; the default is the fastest measured).  Results do not depend on it. */
+int orbfe_debug_pipeline_streams(int layout);
 /* orbfe_gather_records of slot s's left records (`batch` frames of `cap` rows each, every rank alike) on a stream of the
  * pipeline's own, behind the slot's kernels: the collective overlaps the next chunk's kernels and the slot's next submit waits
  * for it.  Every rank calls it once per chunk, in chunk order (a rank whose shard has ended submits empty chunks).  The *_all

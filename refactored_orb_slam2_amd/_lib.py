@@ -104,7 +104,7 @@ EXPORTS = [
     "orbfe_bow_transform_device", "orbfe_compute_bow", "orbfe_png_info", "orbfe_png_info2", "orbfe_png_read_gray", "orbfe_png_read_gray2", "orbfe_png_read_gray16",
     "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_input", "orbfe_pipeline_submit", "orbfe_pipeline_wait",
     "orbfe_pipeline_output", "orbfe_pipeline_device_records", "orbfe_pipeline_stream", "orbfe_pipeline_gather", "orbfe_pipeline_gather_wait",
-    "orbfe_pipeline_device_input", "orbfe_pipeline_submit_resident",
+    "orbfe_pipeline_device_input", "orbfe_pipeline_submit_resident", "orbfe_debug_pipeline_streams",
 ]
 
 

@@ -45,15 +45,17 @@ struct OutLayout {
   void build(int F, int cap) {
     size_t o = 0;
     auto take = [&o](size_t b) { const size_t at = o; o += up256(b); return at; };
+    // ordered so that what a consumer typically asks for (orbfe_pipeline_config.output_mask) is ONE contiguous copy: the counts, then the
+    // tracked assignments, then the stereo results, then the keypoint records and the descriptors
     n_left = take(sizeof(int32_t) * F);
     n_right = take(sizeof(int32_t) * F);
     n_stereo = take(sizeof(int32_t) * F);
     n_tracked = take(sizeof(int32_t) * F);
-    kps = take(sizeof(orbfe_keypoint) * (size_t)F * cap);
-    desc = take((size_t)32 * F * cap);
+    assigned = take(sizeof(int32_t) * (size_t)F * cap);
     u_right = take(sizeof(float) * (size_t)F * cap);
     depth = take(sizeof(float) * (size_t)F * cap);
-    assigned = take(sizeof(int32_t) * (size_t)F * cap);
+    kps = take(sizeof(orbfe_keypoint) * (size_t)F * cap);
+    desc = take((size_t)32 * F * cap);
     bytes = o;
   }
 };
@@ -79,6 +81,15 @@ struct Slot {
   int frames = 0;
 };
 }  // namespace
+
+// which stream -> priority / creation-order layout the next orbfe_pipeline_create uses (orbfe_debug_pipeline_streams: the A/B knob of
+// tools/pipeline_rate.py; the table in pipeline_build says what each measured)
+static int g_stream_layout = 6;
+extern "C" int orbfe_debug_pipeline_streams(int layout) {
+  if (layout < 0 || layout > 7) return ORBFE_ERR_INVALID;
+  g_stream_layout = layout;
+  return ORBFE_OK;
+}
 
 struct orbfe_pipeline {
   orbfe_pipeline_config cfg{};
@@ -139,20 +150,91 @@ static int pipeline_build(orbfe_pipeline* p) {
   p->in_poses = p->in_cams + up256(sizeof(orbfe_unproject_cam) * F);
   p->in_bytes = p->in_poses + up256(sizeof(orbfe_track_pose) * F);
   p->lay.build(F, cap);
-  // Stream -> hardware queue: HIP maps streams onto a handful of hardware queues per priority level (three levels: 1, 0, -1) in
-  // creation order, and streams that share a queue run one after the other.  Measured on this handle (tools/pipeline_rate.py, 256-frame
-  // chunks, upload / resident frames/s): copy streams at -1 and compute streams at 1: 55.0 k / 80.2 k (round 5's first layout; with one
-  // compute stream the H2D copy of chunk k + 1 had started only when chunk k's kernels were done: 33 k); everything at 0: 33.7 k /
-  // 75.9 k; compute at 0, copies at -1: 37.4 k / 67.8 k; ALL SIX at -1 with the copy streams created first: 56.0 k / 89.0 k -- the
-  // layout below; the same with the compute streams created first: 56.2 k / 75.5 k.  (GPU_MAX_HW_QUEUES = 8 instead of 4: 83 k.)
+  // Stream -> hardware queue: HIP maps streams onto a handful of hardware queues per priority level (three levels) in creation order,
+  // and streams that share a queue run one after the other.  Measured on this handle (tools/pipeline_rate.py, 256-frame KITTI chunks,
+  // three slots; frames/s with the images uploaded per chunk | resident in HBM with every block copied out | resident, assignments +
+  // counts copied out | resident, counts only) -- round 6, profiles/r06_pipeline.md:
+  //   0  all six at the highest priority, copy streams created first (round 5)      54.6 k | 87.7 k |    -   |  94.3 k
+  //   1  compute highest, copies / gather middle                                    37.3 k | 71.1 k |    -   |  90.4 k
+  //   2  compute highest, copies / gather lowest                                    56.4 k | 90.5 k | 97.7 k | 104.5 k
+  //   3  compute middle (torch's level), copies highest                             34.0 k | 65.2 k |    -   |  83.8 k
+  //   4  all at the middle priority, compute streams first                          34.4 k | 81.9 k |    -   |  94.4 k
+  //   5  compute highest, copy out middle, copy in / gather lowest                  56.3 k | 89.2 k | 98.3 k | 104.6 k
+  //   6  compute highest + copy out as the fourth stream of that level, rest lowest 55.9 k | 89.5 k | 99.7 k | 105.1 k   <- default
+  //   7  compute middle, copies lowest                                              35.7 k | 87.5 k | 91.5 k |  97.2 k
+  // (round 5 also: GPU_MAX_HW_QUEUES = 8 with layout 0: 83 k.)  What matters: the three compute streams alone on their priority
+  // level's queues; a copy stream that lands on a compute stream's queue delays that eye's kernels by the copy (layout 0: the 37 MB
+  // copy-out shared the right extractor's queue).  The torch-driven step of bench.py (three streams, nothing else) does 105-107 k.
   int prio_low = 0, prio_high = 0;
   PCHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
-  PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
+  const int prio_mid = (prio_low + prio_high) / 2;
+  switch (g_stream_layout) {
+    default:
+    case 0:   // round 5: all six at the highest priority, the copy streams created first
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
+      break;
+    case 1:   // the three compute streams at the highest priority (a level of their own), the copy / gather streams at the middle one
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_mid));
+      break;
+    case 2:   // the same with the copy / gather streams at the lowest priority
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_low));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_low));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_low));
+      break;
+    case 3:   // compute streams at the middle priority (what torch's streams have), copies at the highest
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_high));
+      break;
+    case 5:   // compute at the highest priority, copy out at the middle one, copy in / gather at the lowest
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_low));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_low));
+      break;
+    case 6:   // compute at the highest priority and copy out as the FOURTH stream of that level, copy in / gather at the lowest
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_high));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_low));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_low));
+      break;
+    case 7:   // compute at the middle priority, every copy at the lowest
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_low));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_low));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_low));
+      break;
+    case 4:   // all at the middle priority, compute streams first
+      PCHK(hipStreamCreateWithPriority(&p->s_l, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_r, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_mid));
+      PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_mid));
+      break;
+  }
   PCHK(hipMalloc((void**)&p->d_pts, sizeof(orbfe_last_point) * (size_t)(F + 1) * cap));
   PCHK(hipMalloc((void**)&p->d_npts, sizeof(int32_t) * (F + 1)));
   PCHK(hipMalloc((void**)&p->d_q, sizeof(orbfe_query) * (size_t)F * cap));
@@ -237,7 +319,7 @@ extern "C" int orbfe_pipeline_create(const orbfe_pipeline_config* cfg, int devic
   if (!cfg || !out) return ORBFE_ERR_INVALID;
   *out = nullptr;
   if (cfg->width < 1 || cfg->height < 1 || cfg->batch < 1 || cfg->batch > 4096 || cfg->slots < 1 || cfg->slots > 4 ||
-      !(cfg->fx > 0.0f) || !(cfg->fy > 0.0f)) {
+      !(cfg->fx > 0.0f) || !(cfg->fy > 0.0f) || cfg->output_mask < 0 || cfg->output_mask > 31) {
     orbfe_set_error("invalid pipeline configuration");
     return ORBFE_ERR_INVALID;
   }
@@ -391,9 +473,24 @@ static int submit_chunk(orbfe_pipeline* p, int slot, int n, int has_predecessor,
     PCHK(hipMemcpyAsync(p->d_npts, p->d_npts + n, sizeof(int32_t), hipMemcpyDeviceToDevice, cs));
   }
   PCHK(hipEventRecord(s.ev_done, cs));
-  // ---- copy out
+  // ---- copy out: the whole block in one copy, or the blocks the configuration asks for (the counts always: they lead the block)
   PCHK(hipStreamWaitEvent(p->s_out, s.ev_done, 0));
-  PCHK(hipMemcpyAsync(s.h_out, s.d_out, L.bytes, hipMemcpyDeviceToHost, p->s_out));
+  const int om = c.output_mask;
+  if (om == 0) {
+    PCHK(hipMemcpyAsync(s.h_out, s.d_out, L.bytes, hipMemcpyDeviceToHost, p->s_out));
+  } else {
+    // block boundaries in layout order: counts | assigned | u_right, depth | keypoints | descriptors; adjacent wanted blocks go in one copy
+    const size_t edge[6] = {0, L.assigned, L.u_right, L.kps, L.desc, L.bytes};
+    const bool want[5] = {true, (om & ORBFE_PIPE_OUT_ASSIGNED) != 0, (om & ORBFE_PIPE_OUT_STEREO) != 0, (om & ORBFE_PIPE_OUT_KEYPOINTS) != 0,
+                          (om & ORBFE_PIPE_OUT_DESCRIPTORS) != 0};
+    for (int b = 0; b < 5;) {
+      if (!want[b]) { b++; continue; }
+      int e = b;
+      while (e + 1 < 5 && want[e + 1]) e++;
+      PCHK(hipMemcpyAsync(s.h_out + edge[b], s.d_out + edge[b], edge[e + 1] - edge[b], hipMemcpyDeviceToHost, p->s_out));
+      b = e + 1;
+    }
+  }
   PCHK(hipEventRecord(s.ev_out, p->s_out));
   return ORBFE_OK;
 }

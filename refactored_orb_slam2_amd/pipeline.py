@@ -17,7 +17,10 @@ from . import _lib
 class PipelineConfig(C.Structure):
     _fields_ = [("extractor", _lib.Params), ("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32), ("slots", C.c_int32),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("th", C.c_float),
-                ("check_orientation", C.c_int32)]
+                ("check_orientation", C.c_int32), ("output_mask", C.c_int32)]
+
+
+OUT_KEYPOINTS, OUT_DESCRIPTORS, OUT_STEREO, OUT_ASSIGNED, OUT_COUNTS = 1, 2, 4, 8, 16   # ORBFE_PIPE_OUT_*
 
 
 class _InputView(C.Structure):
@@ -41,7 +44,7 @@ class StereoPipeline:
 
     def __init__(self, width: int, height: int, batch: int, fx: float, fy: float, cx: float, cy: float, bf: float, th: float = 7.0,
                  n_features: int = 2000, scale_factor: float = 1.2, n_levels: int = 8, ini_th: int = 20, min_th: int = 7, slots: int = 2,
-                 check_orientation: bool = True, device: int = -1):
+                 check_orientation: bool = True, device: int = -1, output_mask: int = 0):
         self._L = _lib.lib()
         self._L.orbfe_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_int, C.POINTER(C.c_void_p)]
         self._L.orbfe_pipeline_destroy.argtypes = [C.c_void_p]
@@ -52,7 +55,7 @@ class StereoPipeline:
         self._L.orbfe_pipeline_submit_resident.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         self._L.orbfe_pipeline_device_input.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
         self.cfg = PipelineConfig(_lib.Params(n_features, scale_factor, n_levels, ini_th, min_th), width, height, batch, slots,
-                                  fx, fy, cx, cy, bf, th, int(check_orientation))
+                                  fx, fy, cx, cy, bf, th, int(check_orientation), int(output_mask))
         self._h = C.c_void_p(None)
         _lib.check(self._L.orbfe_pipeline_create(C.byref(self.cfg), device, C.byref(self._h)), "orbfe_pipeline_create")
         self.batch, self.slots, self.width, self.height = batch, slots, width, height

@@ -204,3 +204,32 @@ def test_pipeline_handle_at_batch_256_three_slots_equals_the_step(rig, oracle):
             assert g["depth"][f, :n].tobytes() == np.asarray(o["depth"], np.float32).tobytes()
             assert int(g["n_tracked"][f]) == o["nm"]
             np.testing.assert_array_equal(g["assigned"][f, :n], o["assigned"])
+
+
+def test_pipeline_output_mask_copies_what_was_asked_for(rig):
+    """orbfe_pipeline_config.output_mask: a handle that copies only the tracked assignments (+ the counts, always) delivers those
+    byte-equal to the full handle's, leaves the other host blocks untouched, and keeps everything readable in HBM."""
+    from refactored_orb_slam2_amd.pipeline import OUT_ASSIGNED, OUT_COUNTS, StereoPipeline
+    import bench
+    cfg, W, H = rig.cfg, rig.W, rig.H
+    F = 16
+    outs = {}
+    for mask in (0, OUT_ASSIGNED, OUT_COUNTS):
+        with StereoPipeline(W, H, F, cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], cfg["bf"], cfg["th"], n_features=rig.NFEAT, slots=2,
+                            output_mask=mask) as p:
+            for s in range(2):
+                p.poses(s)["cx"] = np.float32(cfg["cx"]) + np.float32(bench.SHIFT_X)
+                p.left(s)[:] = rig.hL.numpy()[s * F:(s + 1) * F]; p.right(s)[:] = rig.hR.numpy()[s * F:(s + 1) * F]
+            p.submit(0, F, has_predecessor=False); p.submit(1, F, has_predecessor=True)
+            p.wait(0); p.wait(1)
+            outs[mask] = [{k: np.array(v, copy=True) for k, v in p.output(s).items() if k != "cap"} for s in range(2)]
+    for s in range(2):
+        full, am, cm = outs[0][s], outs[OUT_ASSIGNED][s], outs[OUT_COUNTS][s]
+        assert int(full["n_tracked"][1:].min()) > 500
+        for key in ("n_left", "n_right", "n_stereo", "n_tracked"):
+            np.testing.assert_array_equal(am[key], full[key]); np.testing.assert_array_equal(cm[key], full[key])
+        n = full["n_left"]
+        m = np.arange(full["assigned"].shape[1])[None, :] < n[:, None]
+        np.testing.assert_array_equal(am["assigned"][m], full["assigned"][m])
+        # blocks that were not asked for stay as the handle's warm-up left them (zeroed at creation): nothing of this chunk arrived
+        assert not am["desc_left"][m].any() and not am["u_right"][m].any() and not cm["assigned"][m].any() and not cm["depth"][m].any()

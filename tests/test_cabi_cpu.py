@@ -88,10 +88,10 @@ def test_pipeline_handle_validates_and_has_no_cpu_fallback(L):
     """orbfe_pipeline_* (the batched stereo step behind one handle, for hosts without the HIP runtime): the config struct has the
     header's layout, a bad configuration is refused before anything touches a device, and without a device creation is an error."""
     from refactored_orb_slam2_amd.pipeline import PipelineConfig, StereoPipeline
-    assert C.sizeof(PipelineConfig) == 64
+    assert C.sizeof(PipelineConfig) == 68
     L.orbfe_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_int, C.POINTER(C.c_void_p)]
     h = C.c_void_p(None)
-    good = PipelineConfig(_lib.Params(2000, 1.2, 8, 20, 7), 1241, 376, 8, 2, 718.856, 718.856, 607.19, 185.21, 386.14, 7.0, 1)
+    good = PipelineConfig(_lib.Params(2000, 1.2, 8, 20, 7), 1241, 376, 8, 2, 718.856, 718.856, 607.19, 185.21, 386.14, 7.0, 1, 0)
     assert L.orbfe_pipeline_create(None, -1, C.byref(h)) == _lib.ERR_INVALID
     assert L.orbfe_pipeline_create(C.byref(good), -1, None) == _lib.ERR_INVALID
     for field, value in (("batch", 0), ("slots", 0), ("slots", 5), ("width", 0), ("fx", 0.0)):
