@@ -634,10 +634,12 @@ def main():
                                                                 "liborbfe) in both modes, compare with the local records, report on stderr (default off: "
                                                                 "the path has never run with peers and must not be able to cost the line)")
     ap.add_argument("--content-steps", type=int, default=30, help="steps per image content of the content-sensitivity key (0 = skip)")
-    ap.add_argument("--gather-impl", choices=("torch", "cabi"), default="torch",
-                    help="which implementation of the record gather is the timed collective: torch.distributed (sharding.AsyncGather, the default until "
-                         "the other one has run with peers once) or the C ABI's (orbfe_gather_*: RCCL called by liborbfe, what a C++ host uses); "
-                         "with cabi the gather also runs at N = 1 (a one-rank communicator: the code path on a one-GPU box)")
+    ap.add_argument("--gather-impl", choices=("auto", "torch", "cabi"), default="auto",
+                    help="which implementation of the record gather is the timed collective: `cabi` = the C ABI's (orbfe_gather_*: RCCL called by "
+                         "liborbfe, what a C++ host of the batched mode uses; with it the gather also runs at N = 1, a one-rank communicator), "
+                         "`torch` = torch.distributed (sharding.AsyncGather).  `auto` (default): at N > 1 on RCCL the C ABI's -- the product's own "
+                         "collective --, falling back to torch.distributed if its communicator cannot be created (the path has not run with "
+                         "peers on this pool: DESIGN 6; the line says which one ran); nothing at N = 1")
     ap.add_argument("--gather", choices=("all", "root"), default="all",
                     help="N > 1: all_gather of the per-frame records on every rank, or gather to rank 0 only (SURVEY.md 8(e))")
     ap.add_argument("--blur-kind", type=int, default=0, choices=(0, 1, 2),
@@ -703,11 +705,26 @@ def main():
     two_sets, n_sets, more_B, B0, Buffers = rig.two_sets, rig.n_sets, rig.more_B, rig.B0, rig.Buffers
     sM, sL, sR, lr = rig.sM, rig.sL, rig.sR, rig.lr
     _step, step, barrier = rig._step, rig.step, rig.barrier
-    gatherer = None
-    if args.gather_impl == "cabi" and backend == "nccl":
-        rig.gatherer = gatherer = CabiAsyncGather(B0.nl, B0.kl, B0.dl, rank, world, local, mode=args.gather)
-    elif world > 1:
+    gatherer, gather_impl, gather_fallback = None, None, None
+    want_cabi = backend == "nccl" and (args.gather_impl == "cabi" or (args.gather_impl == "auto" and world > 1))
+    if want_cabi:
+        try:
+            rig.gatherer = gatherer = CabiAsyncGather(B0.nl, B0.kl, B0.dl, rank, world, local, mode=args.gather)
+            gather_impl = "cabi"
+        except Exception as ex:   # every rank takes part in the unique-id broadcast first, so a refusal is seen by all of them alike
+            if args.gather_impl == "cabi":
+                raise
+            gather_fallback = str(ex)[:200]
+        if world > 1 and args.gather_impl == "auto":
+            # all ranks agree on the implementation: one rank without a communicator sends every rank to torch.distributed
+            flag = torch.tensor([1 if gatherer is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and gatherer is not None:
+                gatherer.close(); rig.gatherer = gatherer = None; gather_impl = None
+                gather_fallback = gather_fallback or "another rank could not create its communicator"
+    if gatherer is None and world > 1:
         rig.gatherer = gatherer = AsyncGather(B0.nl, B0.kl, B0.dl, mode=args.gather)
+        gather_impl = "torch"
 
     for _ in range(max(args.warmup, 1) if args.warmup >= 0 else 0):
         step()
@@ -996,7 +1013,7 @@ def main():
         # HBM-side traffic of the dominant kernel: FETCH_SIZE (x2 for 16-byte-per-lane streams on gfx950) + WRITE_SIZE from the
         # committed PMC pass of THIS kernel build (profiles/rNN_pmc_dominant.json, latest round), scaled to this launch's image count;
         # null when the pass covers another kernel or configuration
-        traffic, traffic_src = None, None
+        traffic, traffic_src, issue = None, None, None
         try:
             import glob
             pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_dominant.json")))[-1]   # the latest round's pass
@@ -1008,6 +1025,14 @@ def main():
                     kb = pmc["fetch_kb"] * pmc.get("fetch_correction", 1.0) + pmc["write_kb"]
                 traffic = int(kb * 1024 * F / pmc["images_per_launch"])
                 traffic_src = f"committed rocprofv3 --pmc pass ({pmc['kernel']}, {os.path.basename(pmc_path)}), not measured in this run"
+                if pmc.get("issue"):
+                    # what the kernel is bound by when it is not HBM (profiles/r06_fast.md): the instruction stream of its waves.  Lane-
+                    # instructions per pixel = 64 lanes x vector instructions per wave x waves / the pixels one launch tests
+                    issue = dict(pmc["issue"])
+                    if dom == "fast":
+                        issue["lane_instructions_per_pixel"] = round(64.0 * issue["valu_per_wave"] * issue["waves_per_launch"] /
+                                                                     max(sumP * pmc["images_per_launch"], 1), 2)
+                    issue["source"] = traffic_src
         except Exception:
             pass
         value = world * F * args.steps / dt
@@ -1026,12 +1051,12 @@ def main():
                                        "extraction of step k + 1 runs beside the matching half of step k (third stream)") if two_sets else
                                       (f"one set of handles; extractors on {args.lr_streams if STEREO else 1} stream(s), a step starts when the one before it has ended"),
                        "images_per_step": n_img * world, "parallelism": f"frame-shard x{world}",
-                       "collective": ((f"{'RCCL through the C ABI (orbfe_gather_records)' if (args.gather_impl == 'cabi' and backend == 'nccl') else backend} "
+                       "collective": ((f"{'RCCL through the C ABI (orbfe_gather_records)' if gather_impl == 'cabi' else backend} "
                                        f"{'all_gather' if args.gather == 'all' else 'gather to rank 0'} of padded per-frame records, world size {world}") if gatherer is not None else "none"),
                        "keypoints_per_image": round(n_kp / n_img, 1), "stereo_matches_per_frame": round(n_st / F, 1),
                        "matches_per_frame": round(n_tr / F, 1), "timed_region_s": round(dt, 3), "self_check": self_check},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved_alone, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved_alone / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "GB/s", "frac": round(achieved_alone / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "issue": issue,
                          "algorithmic_bytes_per_launch": int(alg[dom] * F), "avg_launch_ms": round(per_launch_ms[dom], 4),
                          "measured": (f"HIP events on the launch stream around {dom_alone_launches} launches of the kernel in a one-stream pass of this run (every "
                                       "kernel alone on the chip: the figure rocprofv3 --stats and the serialised --pmc passes can be compared with -- "
@@ -1053,7 +1078,7 @@ def main():
         if args.driver == "cabi":
             out["config"]["torch_driver"] = torch_driver
         if gatherer is not None:
-            out["config"]["gather"] = dict(gather_traffic(B0.nl, B0.kl, B0.dl, world, args.gather), impl=args.gather_impl if backend == "nccl" else "torch",
+            out["config"]["gather"] = dict(gather_traffic(B0.nl, B0.kl, B0.dl, world, args.gather), impl=gather_impl, impl_fallback_reason=gather_fallback,
                                            own_slot_equal_rank0=gather_check,
                                            standalone_ms_rank0=(round(coll_ms, 4) if coll_ms is not None else None),
                                            note="per step, overlapped with the next step's kernels; standalone_ms = the same collective alone, HIP events on rank 0"

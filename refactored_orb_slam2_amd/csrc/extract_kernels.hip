@@ -723,11 +723,11 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       int wcnt = 0;
       // ---- A1
       if (th > 0 && tw > 0) {
-        const int ppr = (tw + 1) >> 1;                 // <= 30
-        const int RI = WAVE / ppr;                     // rows per iteration, >= 2
-        const int rl = (int)((lane + 0.5f) * (1.0f / (float)ppr)), pl = lane - rl * ppr;
+        const int ppr = cd.ppr;                        // (tw + 1) >> 1, <= 30
+        const int RI = cd.ri;                          // WAVE / ppr: rows per iteration, >= 2
+        const int rl = (int)((lane + 0.5f) * cd.inv_ppr), pl = lane - rl * ppr;
         const bool lane_ok = rl < RI;
-        const int n_it = (th + RI - 1) / RI;
+        const int n_it = cd.n_it;                      // (th + RI - 1) / RI
         const int x = c_lo + 2 * pl;                   // even: the pair (x, x + 1) starts at byte 0 or 2 of its dword
         const bool odd2 = (x & 2) != 0;
         const uint32_t selV = odd2 ? 0x0c030c02u : 0x0c010c00u;    // (x, x+1) and (x, x+1) of rows +-3

@@ -55,6 +55,10 @@ struct CellDesc {
   int16_t shift_x, shift_y;  // j*wCell, i*hCell added to FAST's local coordinates
   int16_t slot_cap;    // capacity of this cell's output slot
   uint32_t slot_off;   // offset (entries) of this cell's slot inside one image's slot block
+  // the quick-test loop's lane layout, computed once at plan time (the kernel spent two scalar divisions and a reciprocal per cell on
+  // them): pixel pairs per tested row, rows per iteration of 64 lanes, iterations; 1 / ppr
+  int16_t ppr, ri, n_it, pad;
+  float inv_ppr;
 };
 
 // A run of horizontally adjacent FAST cells of one cell row: one wave of fast_cells_kernel walks them one after the other

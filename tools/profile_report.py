@@ -26,6 +26,9 @@ ALG_KB = {  # algorithmic KB per 256-image launch at KITTI geometry (DESIGN.md s
     "blur_level_kernel<true>": ((1444097 - 36330) + (1444097 - 36330) + (1444097 - 466616)) * 256 / 1024 / 7,
     "blur_level_kernel<false>": 2 * 36330 * 256 / 1024,
     "orient_describe": 2000 * (749 + 512 + 60) * 256 / 1024,
+    # stereo association per pair: both eyes' keypoint records + descriptors (2 x 2000 x 60 B), per matched left keypoint (~1 850) the 11 x 11
+    # left SAD window and the 11 x 21 right strip it slides over, 8 B of result per left keypoint (an estimate: windows overlap)
+    "stereo_match": (2 * 2000 * 60 + 1850 * (121 + 231) + 2000 * 8) * 256 / 1024,
 }
 
 
@@ -154,7 +157,25 @@ def main(tag_dir, out_prefix, config="kitti_stereo"):
     st = next((v for a, v in stage.items() if dom.startswith(a)), dom)
     wide = any(dom.startswith(w) for w in WIDE)
     rk, wk = fabric_kb(cs[dom])
-    json.dump({"stage": st, "config": config, "kernel": dom, "images_per_launch": 256, "fetch_kb": cs[dom].get("FETCH_SIZE", 0),
+    cd = cs[dom]
+    wv, wcyc = max(cd.get("SQ_WAVES", 0), 1), max(cd.get("SQ_WAVE_CYCLES", 0), 1)
+    clk = cd.get("GRBM_GUI_ACTIVE", 0) / 8
+    issue = {"waves_per_launch": wv, "valu_per_wave": round(cd.get("SQ_INSTS_VALU", 0) / wv, 1), "salu_per_wave": round(cd.get("SQ_INSTS_SALU", 0) / wv, 1),
+             "lds_per_wave": round(cd.get("SQ_INSTS_LDS", 0) / wv, 1),
+             "wave_cycles": {"active": round(cd.get("SQ_ACTIVE_INST_ANY", 0) / wcyc, 3), "wait_issue": round(cd.get("SQ_WAIT_INST_ANY", 0) / wcyc, 3),
+                             "wait_memory": round(cd.get("SQ_WAIT_ANY", 0) / wcyc, 3)},
+             "valu_busy": round(cd.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * clk), 3) if clk else None,
+             "lds_busy": round(cd.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * clk), 3) if clk else None,
+             "lds_bank_conflict_share": round(cd.get("SQ_LDS_BANK_CONFLICT", 0) / max(cd.get("SQ_LDS_IDX_ACTIVE", 0), 1), 3)}
+    # the raw material of every table above, a few KB: profiles/<round>_raw/
+    fin = os.path.join(tag_dir, "final")
+    if os.path.isdir(fin):
+        import shutil
+        raw = out_prefix + "_raw"
+        os.makedirs(raw, exist_ok=True)
+        for fn in os.listdir(fin):
+            shutil.copy(os.path.join(fin, fn), os.path.join(raw, fn))
+    json.dump({"stage": st, "config": config, "kernel": dom, "images_per_launch": 256, "issue": issue, "fetch_kb": cs[dom].get("FETCH_SIZE", 0),
                "fetch_correction": 2.0 if wide else 1.0, "write_kb": cs[dom].get("WRITE_SIZE", 0), "avg_us_stats_pass": avg_us[dom],
                "read_kb_by_request_size": rk, "write_kb_by_request_size": wk,
                "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "

@@ -20,3 +20,21 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
   echo "pass $i done"
 done
+# ---- what the committed tables are derived from, small enough to keep: the two kernel-stats tables and the per-kernel averages of
+#      every counter pass (tools/profile_report.py copies gpurun_out/<tag>/final/ to profiles/<round>_raw/)
+mkdir -p $OUT/final
+cp $(find $OUT -name "stats_kernel_stats.csv" | head -1) $OUT/final/stats_kernel_stats.csv
+cp $(find $OUT -name "stats1_kernel_stats.csv" | head -1) $OUT/final/stats1_kernel_stats.csv
+grep "^{" $OUT/stats.log | tail -1 > $OUT/final/bench_line_stats_pass.json
+grep "^{" $OUT/stats1.log | tail -1 > $OUT/final/bench_line_one_stream_pass.json
+python3 - $OUT <<'PY'
+import collections, csv, glob, json, os, sys
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in sorted(glob.glob(os.path.join(sys.argv[1], "**", "pmc*counter_collection.csv"), recursive=True)):
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: {"mean_of_later_launches": sum(v[len(v) // 3:]) / max(len(v[len(v) // 3:]), 1), "launches": len(v)} for c, v in cs.items()}
+       for k, cs in acc.items() if not k.startswith("at::") and "rocclr" not in k}
+json.dump(out, open(os.path.join(sys.argv[1], "final", "pmc_averages.json"), "w"), indent=1)
+print("final/: kernel stats x 2, bench lines x 2, pmc_averages.json for", len(out), "kernels")
+PY
