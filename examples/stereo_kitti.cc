@@ -611,7 +611,9 @@ static void RunShardBatched(const Options& o, const std::vector<std::string>& vs
       }
       sh.gather_ms = std::max(sh.gather_ms, 0.0) + 1e3 * seconds_since(tg);
     }
-    finish_upto(k - 1);
+    // S chunks stay in flight (round 5 waited for chunk k - 1 here: two in flight, the third slot idle -- 82 k frames/s where the same handle
+    // driven with three in flight does 91 k with every block copied out, 105 k with the counts alone: profiles/r06_pipeline.md)
+    finish_upto(k - (S - 1));
   }
   finish_upto(K - 1);
   sh.wall_s = seconds_since(tSequence);
