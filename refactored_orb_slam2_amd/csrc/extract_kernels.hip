@@ -2348,7 +2348,7 @@ __device__ __forceinline__ void patch_store16(uint8_t* base, int r, int c, const
   }
 }
 #define ORI_BYTES ((31 * ORI_PITCH + 15) & ~15)            // 1488
-#define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 2608
+#define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 3856
 
 // ---- orientation + description, eight keypoints per wave ------------------------------------------------------------------
 // The per-keypoint work has two kinds of instructions: cooperative ones (patch staging, the 749-pixel moment sums, the 256
@@ -2363,13 +2363,6 @@ __device__ __forceinline__ void patch_store16(uint8_t* base, int r, int c, const
 // keypoint instead of three.
 #ifndef OD_K
 #define OD_K 8
-#ifndef OD_DISC
-#define OD_DISC 0         // raw patch: only the 16-byte pieces that meet the moment disc are requested (93 -> 76 per keypoint); measured
-                          // 0.279-0.283 ms against 0.275-0.276 without: the addresser's time goes with load INSTRUCTIONS, not with active lanes
-#endif
-#ifndef OD_DISC_DSC
-#define OD_DISC_DSC 0     // blurred patch: only the pieces that meet the disc of reachable pattern positions (120 -> 105; needs OD_DSC_NARROW).
-#endif                    // Measured: its four more registers (74: six waves per SIMD instead of seven) cost what the requests save -- off
 #ifndef OD_DSC_NARROW
 #define OD_DSC_NARROW 1   // three 16-byte pieces per row of the blurred window where its 37 columns fit them (0: always four)
 #endif
@@ -2390,12 +2383,6 @@ extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
 }
 #endif
 __device__ __attribute__((aligned(16))) uint32_t g_ic_w[256 * 2];   // [item][u-weights | v-weights] (int8 x 4), item = row * 8 + 4-column group
-// Which 16-byte pieces of a keypoint's two windows are requested at all (OD_DISC): per lane and load round a 16-bit word, bit m set iff
-// the lane's piece meets the disc for a window whose centre column is m + 15 (raw patch: the moment disc, umax) / m + 18 (blurred
-// patch: every position a rotated, rounded pattern point can take) -- built on the host (orbfe_upload_pattern_floats).
-//   [0] raw round 0 | round 1 << 16   [1] blurred, four pieces per row: round 0 | round 1 << 16
-//   [2] blurred four-piece round 2 | three-piece round 0 << 16   [3] blurred three-piece round 1
-__device__ __attribute__((aligned(16))) uint32_t g_od_act[4 * 64];
 __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -2433,11 +2420,6 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     const uint2 w2 = reinterpret_cast<const uint2*>(g_ic_w)[it];
     wu[j] = w2.x; wv[j] = w2.y;
   }
-#if OD_DISC
-  uint32_t aw[OD_DISC_DSC ? 4 : 1];
-#pragma unroll
-  for (int j = 0; j < (OD_DISC_DSC ? 4 : 1); j++) aw[j] = g_od_act[j * 64 + lane];
-#endif
   uint8_t* ori = &patch[wv_id][0];
   uint8_t* dsc = ori + ORI_BYTES;
 
@@ -2492,14 +2474,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       (void)pitch; (void)plane;   // raw levels in 16 x 8 tiles: 0.346 -> 0.277 ms (DESIGN lesson 44)
       vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(P.blur.base[level] + (size_t)img * P.blur.img_stride[level] + blur_tiled_offset(ax_o + 16 * c, cy - 15 + r, P.blur.pitch[level])) : make_uint4(0, 0, 0, 0);
 #else
-#if OD_DISC
-      // (a lane whose piece lies outside the moment disc for this centre column requests nothing: the weights of those pixels are zero)
-      vo[j] = ((aw[0] >> (((cx - 15) & 15) + 16 * j)) & 1u)
-                  ? *reinterpret_cast<const uint4*>(plane + orbfe_level_offset(ax_o + 16 * c, cy - 15 + r, pitch, (P.pyr.tiled >> level) & 1u))
-                  : make_uint4(0, 0, 0, 0);
-#else
       vo[j] = i < 31 * 3 ? *reinterpret_cast<const uint4*>(plane + orbfe_level_offset(ax_o + 16 * c, cy - 15 + r, pitch, (P.pyr.tiled >> level) & 1u)) : make_uint4(0, 0, 0, 0);
-#endif
 #endif
     }
   };
@@ -2513,22 +2488,13 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     // rounds -- the kernel is bound by the texture addresser (TA / TD / TCP 0.95-0.99 busy), i.e. by pieces requested.  One code path:
     // the lane -> (row, piece) map and the count are selected by the wave-uniform flag (a branch around the loads would make the
     // compiler wait for them at its end: the next keypoint's patch could no longer be in flight during this one's tests)
-    const int md = (cx - 18) & 15;
-    const bool wide = md > 11;
+    const bool wide = ((cx - 18) & 15) > 11;
     const int n_pieces = wide ? 37 * 4 : 37 * 3;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int i = lane + WAVE * j;
       const int r = wide ? (i >> 2) : r3[j], c = wide ? (i & 3) : c3[j];
-#if OD_DISC && OD_DISC_DSC
-      // pieces outside the disc of reachable pattern positions are not requested (the tests never read them)
-      const uint32_t word = j == 0 ? (wide ? aw[1] : aw[2] >> 16) : j == 1 ? (wide ? aw[1] >> 16 : aw[3]) : (wide ? aw[2] : 0u);
-      (void)n_pieces;
-      vd[j] = ((word >> md) & 1u) ? *reinterpret_cast<const uint4*>(bplane + blur_tiled_offset(max(ax_d + 16 * c, 0), max(cy - 18 + r, 0), bpitch))
-                                  : make_uint4(0, 0, 0, 0);
-#else
       vd[j] = i < n_pieces ? *reinterpret_cast<const uint4*>(bplane + blur_tiled_offset(max(ax_d + 16 * c, 0), max(cy - 18 + r, 0), bpitch)) : make_uint4(0, 0, 0, 0);
-#endif
     }
 #else
 #pragma unroll
@@ -2543,7 +2509,9 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
   auto next_valid = [&](int k) { const unsigned m = valid_mask >> (k + 1); return m ? k + 1 + (__ffs((int)m) - 1) : OD_K; };
   const int k_first = __ffs((int)valid_mask) - 1;
 
-  // ---- phase 1: moments of the keypoints, keypoint k's in lane k.  The loads of keypoint k + 1 are in flight while k is summed.
+  // ---- phase 1: moments of the keypoints, keypoint k's in lane k.
+  // The loads of keypoint k + 1 are in flight while k is summed.  (Requesting the raw patches of TWO keypoints with three load instructions
+  // instead of four, lane -> (patch, row, piece): 0.2769 ms against 0.2753-0.2763 -- no gain, removed: profiles/r06_describe.md.)
   int m10v = 0, m01v = 0;
   {
     uint4 vn[2];
@@ -2555,11 +2523,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
       for (int j = 0; j < 2; j++) {
         const int i = lane + WAVE * j;
         const int r = i / 3, c = i - r * 3;
-#if OD_DISC
-        if ((aw[0] >> (m + 16 * j)) & 1u) patch_store16<ORI_PITCH>(ori, r, c, vn[j]);
-#else
         if (i < 31 * 3) patch_store16<ORI_PITCH>(ori, r, c, vn[j]);
-#endif
       }
       FC_T(1);   // wait for the raw patch + LDS store
       const int kn = next_valid(k);
@@ -2612,13 +2576,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int i = lane + WAVE * j;
-#if OD_DISC && OD_DISC_DSC && OD_DSC_NARROW
-        const uint32_t word = j == 0 ? (wide ? aw[1] : aw[2] >> 16) : j == 1 ? (wide ? aw[1] >> 16 : aw[3]) : (wide ? aw[2] : 0u);
-        (void)n_pieces; (void)i;
-        if ((word >> ((cx - 18) & 15)) & 1u) patch_store16<DSC_PITCH>(dsc, wide ? (i >> 2) : r3[j], wide ? (i & 3) : c3[j], wn[j]);
-#else
         if (i < n_pieces) patch_store16<DSC_PITCH>(dsc, wide ? (i >> 2) : r3[j], wide ? (i & 3) : c3[j], wn[j]);
-#endif
       }
     }
     FC_T(4);   // wait for the blurred patch + LDS store
@@ -2813,41 +2771,6 @@ int orbfe_upload_pattern_floats() {
   }
   e = hipMemcpyToSymbol(HIP_SYMBOL(g_ic_w), wtab, sizeof(wtab));
   if (e != hipSuccess) return (int)e;
-  {
-    // g_od_act.  Raw patch: row v holds the moment disc's columns |u| <= umax[|v|] around column m + 15.  Blurred patch: a pattern point
-    // at radius rho lands, rotated by any angle and rounded (cvRound per coordinate), in row ry only at |rx| <= floor(sqrt(rho^2 -
-    // (|ry| - 1/2)^2) + 1/2); rho = the largest pattern radius (+ 0.01 for the float arithmetic of the rotation), around column m + 18.
-    double rho2 = 0;
-    for (int i = 0; i < 512; i++) rho2 = std::max(rho2, (double)pat[2 * i] * pat[2 * i] + (double)pat[2 * i + 1] * pat[2 * i + 1]);
-    const double rho = sqrt(rho2) + 0.01;
-    int hw[19];
-    for (int v = 0; v <= 18; v++) {
-      const double y = std::max(v - 0.5, 0.0), x2 = rho * rho - y * y;
-      hw[v] = x2 <= 0 ? -1 : std::min(18, (int)floor(sqrt(x2) + 0.5));   // -1: no pattern point can land in this row
-    }
-    auto bits = [](int r, int c, int rows, int centre, const int* half, int half_n) {
-      uint32_t b = 0;
-      if (r >= rows) return b;
-      const int v = abs(r - (rows - 1) / 2);
-      const int h = v < half_n ? half[v] : -1;
-      if (h < 0) return b;
-      for (int m = 0; m < 16; m++)
-        if (16 * c <= m + centre + h && 16 * c + 15 >= m + centre - h) b |= 1u << m;
-      return b;
-    };
-    uint32_t act[4 * 64];
-    for (int lane = 0; lane < 64; lane++) {
-      auto ori_w = [&](int j) { const int i = lane + 64 * j; return i < 31 * 3 ? bits(i / 3, i % 3, 31, 15, umax, 16) : 0u; };
-      auto d4_w = [&](int j) { const int i = lane + 64 * j; return i < 37 * 4 ? bits(i >> 2, i & 3, 37, 18, hw, 19) : 0u; };
-      auto d3_w = [&](int j) { const int i = lane + 64 * j; return i < 37 * 3 ? bits(i / 3, i % 3, 37, 18, hw, 19) : 0u; };
-      act[0 * 64 + lane] = ori_w(0) | (ori_w(1) << 16);
-      act[1 * 64 + lane] = d4_w(0) | (d4_w(1) << 16);
-      act[2 * 64 + lane] = d4_w(2) | (d3_w(0) << 16);
-      act[3 * 64 + lane] = d3_w(1);
-    }
-    e = hipMemcpyToSymbol(HIP_SYMBOL(g_od_act), act, sizeof(act));
-    if (e != hipSuccess) return (int)e;
-  }
   // band matrices of the tile kernel's matrix-core blur (blur_level_kernel, BT_MFMA): lane (q, n) of a matrix holds 16 bytes.
   //   horizontal (one for every column group g): byte j <-> LDS column 16g + 16q + j, output = LDS column BT_COL0 + 4 + 16g + n
   //   vertical, block b:  byte j = 4 ww + i <-> window row 16 ww + 4q + i, output = window row 3 + 16b + n
