@@ -2593,15 +2593,22 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     const uint32_t MB = 0x4B400000u;   // its bit pattern
     const uint32_t bc0 = (uint32_t)(18 * DSC_PITCH + (cx - ax_d)) - (MB * (uint32_t)DSC_PITCH + MB);
     uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
+    // all eight samples requested before the first comparison, and the 32 descriptor bytes stored by lanes 0 .. 3 in one instruction:
+    // with a ballot and lane 0's store behind every pair of samples the compiler kept the four rounds apart -- four dependent LDS
+    // round trips (with their bank conflicts: the rotated positions are pseudo-random bytes of the window) and four stores per keypoint
+    int t0[4], t1[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
       const uint32_t ry0 = __float_as_uint((x0 * b + y0 * a) + MAGIC), rx0 = __float_as_uint((x0 * a - y0 * b) + MAGIC);
       const uint32_t ry1 = __float_as_uint((x1 * b + y1 * a) + MAGIC), rx1 = __float_as_uint((x1 * a - y1 * b) + MAGIC);
-      const int t0 = dsc[bc0 + ry0 * (uint32_t)DSC_PITCH + rx0];
-      const int t1 = dsc[bc0 + ry1 * (uint32_t)DSC_PITCH + rx1];
-      const unsigned long long bits = __ballot(t0 < t1);
-      if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = bits;
+      t0[r] = dsc[bc0 + ry0 * (uint32_t)DSC_PITCH + rx0];
+      t1[r] = dsc[bc0 + ry1 * (uint32_t)DSC_PITCH + rx1];
+    }
+    {
+      const unsigned long long b0 = __ballot(t0[0] < t1[0]), b1 = __ballot(t0[1] < t1[1]), b2 = __ballot(t0[2] < t1[2]), b3 = __ballot(t0[3] < t1[3]);
+      const unsigned long long mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+      if (lane < 4) reinterpret_cast<unsigned long long*>(dout)[lane] = mine;
     }
     if (lane < 7) {
       float fx = (float)cx, fy = (float)cy;
