@@ -2348,7 +2348,23 @@ __device__ __forceinline__ void patch_store16(uint8_t* base, int r, int c, const
   }
 }
 #define ORI_BYTES ((31 * ORI_PITCH + 15) & ~15)            // 1488
+#ifndef OD_DMA_STAGE
+#define OD_DMA_STAGE 1   // the windows go global -> LDS directly (global_load_lds_dwordx4), two buffers per wave; 0: through registers (rounds 2-5)
+#endif
+#define OD_BUF (37 * DSC_PITCH)                            // 2368: one LDS buffer holds either window
+#if OD_DMA_STAGE
+#define PATCH_BYTES (2 * OD_BUF)                           // 4736
+// lane l's 16 bytes land at lds_dst + 16 l: the windows' LDS images are exactly that order -- raw patch 31 rows x 3 pieces at pitch 48,
+// blurred patch 37 rows x 4 pieces at pitch 64 or x 3 pieces at pitch 48 (piece i = row * pieces + column at byte 16 i).  The compiler
+// does not count these loads: every wait for them is an explicit s_waitcnt vmcnt below.  M0 (the destination) is saved and restored.
+#define OD_DMA(gsrc, lds_dst) do { \
+    unsigned keep_m0; \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_m0) : "v"(gsrc), "s"(lds_dst) : "memory"); \
+  } while (0)
+#else
 #define PATCH_BYTES ((ORI_BYTES + 37 * DSC_PITCH + 15) & ~15)  // 3856
+#endif
 
 // ---- orientation + description, eight keypoints per wave ------------------------------------------------------------------
 // The per-keypoint work has two kinds of instructions: cooperative ones (patch staging, the 749-pixel moment sums, the 256
@@ -2383,7 +2399,10 @@ extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
 }
 #endif
 __device__ __attribute__((aligned(16))) uint32_t g_ic_w[256 * 2];   // [item][u-weights | v-weights] (int8 x 4), item = row * 8 + 4-column group
-__global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P) {
+#ifndef OD_WGS
+#define OD_WGS 7   // workgroups (= waves per SIMD) resident per CU: the register budget the compiler is given and the LDS padding below
+#endif
+__global__ __launch_bounds__(256, OD_WGS) void orient_describe8_kernel(DescribeParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t patch[4][PATCH_BYTES];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2420,8 +2439,10 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     const uint2 w2 = reinterpret_cast<const uint2*>(g_ic_w)[it];
     wu[j] = w2.x; wv[j] = w2.y;
   }
+#if !OD_DMA_STAGE
   uint8_t* ori = &patch[wv_id][0];
   uint8_t* dsc = ori + ORI_BYTES;
+#endif
 
   // slot bookkeeping, lane k for slot s0 + k: level, position, score and output index (-1 = no keypoint in this slot)
   int i_out = -1, i_level = 0, i_cx = 0, i_cy = 0, i_score = 0;
@@ -2455,11 +2476,12 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
   if (valid_mask == 0) return;
   FC_T(0);   // tables + slot bookkeeping
 
-#if OD_DSC_NARROW
+#if OD_DSC_NARROW && !OD_DMA_STAGE
   int r3[3], c3[3];   // lane -> (row, piece) of the three-piece blurred window
 #pragma unroll
   for (int j = 0; j < 3; j++) { const int i = lane + WAVE * j; r3[j] = i / 3; c3[j] = i - 3 * r3[j]; }
 #endif
+#if !OD_DMA_STAGE
   // the loads of keypoint k's raw patch (two 16-byte pieces per lane) / blurred patch (three)
   auto issue_ori = [&](int k, uint4 vo[2]) {
     const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
@@ -2505,10 +2527,170 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     }
 #endif
   };
+#endif
   // next valid slot after k (OD_K if none)
   auto next_valid = [&](int k) { const unsigned m = valid_mask >> (k + 1); return m ? k + 1 + (__ffs((int)m) - 1) : OD_K; };
   const int k_first = __ffs((int)valid_mask) - 1;
 
+#if OD_DMA_STAGE
+  // ---- phase 1: moments of the keypoints, keypoint k's in lane k.  The window of keypoint k + 1 travels global -> LDS (the other
+  // buffer) while k's is summed: no staging registers, no LDS store instructions, no wait between a load's arrival and its store.
+  const uint32_t lds_buf = (uint32_t)(uintptr_t)&patch[wv_id][0];
+  auto dma_ori = [&](int k, uint32_t lds) {
+    const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
+    const int pitch = P.pyr.pitch[level];
+    const uint8_t* plane = P.pyr.base[level] + (size_t)img * P.pyr.img_stride[level];
+    const bool tiled = (P.pyr.tiled >> level) & 1u;
+    const int ax_o = (cx - 15) & ~15;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = lane + WAVE * j;
+      const int r = (i * 43) >> 7, c = i - 3 * r;   // i / 3, i % 3 for i < 128
+      if (i < 31 * 3) OD_DMA(plane + orbfe_level_offset(ax_o + 16 * c, cy - 15 + r, pitch, tiled), lds + 1024u * j);
+    }
+  };
+  int m10v = 0, m01v = 0;
+  {
+    // every load the compiler knows of (pattern, weights, slot records) has arrived before the first window is requested: it does not
+    // see the LDS-DMA loads, and would otherwise wait for "its" loads inside the loops below -- with a count that also drains the
+    // window that was just requested (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    dma_ori(k_first, lds_buf);
+    uint32_t par = 0;
+    for (int k = k_first; k < OD_K; k = next_valid(k), par ^= 1u) {
+      const int kn = next_valid(k);
+      // (the buffer the next window lands in was last read two keypoints ago; those reads were consumed before that iteration ended.
+      //  Three buffers with the windows of k + 1 AND k + 2 in flight: 0.269 ms against 0.262 -- more requests in flight are not faster)
+      if (kn < OD_K) {
+        dma_ori(kn, lds_buf + (par ^ 1u) * OD_BUF);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // everything older than the two loads just issued: this keypoint's window
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      FC_T(1);   // wait for the raw patch
+      const uint8_t* ob = &patch[wv_id][0] + par * OD_BUF;
+      const int cx = __builtin_amdgcn_readlane(i_cx, k);
+      const int m = (cx - 15) & 15;
+      int A = 0, B = 0;
+      const uint32_t sh = (uint32_t)(m & 3);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int it = lane + WAVE * j;
+        const int r = it >> 3, c = it & 7;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(ob + (r < 31 ? r : 30) * ORI_PITCH + ((m + 4 * c) & ~3));
+        // the four pixels u = -15 + 4c .. -12 + 4c of row v = r - 15, as I - 128
+        const int px = (int)(__builtin_amdgcn_alignbyte(q[1], q[0], sh) ^ 0x80808080u);
+        A = __builtin_amdgcn_sdot4(px, (int)wu[j], A, false);
+        B = __builtin_amdgcn_sdot4(px, (int)wv[j], B, false);
+      }
+      const int At = __builtin_amdgcn_readlane(wave_incl_scan(A), 63), Bt = __builtin_amdgcn_readlane(wave_incl_scan(B), 63);
+      if (lane == k) { m10v = At; m01v = Bt; }
+      FC_T(2);   // moments
+    }
+  }
+  // ---- phase 2: lane k computes keypoint k's angle and rotation; the first blurred patch is already on its way
+  auto dsc_wide = [&](int k) { return ((__builtin_amdgcn_readlane(i_cx, k) - 18) & 15) > 11; };
+  auto dma_dsc = [&](int k, uint32_t lds) {
+    const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
+    const int bpitch = P.blur.pitch[level];
+    const uint8_t* bplane = P.blur.base[level] + (size_t)img * P.blur.img_stride[level];
+    const int ax_d = (cx - 18) & ~15;
+    // 37 x 3 pieces (two rounds) where the window's 37 columns end inside the third 16-byte piece, 37 x 4 (three) otherwise
+    const bool wide = ((cx - 18) & 15) > 11;
+    const int n_pieces = wide ? 37 * 4 : 37 * 3;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i = lane + WAVE * j;
+      const int q3 = (i * 43) >> 7;
+      const int r = wide ? (i >> 2) : q3, c = wide ? (i & 3) : i - 3 * q3;
+      if (j < 2 || wide)   // (wave-uniform: the third round exists only for the wide window)
+        if (i < n_pieces) OD_DMA(bplane + blur_tiled_offset(max(ax_d + 16 * c, 0), max(cy - 18 + r, 0), bpitch), lds + 1024u * j);
+    }
+  };
+  dma_dsc(k_first, lds_buf);
+  const float angle_v = fast_atan2_deg((float)m01v, (float)m10v);
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a_v, b_v;
+  glibc_sincosf(angle_v * factorPI, &b_v, &a_v);
+  FC_T(3);   // angle, sin / cos
+  // ---- phase 3: steered BRIEF on the blurred level
+  {
+    uint32_t par = 0;
+    for (int k = k_first; k < OD_K; k = next_valid(k), par ^= 1u) {
+      const int level = __builtin_amdgcn_readlane(i_level, k), cx = __builtin_amdgcn_readlane(i_cx, k), cy = __builtin_amdgcn_readlane(i_cy, k);
+      const int out = __builtin_amdgcn_readlane(i_out, k), score = __builtin_amdgcn_readlane(i_score, k);
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_v), k)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_v), k)),
+                  angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_v), k));
+      const int ax_d = (cx - 18) & ~15;
+      const bool wide = ((cx - 18) & 15) > 11;
+      const int kn = next_valid(k);
+      // the queue holds, oldest first: this keypoint's window, the previous keypoint's two stores, then the loads issued here
+      if (kn < OD_K) {
+        dma_dsc(kn, lds_buf + (par ^ 1u) * OD_BUF);
+        if (dsc_wide(kn)) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      FC_T(4);   // wait for the blurred patch
+      const uint8_t* dsc = &patch[wv_id][0] + par * OD_BUF;
+      // cvRound of the rotated coordinates (L/src/ORBextractor.cc:119-121) by the magic-number addition: v + 1.5 * 2^23 rounds |v| < 2^22
+      // to nearest-even in the mantissa's low bits -- one v_add_f32 where v_rndne_f32 + v_cvt_i32_f32 were two.  The integers are never
+      // separated from the magic word: in 32-bit wrap-around arithmetic (M + ry) * PITCH + (M + rx) is the patch index plus a constant
+      // that goes into the wave-uniform base.  PITCH is 64 for the wide window and 48 for the narrow one (3 * 16: a shift-add more).
+      const float MAGIC = 12582912.0f;
+      const uint32_t MB = 0x4B400000u;   // its bit pattern
+      const uint32_t pitch = wide ? 64u : 48u;
+      const uint32_t bc0 = 18u * pitch + (uint32_t)(cx - ax_d) - (MB * pitch + MB);
+      uint8_t* dout = P.out_desc + ((size_t)img * P.cap + out) * 32;
+      int t0[4], t1[4];
+      if (wide) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
+          const uint32_t ry0 = __float_as_uint((x0 * b + y0 * a) + MAGIC), rx0 = __float_as_uint((x0 * a - y0 * b) + MAGIC);
+          const uint32_t ry1 = __float_as_uint((x1 * b + y1 * a) + MAGIC), rx1 = __float_as_uint((x1 * a - y1 * b) + MAGIC);
+          t0[r] = dsc[bc0 + ry0 * 64u + rx0];
+          t1[r] = dsc[bc0 + ry1 * 64u + rx1];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float x0 = pk[r].x, y0 = pk[r].y, x1 = pk[r].z, y1 = pk[r].w;
+          const uint32_t ry0 = __float_as_uint((x0 * b + y0 * a) + MAGIC), rx0 = __float_as_uint((x0 * a - y0 * b) + MAGIC);
+          const uint32_t ry1 = __float_as_uint((x1 * b + y1 * a) + MAGIC), rx1 = __float_as_uint((x1 * a - y1 * b) + MAGIC);
+          t0[r] = dsc[bc0 + ry0 * 48u + rx0];
+          t1[r] = dsc[bc0 + ry1 * 48u + rx1];
+        }
+      }
+      {
+        const unsigned long long b0 = __ballot(t0[0] < t1[0]), b1 = __ballot(t0[1] < t1[1]), b2 = __ballot(t0[2] < t1[2]), b3 = __ballot(t0[3] < t1[3]);
+        const unsigned long long mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        if (lane < 4) reinterpret_cast<unsigned long long*>(dout)[lane] = mine;
+      }
+      {
+        float fx = (float)cx, fy = (float)cy;
+        if (level != 0) {
+          fx *= P.scale[level];
+          fy *= P.scale[level];
+        }
+        uint32_t wvv;
+        switch (lane) {
+          case 0: wvv = __float_as_uint(fx); break;
+          case 1: wvv = __float_as_uint(fy); break;
+          case 2: wvv = __float_as_uint(P.kp_size[level]); break;
+          case 3: wvv = __float_as_uint(angle); break;
+          case 4: wvv = __float_as_uint((float)score); break;
+          case 5: wvv = (uint32_t)level; break;
+          default: wvv = 0xFFFFFFFFu; break;
+        }
+        // (every keypoint issues exactly these two stores: the wait above counts on it)
+        if (lane < 7) reinterpret_cast<uint32_t*>(P.out_kps + (size_t)img * P.cap + out)[lane] = wvv;
+      }
+      FC_T(5);   // BRIEF + stores
+    }
+  }
+#else
   // ---- phase 1: moments of the keypoints, keypoint k's in lane k.
   // The loads of keypoint k + 1 are in flight while k is summed.  (Requesting the raw patches of TWO keypoints with three load instructions
   // instead of four, lane -> (patch, row, piece): 0.2769 ms against 0.2753-0.2763 -- no gain, removed: profiles/r06_describe.md.)
@@ -2631,6 +2813,7 @@ __global__ __launch_bounds__(256) void orient_describe8_kernel(DescribeParams P)
     __builtin_amdgcn_wave_barrier();
     FC_T(5);   // BRIEF + stores
   }
+#endif
 #if FC_TIMING
   if (lane == 0) {
     unsigned long long* pr = g_od_prof + (size_t)((((unsigned)(bx * 4 + wv_id) + 977u * (unsigned)img) * 2654435761u) >> 20) * 8;
@@ -2751,7 +2934,9 @@ void orbfe_launch_describe(const DescribeParams& p, int n_images, hipStream_t s)
   // 63 VGPRs would let eight waves per SIMD run; the gather of 2 000 patches per image is L2-miss bound and an eighth wave
   // measured slower (0.352 against 0.341 ms per 256 images): unused dynamic LDS keeps a CU at seven workgroups
 #ifndef OD_LDS_PAD
-#define OD_LDS_PAD (4 * PATCH_BYTES < 21504 ? 21504 - 4 * PATCH_BYTES : 0)   // 21 KB per workgroup: seven per CU
+// dynamic LDS that brings a workgroup to (160 KB / (OD_WGS + 1) rounded up to 512 B) + 512: OD_WGS workgroups fit a CU, OD_WGS + 1 do not
+#define OD_LDS_WG ((((163840 / (OD_WGS + 1)) + 511) & ~511) + 512)
+#define OD_LDS_PAD (4 * PATCH_BYTES < OD_LDS_WG ? OD_LDS_WG - 4 * PATCH_BYTES : 0)
 #endif
   hipLaunchKernelGGL(orient_describe8_kernel, grid, block, OD_LDS_PAD, s, pp);
 }
