@@ -6,10 +6,10 @@
 #   the markdown / json files committed under profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; shift; mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 --cabi-steps 0 "$@" > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
 tail -1 $OUT/stats.log | cut -c1-200
 # the same with every kernel alone on the chip (one stream, one set of handles): the per-kernel durations of the PMC tables
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats1 -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 --lr-streams 1 --sets 1 "$@" > $OUT/stats1.log 2>&1 || { echo "one-stream stats pass failed"; tail -3 $OUT/stats1.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats1 -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 --cabi-steps 0 --lr-streams 1 --sets 1 "$@" > $OUT/stats1.log 2>&1 || { echo "one-stream stats pass failed"; tail -3 $OUT/stats1.log; exit 1; }
 tail -1 $OUT/stats1.log | cut -c1-200
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
@@ -17,7 +17,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 "$@" > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --per-frame 0 --content-steps 0 --cabi-steps 0 "$@" > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
   echo "pass $i done"
 done
 # ---- what the committed tables are derived from, small enough to keep: the two kernel-stats tables and the per-kernel averages of
@@ -38,3 +38,9 @@ out = {k: {c: {"mean_of_later_launches": sum(v[len(v) // 3:]) / max(len(v[len(v)
 json.dump(out, open(os.path.join(sys.argv[1], "final", "pmc_averages.json"), "w"), indent=1)
 print("final/: kernel stats x 2, bench lines x 2, pmc_averages.json for", len(out), "kernels")
 PY
+# ---- the reports, written on the GPU box (gpurun merges at most 64 MiB back: the per-dispatch CSVs stay there): $OUT/report/<name>_*.md / .json /
+#      _raw/; copy them into profiles/ afterwards.  REPORT_NAME (default r06), REPORT_CONFIG (default kitti_stereo)
+mkdir -p $OUT/report
+python3 tools/profile_report.py $OUT $OUT/report/${REPORT_NAME:-r06} ${REPORT_CONFIG:-kitti_stereo}
+find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+du -sh $OUT
