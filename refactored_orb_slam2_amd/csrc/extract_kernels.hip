@@ -498,6 +498,9 @@ extern "C" int orbfe_debug_fc_profile(unsigned long long* out, int reset) {
 #else
 #define FC_T(i)
 #endif
+#ifndef FC_SCALAR_CELL
+#define FC_SCALAR_CELL 1   // a cell's descriptor through the scalar cache (eight dwords) instead of the compiler's vector loads of its 16-bit fields
+#endif
 #ifndef FC_PE_COND
 #define FC_PE_COND 1   // the dword in front of a chunk is loaded only for cells whose tile is shifted by a column (-1 %)
 #endif
@@ -554,8 +557,21 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
 #if FC_TIMING
   uint32_t tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tacc4 = 0, tacc5 = 0, tprev = (uint32_t)__builtin_readcyclecounter();
 #endif
+  // a cell's descriptor through the scalar cache (eight dwords at a wave-uniform address): left to itself the compiler reads the 16-bit
+  // fields with vector loads, one memory round trip after the other
+  static_assert(sizeof(CellDesc) == 32, "eight dwords");
+  auto load_cell = [&](int idx) {
+    const __attribute__((address_space(4))) uint32_t* q =
+        (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(cells + __builtin_amdgcn_readfirstlane(idx));
+    CellDesc c;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = q[j];
+    __builtin_memcpy(&c, w, sizeof(c));
+    return c;
+  };
   for (int k = 0; k < g.n_cells; k++) {
-    const CellDesc cd = cells[g.first_cell + k];
+    const CellDesc cd = FC_SCALAR_CELL ? load_cell(g.first_cell + k) : cells[g.first_cell + k];
     // ---- the cell's pixels: every lane loads in every round (row and chunk clamped into the cell: a duplicate load and,
     //      below, a duplicate LDS store of the same bytes cost nothing, a divergent branch around them does)
     uint4 pv[NLD];
@@ -1721,6 +1737,9 @@ __device__ __forceinline__ void blur_pack(const v4i d, int& hi, int& lo) {
 #ifndef BT_XCD_IMAGES
 #define BT_XCD_IMAGES 1  // whole images per XCD instead of runs of eight tiles: 88.1 k -> 90.2 k frames/s (level chain 0.466 -> 0.441 ms)
 #endif
+#ifndef BT_SCALAR_TILE
+#define BT_SCALAR_TILE 1
+#endif
 #ifndef BT_MIN_WAVES
 #define BT_MIN_WAVES 2   // with one argument hipcc puts the MFMA results into AGPRs and copies every one back (lesson 31)
 #endif
@@ -1763,7 +1782,22 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
   const int q = blockIdx.x >> 3, img = (int)blockIdx.y;
   const int tile_id = (int)blockIdx.x >= (n_tiles / 64) * 64 ? (int)blockIdx.x : (q >> 3) * 64 + (blockIdx.x & 7) * 8 + (q & 7);
 #endif
+#if BT_SCALAR_TILE
+  // the tile's record through the scalar cache (four dwords at a wave-uniform address): the compiler's own choice is a vector
+  // dwordx3 + ushort load -- an L2 round trip in front of the window's first load address, on the critical path of every tile
+  static_assert(sizeof(BlurTile) == 16, "four dwords");
+  BlurTile t;
+  {
+    const __attribute__((address_space(4))) uint32_t* q =
+        (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(tiles + __builtin_amdgcn_readfirstlane(tile_id));
+    uint32_t w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w4[j] = q[j];
+    __builtin_memcpy(&t, w4, sizeof(t));
+  }
+#else
   const BlurTile t = tiles[tile_id];
+#endif
   const int lvl = t.level;
   const int w = src.w[lvl], h = src.h[lvl], pitch = src.pitch[lvl];
   const uint8_t* S = src.base[lvl] + (size_t)img * src.img_stride[lvl];

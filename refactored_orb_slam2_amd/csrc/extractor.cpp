@@ -366,11 +366,7 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
           const int tw = std::max(c.cols - 6, 0), th = std::max(c.rows - 6, 0);
           const int cap = std::max(((tw + 1) / 2) * ((th + 1) / 2), 1);  // NMS survivors are never 8-adjacent
           c.slot_cap = (int16_t)cap;
-          {
-            const int ppr = std::max((tw + 1) >> 1, 1), ri = std::max(64 / ppr, 1);
-            c.ppr = (int16_t)ppr; c.ri = (int16_t)ri; c.n_it = (int16_t)((th + ri - 1) / ri); c.pad = 0;
-            c.inv_ppr = 1.0f / (float)ppr;
-          }
+          c.ppr = c.ri = c.n_it = c.pad = 0; c.inv_ppr = 0.0f;   // filled below, once it is known which kernel variant stages the cells
           e->fc_rows = std::max(e->fc_rows, (int)c.rows);
           e->fc_span = std::max(e->fc_span, (c.x0 & 15) + 1 + (int)c.cols);
           e->fc_sc = std::max(e->fc_sc, (th + 2) * (tw + 2));
@@ -415,6 +411,13 @@ static int build_plan(orbfe_extractor* e, int w, int h) {
     o.key_off = key_off;
     o.key_cap = (int)std::min<size_t>(level_slots, 0xFFFFFF);
     key_off += level_slots;
+  }
+  // the quick-test loop's lane layout per cell (the tile is shifted by a column where that makes the first tested column even)
+  for (CellDesc& c : e->cells) {
+    const int tw = std::max(c.cols - 6, 0), th = std::max(c.rows - 6, 0);
+    const int ppr = std::max((tw + 1) >> 1, 1), ri = std::max(64 / ppr, 1);
+    c.ppr = (int16_t)ppr; c.ri = (int16_t)ri; c.n_it = (int16_t)((th + ri - 1) / ri);
+    c.inv_ppr = 1.0f / (float)ppr;
   }
   // resize coefficient tables of every step l - 1 -> l, and which kernel can run it
   std::vector<ResizeTap> hxt[ORBFE_MAX_LEVELS], hyt[ORBFE_MAX_LEVELS];
