@@ -237,8 +237,8 @@ def per_frame_latency(cfg, n_frames: int):
                 f.write(f"{i * 0.1:e}\n")
         base = [exe, seq, "--features", str(cfg["nfeat"]), "--bf", str(cfg["bf"]), "--fx", str(cfg["fx"]), "--fy", str(cfg["fy"]),
                 "--cx", str(cfg["cx"]), "--cy", str(cfg["cy"]), "--th", str(cfg["th"])]
-        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = max(1, min(16, usable - 3))   # the tracking thread and the two extractor threads keep a core each
+        usable = usable_cpus()   # affinity AND the cgroup quota: a GPU box shows 256 hardware threads and grants 16
+        threads = max(1, min(16, usable - 5))   # the tracking thread, the two extractor threads and the matcher adapter's two marshalling helpers keep a core each
         r = subprocess.run(base + ["--decode-threads", str(threads), "--prefetch", "32"], capture_output=True, text=True, timeout=600)
         r0 = subprocess.run(base + ["--decode-threads", "0"], capture_output=True, text=True, timeout=600)   # load, then track
         # the batched pipeline from the same C++ host (orbfe_pipeline_*): chunks of 256 pairs, PNGs decoded inside the clock

@@ -16,78 +16,10 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <thread>
-
 #include "ORBmatcher_hip.h"
 
 namespace ORB_SLAM2 {
 
-namespace {
-// The marshalling loops call the reference's own accessors (MapPoint::GetWorldPos / GetDescriptor: a lock and a cv::Mat clone each,
-// L/src/MapPoint.cc:66-76,334-338) once per point: 2 000 points cost ~90 us on one core, half of SearchByProjection(cur, last) on this
-// path.  The points are independent, so the loop is cut into chunks taken by the calling thread and (at most) two helpers that the
-// process keeps; a host with one core, or a loop of a few points, runs it inline.  Results do not depend on who takes which chunk.
-class MarshalPool {
- public:
-  static MarshalPool& Get() { static MarshalPool p; return p; }
-  // fn(begin, end) over [0, n) in chunks of `grain`
-  void For(int n, int grain, const std::function<void(int, int)>& fn) {
-    if (n <= 2 * grain || workers_.empty() || !call_.try_lock()) { fn(0, n); return; }   // (a second matcher thread marshals inline)
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn; n_ = n; grain_ = grain; next_.store(0); busy_ = (int)workers_.size(); ++gen_;
-    }
-    cv_.notify_all();
-    Take();
-    { std::unique_lock<std::mutex> lk(mu_); done_.wait(lk, [&] { return busy_ == 0; }); fn_ = nullptr; }
-    call_.unlock();
-  }
-
- private:
-  MarshalPool() {
-    const unsigned hc = std::thread::hardware_concurrency();
-    const int k = hc >= 4 ? 2 : (hc >= 2 ? 1 : 0);
-    for (int i = 0; i < k; i++) workers_.emplace_back([this] { Loop(); });
-  }
-  ~MarshalPool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
-    cv_.notify_all();
-    for (std::thread& t : workers_) t.join();
-  }
-  void Take() {
-    for (;;) {
-      const int b = next_.fetch_add(grain_);
-      if (b >= n_) return;
-      (*fn_)(b, b + grain_ < n_ ? b + grain_ : n_);
-    }
-  }
-  void Loop() {
-    unsigned long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (stop_) return;
-      }
-      Take();
-      { std::lock_guard<std::mutex> lk(mu_); if (--busy_ == 0) done_.notify_one(); }
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex mu_, call_;
-  std::condition_variable cv_, done_;
-  const std::function<void(int, int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, grain_ = 1, busy_ = 0;
-  unsigned long gen_ = 0;
-  bool stop_ = false;
-};
-}  // namespace
 
 const int ORBmatcher::TH_HIGH = 100;
 const int ORBmatcher::TH_LOW = 50;
@@ -255,8 +187,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
   const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
   std::vector<orbfe_query> q((size_t)LastFrame.N);
-  MarshalPool::Get().For(LastFrame.N, 256, [&](int i0, int i1) {
-  for (int i = i0; i < i1; i++) {
+  for (int i = 0; i < LastFrame.N; i++) {
     orbfe_query& e = q[(size_t)i];
     memset(&e, 0, sizeof(e));
     MapPoint* pMP = LastFrame.mvpMapPoints[i];
@@ -285,7 +216,6 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     const cv::Mat d = pMP->GetDescriptor();
     memcpy(e.desc, d.ptr(0), 32);
   }
-  });
   return orbfe_host::SearchByProjectionFrame(CurrentFrame, LastFrame, q, mbCheckOrientation);
 }
 
