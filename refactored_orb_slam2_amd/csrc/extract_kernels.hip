@@ -2588,8 +2588,9 @@ __global__ __launch_bounds__(256, OD_WGS) void orient_describe8_kernel(DescribeP
     // every load the compiler knows of (pattern, weights, slot records) has arrived before the first window is requested: it does not
     // see the LDS-DMA loads, and would otherwise wait for "its" loads inside the loops below -- with a count that also drains the
     // window that was just requested (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // (the first window is requested in front of that wait: its latency passes together with the tables')
     dma_ori(k_first, lds_buf);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     uint32_t par = 0;
     for (int k = k_first; k < OD_K; k = next_valid(k), par ^= 1u) {
       const int kn = next_valid(k);
