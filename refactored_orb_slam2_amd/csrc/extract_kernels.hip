@@ -1829,6 +1829,9 @@ __global__ __launch_bounds__(THREADS, BT_MIN_WAVES) void blur_level_kernel(PyrVi
     uint32_t v[NLD];
     const bool interior = oy >= 3 && oy + BT_H + 3 <= h && ox >= 4 && ox - 4 + 4 * NC <= w;
     const bool tilepath = stiled && BT_COL0 != 0;   // a tiled level arrives as whole tile rows (below), also at the level's edges
+    // (round 6: interior windows staged by LDS-DMA -- piece i = 6 * row + column IS byte 16 i of the window for row-major and, with tile
+    //  addresses, for tiled sources -- bit-exact, level chain 0.416-0.421 against 0.422-0.425 on packed input, +-0 in the bench: removed,
+    //  profiles/r06_level_chain.md)
     if (r0 < RPP && !tilepath) {
       if (interior && stiled) {
         // (vector-ALU build) an aligned dword of a tiled level lies inside one tile row: the same loads, tile addresses
