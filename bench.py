@@ -238,13 +238,14 @@ def per_frame_latency(cfg, n_frames: int):
         base = [exe, seq, "--features", str(cfg["nfeat"]), "--bf", str(cfg["bf"]), "--fx", str(cfg["fx"]), "--fy", str(cfg["fy"]),
                 "--cx", str(cfg["cx"]), "--cy", str(cfg["cy"]), "--th", str(cfg["th"])]
         usable = usable_cpus()   # affinity AND the cgroup quota: a GPU box shows 256 hardware threads and grants 16
-        threads = max(1, min(16, usable - 5))   # the tracking thread, the two extractor threads and the matcher adapter's two marshalling helpers keep a core each
+        threads = max(1, min(16, usable - 3))   # the tracking thread and the two extractor threads keep a core each
+        bthreads = max(1, min(16, usable - 1))  # the batched driver: one submitting thread beside the decode pool
         r = subprocess.run(base + ["--decode-threads", str(threads), "--prefetch", "32"], capture_output=True, text=True, timeout=600)
         r0 = subprocess.run(base + ["--decode-threads", "0"], capture_output=True, text=True, timeout=600)   # load, then track
         # the batched pipeline from the same C++ host (orbfe_pipeline_*): chunks of 256 pairs, PNGs decoded inside the clock
         # (decode-bound), and the sequence walked eight times from frames decoded before the clock (the pipeline itself, PCIe included)
-        rb = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--repeat", "4"], capture_output=True, text=True, timeout=600)
-        rp = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "1", "--repeat", "16"], capture_output=True, text=True, timeout=600)
+        rb = subprocess.run(base + ["--decode-threads", str(bthreads), "--batch", "256", "--repeat", "4"], capture_output=True, text=True, timeout=600)
+        rp = subprocess.run(base + ["--decode-threads", str(bthreads), "--batch", "256", "--preload", "1", "--repeat", "16"], capture_output=True, text=True, timeout=600)
         rq = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "2", "--repeat", "24"], capture_output=True, text=True, timeout=600)
         rd = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "144"], capture_output=True, text=True, timeout=600)
         # the same with orbfe_pipeline_config.output_mask: only the tracked assignments (+ the counts), only the counts copied to the host
