@@ -2423,6 +2423,9 @@ __device__ __forceinline__ void patch_store16(uint8_t* base, int r, int c, const
 #ifndef OD_FAKE_TILED_RAW
 #define OD_FAKE_TILED_RAW 0
 #endif
+#ifndef OD_FAKE_TABLES
+#define OD_FAKE_TABLES 0
+#endif
 #if FC_TIMING
 __device__ unsigned long long g_od_prof[4096 * 8];
 extern "C" int orbfe_debug_od_profile(unsigned long long* out, int reset) {
@@ -2468,13 +2471,21 @@ __global__ __launch_bounds__(256, OD_WGS) void orient_describe8_kernel(DescribeP
   const uint32_t e_lane = P.lvl_kp[(size_t)img * P.kp_per_image + slot_c];
   float4 pk[4];
 #pragma unroll
+#if OD_FAKE_TABLES   // timing experiment only (wrong results): no table loads
+  for (int r = 0; r < 4; r++) pk[r] = make_float4((float)(lane & 7) - 3.f, (float)(r * 2 + (lane >> 4)) - 5.f, (float)(lane & 15) - 8.f, (float)(r) - 2.f);
+#else
   for (int r = 0; r < 4; r++) pk[r] = *reinterpret_cast<const float4*>(&g_pattern_f[(r * 64 + lane) * 4]);
+#endif
   uint32_t wu[4], wv[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int it = lane + WAVE * j;   // items >= 248 carry zero weights
+#if OD_FAKE_TABLES
+    wu[j] = 0x01020304u * (uint32_t)(it & 7); wv[j] = 0x01010101u * (uint32_t)(it >> 3);
+#else
     const uint2 w2 = reinterpret_cast<const uint2*>(g_ic_w)[it];
     wu[j] = w2.x; wv[j] = w2.y;
+#endif
   }
 #if !OD_DMA_STAGE
   uint8_t* ori = &patch[wv_id][0];
