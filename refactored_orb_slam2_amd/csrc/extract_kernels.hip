@@ -507,12 +507,15 @@ extern "C" int orbfe_debug_fc_profile(unsigned long long* out, int reset) {
 #ifndef FC_WAVES_PER_EU
 #define FC_WAVES_PER_EU 7
 #endif
+#ifndef FC_WG_WAVES
+#define FC_WG_WAVES 4   // waves (= runs of cells) per workgroup; the waves share nothing, but a workgroup's LDS and wave slots are held until its last wave ends
+#endif
 // LDS bytes of one wave's slice: byte tile, score plane, bitmap of scored pixels (nbw words), survivor list
 __host__ __device__ inline int fc_wave_lds(int rows_max, int pb, int sc_bytes, int nbw) {
   return rows_max * pb + sc_bytes + nbw * 4 + FC_LIST_CAP * 2 + (FC_T2_QUEUE ? FC_Q1_CAP * 2 : 0) + FC_LDS_PAD;
 }
 template <int PB, int NLD>   // PB: bytes per staged row (64 or 96); NLD: load rounds of 64 lanes x 16 bytes per cell
-__global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
+__global__ __launch_bounds__(64 * FC_WG_WAVES, FC_WAVES_PER_EU) void fast_cells_kernel(PyrView pyr, const CellDesc* __restrict__ cells,
                                                           const FastGroup* __restrict__ runs, int n_runs, int total_cells,
                                                           int rows_max, int sc_bytes, int nbw, int32_t* __restrict__ cell_cnt,
                                                           uint32_t* __restrict__ slots, unsigned long long slots_per_image,
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
   uint16_t* q1 = list + FC_LIST_CAP;                            // ring of tier-1 survivors: tile index of a lane's pixel pair
 #endif
   int img = blockIdx.y;
-  const int nblk = (n_runs + 3) >> 2;
+  const int nblk = (n_runs + FC_WG_WAVES - 1) / FC_WG_WAVES;
   const int q = blockIdx.x >> 3;
   const int unit = 8 << (xcd_run_shift < 0 ? 0 : xcd_run_shift);
   int bid = (xcd_run_shift < 0 || (int)blockIdx.x >= (nblk / unit) * unit)
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256, FC_WAVES_PER_EU) void fast_cells_kernel(PyrVie
       bid = (int)(within >> 3);
     }
   }
-  const int rid = bid * 4 + wid;
+  const int rid = bid * FC_WG_WAVES + wid;
   if (rid >= n_runs) return;   // no barriers below
   const FastGroup g = runs[rid];
   const int level = g.level;
@@ -2918,11 +2921,11 @@ void orbfe_launch_fast_cells(const PyrView& pyr, const CellDesc* cells, const Fa
   const int pb = cell_span <= 64 ? 64 : 96;
   const int sc_bytes = (sc_max + 15) & ~15;
   const int nbw = bits_max <= 64 * 32 ? 64 : 128;   // bitmap words (lane l owns words l and l + 64)
-  const size_t lds = (size_t)4 * fc_wave_lds(cell_rows, pb, sc_bytes, nbw);
+  const size_t lds = (size_t)FC_WG_WAVES * fc_wave_lds(cell_rows, pb, sc_bytes, nbw);
   const bool small = cell_rows <= 48;   // a cell loads in three rounds of sixteen rows
-  dim3 grid4((n_groups + 3) / 4, n_images);
+  dim3 grid4((n_groups + FC_WG_WAVES - 1) / FC_WG_WAVES, n_images);
 #define FC_LAUNCH(PBV, NLDV)                                                                                                   \
-  hipLaunchKernelGGL((fast_cells_kernel<PBV, NLDV>), grid4, dim3(256), lds, s, pyr, cells, groups, n_groups, total_cells,       \
+  hipLaunchKernelGGL((fast_cells_kernel<PBV, NLDV>), grid4, dim3(64 * FC_WG_WAVES), lds, s, pyr, cells, groups, n_groups, total_cells,       \
                      cell_rows, sc_bytes, nbw, cell_cnt, slots, slots_per_image, ini_th, min_th, run_shift)
   if (lds > 48 * 1024) {   // never for the configured datasets (22 KB at KITTI); the largest cell (66 x 66) needs 46 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<96, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -62,8 +62,10 @@ struct CellDesc {
 };
 
 // A run of horizontally adjacent FAST cells of one cell row: one wave of fast_cells_kernel walks them one after the other
+#ifndef ORBFE_FG_MAX
 #define ORBFE_FG_MAX 4           // cells per run
 #define ORBFE_FG_MAX_WIDTH 176   // pixels a run may span
+#endif
 struct FastGroup {
   int32_t first_cell;            // index into the cell table; the group's cells are consecutive there
   int16_t n_cells, level;
