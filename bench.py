@@ -393,11 +393,12 @@ class StepRig:
     UnprojectStereo, the projection of L/src/ORBmatcher.cc:1270-1308, SearchByProjection(cur, last) :1247-1383) on a third; the sets
     take the steps in turn."""
 
-    def __init__(self, cfg, F, local=0, rank=0, n_sets=3, lr_streams=2, blur_kind=0):
+    def __init__(self, cfg, F, local=0, rank=0, n_sets=3, lr_streams=2, blur_kind=0, fused_queries=True):
         import torch
         from refactored_orb_slam2_amd import ORBextractor, synth
         from refactored_orb_slam2_amd.matcher import Matcher
         self.cfg, self.F, self.local = cfg, F, local
+        self.fused_queries = bool(fused_queries)
         W, H, NFEAT, STEREO = cfg["w"], cfg["h"], cfg["nfeat"], cfg["stereo"]
         self.W, self.H, self.NFEAT, self.STEREO = W, H, NFEAT, STEREO
         self.dev = dev = torch.device("cuda", local)
@@ -477,8 +478,18 @@ class StepRig:
             except Exception:
                 pass
 
+    def _queries(self, B, s):
+        """Frame::UnprojectStereo per keypoint with depth (L/src/Frame.cc:668-679), projected into the next frame (L/src/ORBmatcher.cc:1270-1308):
+        one pass (default) or the two calls with the 60-byte point records in between -- byte-equal queries either way
+        (tests/test_matcher_gpu.py)."""
+        from refactored_orb_slam2_amd.matcher import track_queries_batch, track_queries_stereo_batch, unproject_stereo_batch
+        if self.fused_queries:
+            track_queries_stereo_batch(B.kl, B.dl, B.nl, B.depth, self.t_cams, 1, self.t_poses, 1, B.q, B.nq, s)
+        else:
+            unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, self.t_cams, 1, B.pts, s)
+            track_queries_batch(self.t_poses, B.pts, B.nl, 1, B.q, B.nq, s)
+
     def _step(self, cur, B):
-        from refactored_orb_slam2_amd.matcher import track_queries_batch, unproject_stereo_batch
         cfg, W, H, STEREO = self.cfg, self.W, self.H, self.STEREO
         exL, exR, mt, sL, sR = self.exL, self.exR, self.mt, self.sL, self.sR
         if STEREO and self.lr["n"] == 2:
@@ -494,8 +505,7 @@ class StepRig:
         if STEREO:
             mt.stereo_match(exL, exR, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], self.mb, B.ur, B.depth, B.n_stereo, stream=cur)
         if cfg["match"] == "projection":
-            unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, self.t_cams, 1, B.pts, cur)   # Frame::UnprojectStereo per keypoint with depth
-            track_queries_batch(self.t_poses, B.pts, B.nl, 1, B.q, B.nq, cur)               # projected into the next frame (:1270-1308)
+            self._queries(B, cur)
             B.blocked.zero_(); B.assigned.fill_(-1)
             mt.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked,
                                 B.assigned, B.n_track, stream=cur)                    # SearchByProjection(cur, last, th)
@@ -507,7 +517,6 @@ class StepRig:
             self.gatherer.launch(B.nl, B.kl, B.dl)
 
     def _step_piped(self):
-        from refactored_orb_slam2_amd.matcher import track_queries_batch, unproject_stereo_batch
         cfg, W, H, sM, sL, sR = self.cfg, self.W, self.H, self.sM, self.sL, self.sR
         xl, xr, m, B, eL, eR, eT = self.pipe_sets[self.pipe_k % self.n_sets]
         self.pipe_k += 1
@@ -517,8 +526,7 @@ class StepRig:
         eL.record(sL); eR.record(sR)
         sM.wait_event(eL); sM.wait_event(eR)
         m.stereo_match(xl, xr, B.kl, B.dl, B.nl, B.kr, B.dr, B.nr, cfg["bf"], self.mb, B.ur, B.depth, B.n_stereo, stream=sM)
-        unproject_stereo_batch(B.kl, B.dl, B.nl, B.depth, self.t_cams, 1, B.pts, sM)
-        track_queries_batch(self.t_poses, B.pts, B.nl, 1, B.q, B.nq, sM)
+        self._queries(B, sM)
         B.blocked.zero_(); B.assigned.fill_(-1)
         m.proj_match_batch(B.kl, B.dl, B.nl, B.ur, (0.0, float(W), 0.0, float(H)), B.q, B.nq, 1, 0.9, True, B.blocked, B.assigned,
                            B.n_track, stream=sM)
@@ -653,6 +661,10 @@ def main():
     ap.add_argument("--cabi-outputs", type=int, default=8, help="orbfe_pipeline_config.output_mask of the C-ABI driver (8: tracked assignments + counts, "
                                                                  "16: counts only, 0: every block)")
     ap.add_argument("--cabi-steps", type=int, default=120, help="chunks timed through the C-ABI driver (0 = skip)")
+    ap.add_argument("--queries", choices=("fused", "two_pass"), default="fused",
+                    help="fused (default): UnprojectStereo + the projection of SearchByProjection(cur, last) in one pass "
+                         "(orbfe_track_queries_stereo_device); two_pass: orbfe_unproject_stereo_device -> 60-byte point records -> "
+                         "orbfe_track_queries_device (rounds 3-5).  Byte-equal queries")
     ap.add_argument("--lr-streams", type=int, default=2, choices=(1, 2),
                     help="2 (default): left / right extractor on two HIP streams, as the reference runs them on two threads (Frame.cc:87-90): "
                          "their launches overlap and fill each other's tails; 1: one stream, every kernel alone on the chip (the per-stage times "
@@ -671,7 +683,7 @@ def main():
     import torch
     import torch.distributed as dist
     from refactored_orb_slam2_amd import ORBextractor, synth
-    from refactored_orb_slam2_amd.matcher import Matcher, track_queries_batch, unproject_stereo_batch
+    from refactored_orb_slam2_amd.matcher import Matcher
     from refactored_orb_slam2_amd.sharding import AsyncGather, CabiAsyncGather, gather_traffic
 
     cfg = CONFIGS[args.config]
@@ -697,7 +709,8 @@ def main():
             dist.init_process_group(backend)
 
     F = args.frames
-    rig = StepRig(cfg, F, local=local, rank=rank, n_sets=args.sets, lr_streams=args.lr_streams, blur_kind=args.blur_kind)
+    rig = StepRig(cfg, F, local=local, rank=rank, n_sets=args.sets, lr_streams=args.lr_streams, blur_kind=args.blur_kind,
+                  fused_queries=args.queries == "fused")
     import atexit
     atexit.register(rig.close)
     rig.world, rig._dist = world, dist
@@ -1074,6 +1087,9 @@ def main():
                          "stage_ms_per_batch": {k: round(v, 4) for k, v in per_launch_ms.items()}},
         }
         out["config"]["driver"] = args.driver
+        if cfg["match"] == "projection":
+            out["config"]["queries"] = ("one pass: orbfe_track_queries_stereo_device" if rig.fused_queries
+                                        else "two passes: orbfe_unproject_stereo_device + orbfe_track_queries_device")
         if cabi is not None:
             out["config"]["cabi_driver"] = cabi
         if args.driver == "cabi":

@@ -364,6 +364,21 @@ int orbfe_track_queries_device(int n_frames, const orbfe_track_pose* d_pose, con
                                const int32_t* d_n_points, int p_cap, int frame_shift, orbfe_query* d_queries,
                                int32_t* d_nq, void* stream);
 
+/* The two calls above in one pass, for callers that need the stereo points only as the next frame's search queries (a tracking
+ * loop that creates its temporal points from the stereo depth, L/src/Tracking.cc:877-936 UpdateLastFrame, then runs
+ * SearchByProjection(cur, last)): queries of frame f from the KEYPOINTS of frame f - frame_shift -- UnprojectStereo with that frame's
+ * camera (L/src/Frame.cc:668-679), then the projection with frame f's pose (L/src/ORBmatcher.cc:1270-1308) -- without the 60-byte
+ * point record per keypoint going through memory.  Byte-equal to orbfe_unproject_stereo_device + orbfe_track_queries_device.
+ * Frames in front of the batch (f < frame_shift): the carry frame when the five d_carry_* arrays are given (one frame: [cap]
+ * keypoints / descriptors / depth, one count, one camera -- the last frame of the batch before), otherwise the batch's own tail
+ * (index mod n_frames, as orbfe_track_queries_device).  d_nq[f] = keypoint count of the source frame. */
+int orbfe_track_queries_stereo_device(int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                      const float* d_depth, int cap, const orbfe_unproject_cam* d_cam, int observed,
+                                      const orbfe_keypoint* d_carry_kps, const uint8_t* d_carry_desc, const int32_t* d_carry_n,
+                                      const float* d_carry_depth, const orbfe_unproject_cam* d_carry_cam,
+                                      const orbfe_track_pose* d_pose, int frame_shift, orbfe_query* d_queries, int32_t* d_nq,
+                                      void* stream);
+
 /* SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (L/src/ORBmatcher.cc:161-273), entirely on the device.
  * A DBoW2::FeatureVector is passed as its nodes sorted by id, each {node_id, start, count} into an index array
  * (nodesA/idxA = pKF->mFeatVec, nodesB/idxB = F.mFeatVec).  validA[i] != 0 <=> keyframe feature i has a map point

@@ -99,7 +99,7 @@ EXPORTS = [
     "orbfe_hamming_matrix_device", "orbfe_hamming_bf_device", "orbfe_proj_candidates",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_frame", "orbfe_stereo_match_device", "orbfe_stereo_match",
     "orbfe_search_for_initialization", "orbfe_search_by_bow", "orbfe_search_by_bow_kf", "orbfe_search_for_triangulation", "orbfe_proj_best", "orbfe_kf_search", "orbfe_search_by_projection_keyframe", "orbfe_search_local_points",
-    "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device",
+    "orbfe_search_local_points_batch_device", "orbfe_unproject_stereo_device", "orbfe_track_queries_device", "orbfe_track_queries_stereo_device",
     "orbfe_vocabulary_create", "orbfe_vocabulary_load_text", "orbfe_vocabulary_load_binary", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_bow_transform_device", "orbfe_compute_bow", "orbfe_png_info", "orbfe_png_info2", "orbfe_png_read_gray", "orbfe_png_read_gray2", "orbfe_png_read_gray16",
     "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_input", "orbfe_pipeline_submit", "orbfe_pipeline_wait",
@@ -177,6 +177,7 @@ def lib():
     L.orbfe_search_by_projection_frame.argtypes = [C.POINTER(FrameView), vp, ci, ci, vp, vp, pi]
     L.orbfe_unproject_stereo_device.argtypes = [ci, vp, vp, vp, vp, ci, vp, ci, vp, vp]
     L.orbfe_track_queries_device.argtypes = [ci, vp, vp, vp, ci, ci, vp, vp, vp]
+    L.orbfe_track_queries_stereo_device.argtypes = [ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]
     L.orbfe_search_local_points.argtypes = [C.POINTER(FrameView), vp, vp, ci, cf, cf, vp, vp, vp, pi, pi]
     L.orbfe_search_local_points_batch_device.argtypes = [vp, ci, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, ci, cf, cf,
                                                          vp, vp, vp, vp, vp, vp]

@@ -267,6 +267,83 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
   for (int i = tid; i < cnt * Q_DW; i += 256) out[i] = rec[i];
 }
 
+// ---- UnprojectStereo + the projection of SearchByProjection(cur, last) in one pass (L/src/Frame.cc:668-679, L/src/ORBmatcher.cc:1270-1308):
+// thread per keypoint of the SOURCE frame.  The two kernels above hand a 60-byte point record per keypoint through HBM (written, read
+// once, never used again when the points only feed the next frame's search): here the world point stays in registers -- the same float
+// expressions in the same order, so the queries are byte-equal to unproject_stereo_kernel -> track_queries_kernel.  Source of frame f:
+// frame f - frame_shift of the batch; in front of the batch the carry frame (`carry` != 0: the last frame of the batch before) or, without
+// one, the batch's own tail (mod n_frames: what track_queries_kernel does).
+struct TqsFrame {   // one source frame's arrays
+  const orbfe_keypoint* kps; const uint8_t* desc; const int32_t* n; const float* depth; const orbfe_unproject_cam* cam;
+};
+__global__ __launch_bounds__(256) void track_queries_stereo_kernel(TqsFrame B, TqsFrame Cy, int carry, int cap, int n_frames, int frame_shift,
+                                                                   int observed, const orbfe_track_pose* __restrict__ poses,
+                                                                   orbfe_query* __restrict__ queries, int32_t* __restrict__ nq) {
+  __shared__ uint32_t rec[256 * Q_DW];   // the block's queries leave as coalesced dwords instead of 68-byte strided stores
+  const int f = blockIdx.y, tid = threadIdx.x, p0 = blockIdx.x * 256;
+  int fs = f - frame_shift;
+  const bool from_carry = fs < 0 && carry;
+  if (!from_carry) { fs %= n_frames; if (fs < 0) fs += n_frames; }
+  const TqsFrame S = from_carry ? Cy : B;
+  if (from_carry) fs = 0;
+  const int np = S.n[fs];
+  if (p0 == 0 && tid == 0) nq[f] = np;
+  const int cnt = min(256, cap - p0);          // query slots this block owns
+  const int have = max(0, min(cnt, np - p0));  // of which backed by a keypoint
+  orbfe_query q;
+  uint32_t* qw = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+  for (int j = 0; j < Q_DW; j++) qw[j] = 0u;
+  if (tid < have) {
+    const size_t g = (size_t)fs * cap + p0 + tid;
+    const float z = S.depth[g];
+    const orbfe_keypoint kp = S.kps[g];
+    const uint4* d = reinterpret_cast<const uint4*>(S.desc + g * 32);
+    const uint4 d0 = d[0], d1 = d[1];
+    if (z > 0) {
+      const orbfe_unproject_cam c = S.cam[fs];
+      const orbfe_track_pose P = poses[f];
+      const float x = (kp.x - c.cx) * z * c.invfx;
+      const float y = (kp.y - c.cy) * z * c.invfy;
+      float pos[3], xc3[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {   // mRwc * x3Dc + mOw: cv::gemm small-matrix path (float dot, double epilogue)
+        const float t = c.Rwc[3 * r] * x + c.Rwc[3 * r + 1] * y + c.Rwc[3 * r + 2] * z;
+        pos[r] = (float)((double)t * 1.0 + (double)c.Ow[r] * 1.0);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) {   // Rcw * x3Dw + tcw
+        const float t = P.Rcw[3 * r] * pos[0] + P.Rcw[3 * r + 1] * pos[1] + P.Rcw[3 * r + 2] * pos[2];
+        xc3[r] = (float)((double)t * 1.0 + (double)P.tcw[r] * 1.0);
+      }
+      const float invzc = (float)(1.0 / (double)xc3[2]);   // `1.0 / x3Dc.at<float>(2)`: double division (:1283)
+      if (!(invzc < 0)) {
+        const float u = P.fx * xc3[0] * invzc + P.cx;
+        const float v = P.fy * xc3[1] * invzc + P.cy;
+        if (!(u < P.min_x || u > P.max_x) && !(v < P.min_y || v > P.max_y)) {
+          const int oct = kp.octave;
+          q.u = u; q.v = v;
+          q.u_r = u - P.mbf * invzc;                                   // :1327
+          q.radius = P.th * P.scale_factors[oct & (ORBFE_MAX_LEVELS - 1)];   // :1297
+          if (P.forward) { q.min_level = oct; q.max_level = -1; }
+          else if (P.backward) { q.min_level = 0; q.max_level = oct; }
+          else { q.min_level = oct - 1; q.max_level = oct + 1; }
+          q.valid = 1;
+          q.blocks = observed != 0;
+          q.angle = kp.angle;
+          uint32_t* dw = reinterpret_cast<uint32_t*>(q.desc);
+          dw[0] = d0.x; dw[1] = d0.y; dw[2] = d0.z; dw[3] = d0.w; dw[4] = d1.x; dw[5] = d1.y; dw[6] = d1.z; dw[7] = d1.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < Q_DW; j++) rec[tid * Q_DW + j] = qw[j];
+  __syncthreads();
+  uint32_t* out = reinterpret_cast<uint32_t*>(queries + (size_t)f * cap + p0);
+  for (int i = tid; i < cnt * Q_DW; i += 256) out[i] = rec[i];
+}
+
 // ---- projection prologue of Fuse / Fuse(Sim3) / SearchBySim3 / SearchByProjection(KF,Scw) / SearchByProjection(Frame,KF,...)
 // (L/src/ORBmatcher.cc:785-816, 925-977, 1075-1113 & 1155-1192, 296-345, 1406-1437): thread per candidate map point.  Every
 // float expression is written in the operation order of the mode's reference lines (`1 / z` is a float division, `1.0 / z` a
@@ -375,6 +452,16 @@ void orbfe_launch_track_queries(const orbfe_track_pose* poses, const orbfe_last_
                                 int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames, hipStream_t s) {
   hipLaunchKernelGGL(track_queries_kernel, dim3((p_cap + 255) / 256, n_frames), dim3(256), 0, s, poses, points, n_points, p_cap,
                      n_frames, frame_shift, queries, nq);
+}
+
+void orbfe_launch_track_queries_stereo(const orbfe_keypoint* kps, const uint8_t* desc, const int32_t* n, const float* depth, int cap,
+                                       const orbfe_unproject_cam* cams, int observed, const orbfe_keypoint* c_kps, const uint8_t* c_desc,
+                                       const int32_t* c_n, const float* c_depth, const orbfe_unproject_cam* c_cam,
+                                       const orbfe_track_pose* poses, int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames,
+                                       hipStream_t s) {
+  const TqsFrame B{kps, desc, n, depth, cams}, Cy{c_kps, c_desc, c_n, c_depth, c_cam};
+  hipLaunchKernelGGL(track_queries_stereo_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, s, B, Cy, c_kps ? 1 : 0, cap, n_frames,
+                     frame_shift, observed, poses, queries, nq);
 }
 
 void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,

@@ -80,6 +80,11 @@ void orbfe_launch_unproject_stereo(const orbfe_keypoint* kps, const uint8_t* des
                                    hipStream_t s);
 void orbfe_launch_track_queries(const orbfe_track_pose* poses, const orbfe_last_point* points, const int32_t* n_points, int p_cap,
                                 int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames, hipStream_t s);
+void orbfe_launch_track_queries_stereo(const orbfe_keypoint* kps, const uint8_t* desc, const int32_t* n, const float* depth, int cap,
+                                       const orbfe_unproject_cam* cams, int observed, const orbfe_keypoint* c_kps, const uint8_t* c_desc,
+                                       const int32_t* c_n, const float* c_depth, const orbfe_unproject_cam* c_cam,
+                                       const orbfe_track_pose* poses, int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames,
+                                       hipStream_t s);
 void orbfe_launch_frustum_queries(const orbfe_frustum* frustums, const orbfe_map_point* points, const int32_t* n_points,
                                   int p_cap, float th, float viewing_cos_limit, orbfe_track* track, orbfe_query* queries,
                                   int32_t* n_to_match, int n_frames, hipStream_t s);

@@ -403,6 +403,29 @@ extern "C" int orbfe_track_queries_device(int n_frames, const orbfe_track_pose* 
   return launch_ok();
 }
 
+extern "C" int orbfe_track_queries_stereo_device(int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                                 const float* d_depth, int cap, const orbfe_unproject_cam* d_cam, int observed,
+                                                 const orbfe_keypoint* d_carry_kps, const uint8_t* d_carry_desc,
+                                                 const int32_t* d_carry_n, const float* d_carry_depth,
+                                                 const orbfe_unproject_cam* d_carry_cam, const orbfe_track_pose* d_pose,
+                                                 int frame_shift, orbfe_query* d_queries, int32_t* d_nq, void* stream) {
+  if (!d_kps || !d_desc || !d_n || !d_depth || !d_cam || !d_pose || !d_queries || !d_nq || n_frames < 1 || cap < 1 || frame_shift < 0)
+    return ORBFE_ERR_INVALID;
+  const bool carry = d_carry_kps || d_carry_desc || d_carry_n || d_carry_depth || d_carry_cam;
+  if (carry && !(d_carry_kps && d_carry_desc && d_carry_n && d_carry_depth && d_carry_cam)) {
+    orbfe_set_error("the carry frame needs all five arrays (keypoints, descriptors, count, depth, camera) or none");
+    return ORBFE_ERR_INVALID;
+  }
+  if (((uintptr_t)d_desc & 15) || ((uintptr_t)d_carry_desc & 15) || ((uintptr_t)d_kps & 3) || ((uintptr_t)d_carry_kps & 3) ||
+      ((uintptr_t)d_cam & 3) || ((uintptr_t)d_carry_cam & 3) || ((uintptr_t)d_pose & 3) || ((uintptr_t)d_queries & 3)) {
+    orbfe_set_error("descriptors must be 16-byte aligned, records 4-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  orbfe_launch_track_queries_stereo(d_kps, d_desc, d_n, d_depth, cap, d_cam, observed, d_carry_kps, d_carry_desc, d_carry_n, d_carry_depth,
+                                    d_carry_cam, d_pose, frame_shift, d_queries, d_nq, n_frames, (hipStream_t)stream);
+  return launch_ok();
+}
+
 // ---- Tracking::SearchLocalPoints (L/src/Tracking.cc:1050-1078): isInFrustum -> queries (in HBM) -> SearchByProjection
 static int local_points_enqueue(orbfe_matcher* m, int n_frames, const orbfe_keypoint* d_kps, const uint8_t* d_desc,
                                 const int32_t* d_n, const float* d_ur, int cap, float min_x, float max_x, float min_y,

@@ -1,6 +1,6 @@
 // pipeline.cpp -- the batched stereo front-end step behind one handle, for hosts that do not link the HIP runtime
 // (include/orbfe.h: orbfe_pipeline_*).  Nothing here is a second code path: a chunk runs the public device entry points
-// (orbfe_extract_batch_device x 2, orbfe_stereo_match_device, orbfe_unproject_stereo_device, orbfe_track_queries_device,
+// (orbfe_extract_batch_device x 2, orbfe_stereo_match_device, orbfe_track_queries_stereo_device,
 // orbfe_proj_match_batch_device) on the handle's compute stream; what the handle adds is ownership -- pinned pitched host
 // images, device buffers, three streams and the events that order copy-in / compute / copy-out of `slots` buffer sets -- i.e.
 // what `bench.py` and `examples/stereo_kitti.py` borrow from torch.
@@ -99,10 +99,10 @@ struct orbfe_pipeline {
   // copy in | left extractor | right extractor | matching half (stereo match ... projection search) | copy out | record gather
   hipStream_t s_in = nullptr, s_l = nullptr, s_r = nullptr, s_cmp = nullptr, s_out = nullptr, s_gat = nullptr;
   std::vector<Slot> slots;
-  // shared by the chunks (the matching halves run on ONE stream, strictly ordered): the stereo points of the chunk's frames behind the carried
-  // last frame of the previous chunk (row 0), and the queries projected from them
-  orbfe_last_point* d_pts = nullptr;   // [batch + 1][cap]
-  int32_t* d_npts = nullptr;           // [batch + 1]
+  // shared by the chunks (the matching halves run on ONE stream, strictly ordered): the last frame of the chunk before (descriptors |
+  // keypoints | stereo depth | camera | count -- what the first frame of a chunk is searched with) and the queries of the chunk's frames
+  uint8_t* d_carry = nullptr;
+  size_t cy_kps = 0, cy_depth = 0, cy_cam = 0, cy_n = 0, cy_bytes = 0;
   orbfe_query* d_q = nullptr;          // [batch][cap]
   int32_t* d_nq = nullptr;             // [batch]
   std::mutex mu;
@@ -124,7 +124,7 @@ static void pipeline_free(orbfe_pipeline* p) {
     for (hipEvent_t e : {s.ev_in, s.ev_done, s.ev_out, s.ev_gather, s.ev_l, s.ev_r})
       if (e) (void)hipEventDestroy(e);
   }
-  for (void* d : {(void*)p->d_pts, (void*)p->d_npts, (void*)p->d_q, (void*)p->d_nq})
+  for (void* d : {(void*)p->d_carry, (void*)p->d_q, (void*)p->d_nq})
     if (d) (void)hipFree(d);
   for (hipStream_t s : {p->s_in, p->s_l, p->s_r, p->s_cmp, p->s_out, p->s_gat})
     if (s) (void)hipStreamDestroy(s);
@@ -235,12 +235,15 @@ static int pipeline_build(orbfe_pipeline* p) {
       PCHK(hipStreamCreateWithPriority(&p->s_gat, hipStreamNonBlocking, prio_mid));
       break;
   }
-  PCHK(hipMalloc((void**)&p->d_pts, sizeof(orbfe_last_point) * (size_t)(F + 1) * cap));
-  PCHK(hipMalloc((void**)&p->d_npts, sizeof(int32_t) * (F + 1)));
+  p->cy_kps = (size_t)cap * 32;
+  p->cy_depth = p->cy_kps + (size_t)cap * sizeof(orbfe_keypoint);
+  p->cy_cam = p->cy_depth + (size_t)cap * sizeof(float);
+  p->cy_n = p->cy_cam + sizeof(orbfe_unproject_cam);
+  p->cy_bytes = p->cy_n + sizeof(int32_t);
+  PCHK(hipMalloc((void**)&p->d_carry, p->cy_bytes));
   PCHK(hipMalloc((void**)&p->d_q, sizeof(orbfe_query) * (size_t)F * cap));
   PCHK(hipMalloc((void**)&p->d_nq, sizeof(int32_t) * F));
-  PCHK(hipMemset(p->d_npts, 0, sizeof(int32_t) * (F + 1)));
-  PCHK(hipMemset(p->d_pts, 0, sizeof(orbfe_last_point) * (size_t)(F + 1) * cap));
+  PCHK(hipMemset(p->d_carry, 0, p->cy_bytes));
   float sf[ORBFE_MAX_LEVELS] = {0};
   RCHK(orbfe_extractor_scale_factors(p->slots[0].ex_l, sf));
   for (Slot& s : p->slots) {
@@ -310,7 +313,7 @@ static int pipeline_build(orbfe_pipeline* p) {
       memset(sk.h_in + p->in_left, 0, p->image_bytes * F);
       memset(sk.h_in + p->in_right, 0, p->image_bytes * F);
     }
-    PCHK(hipMemset(p->d_npts, 0, sizeof(int32_t) * (F + 1)));   // the warm-up chunk is nobody's predecessor
+    PCHK(hipMemset(p->d_carry + p->cy_n, 0, sizeof(int32_t)));   // the warm-up chunk is nobody's predecessor
   }
   return ORBFE_OK;
 }
@@ -456,10 +459,14 @@ static int submit_chunk(orbfe_pipeline* p, int slot, int n, int has_predecessor,
     PCHK(hipStreamWaitEvent(cs, s.ev_r, 0));
     RCHK(orbfe_stereo_match_device(s.mt, s.ex_l, s.ex_r, n, d_kl, d_dl, d_nl, s.d_kps_r, s.d_desc_r, d_nr, cap, c.bf,
                                    c.bf / c.fx, d_ur, d_depth, d_nst, cs));
-    // the stereo points of frame j go to row j + 1; frame j is searched with the points of row j (row 0: the previous chunk's last)
-    RCHK(orbfe_unproject_stereo_device(n, d_kl, d_dl, d_nl, d_depth, cap, d_cams, 1, p->d_pts + (size_t)cap, cs));
-    PCHK(hipMemcpyAsync(p->d_npts + 1, d_nl, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, cs));
-    RCHK(orbfe_track_queries_device(n, d_poses, p->d_pts, p->d_npts, cap, 0, p->d_q, p->d_nq, cs));
+    // frame j is searched with the stereo points of frame j - 1 (frame 0: of the carried last frame of the chunk before); the points are
+    // unprojected and projected in one pass, no point records in between
+    RCHK(orbfe_track_queries_stereo_device(n, d_kl, d_dl, d_nl, d_depth, cap, d_cams, 1,
+                                           reinterpret_cast<const orbfe_keypoint*>(p->d_carry + p->cy_kps), p->d_carry,
+                                           reinterpret_cast<const int32_t*>(p->d_carry + p->cy_n),
+                                           reinterpret_cast<const float*>(p->d_carry + p->cy_depth),
+                                           reinterpret_cast<const orbfe_unproject_cam*>(p->d_carry + p->cy_cam), d_poses, 1, p->d_q,
+                                           p->d_nq, cs));
     PCHK(hipMemsetAsync(s.d_blocked, 0, (size_t)n * cap, cs));
     PCHK(hipMemsetAsync(d_assigned, 0xff, sizeof(int32_t) * (size_t)n * cap, cs));
     RCHK(orbfe_proj_match_batch_device(s.mt, n, d_kl, d_dl, d_nl, d_ur, cap, 0.0f, (float)c.width, 0.0f, (float)c.height, p->d_q,
@@ -468,9 +475,13 @@ static int submit_chunk(orbfe_pipeline* p, int slot, int n, int has_predecessor,
       PCHK(hipMemsetAsync(d_ntr, 0, sizeof(int32_t), cs));
       PCHK(hipMemsetAsync(d_assigned, 0xff, sizeof(int32_t) * (size_t)cap, cs));
     }
-    // carry: the last frame's points become row 0 of the next chunk
-    PCHK(hipMemcpyAsync(p->d_pts, p->d_pts + (size_t)n * cap, sizeof(orbfe_last_point) * (size_t)cap, hipMemcpyDeviceToDevice, cs));
-    PCHK(hipMemcpyAsync(p->d_npts, p->d_npts + n, sizeof(int32_t), hipMemcpyDeviceToDevice, cs));
+    // carry: the last frame's keypoints, descriptors, depth, camera and count for the first frame of the next chunk
+    const size_t last = (size_t)(n - 1) * cap;
+    PCHK(hipMemcpyAsync(p->d_carry, d_dl + last * 32, (size_t)cap * 32, hipMemcpyDeviceToDevice, cs));
+    PCHK(hipMemcpyAsync(p->d_carry + p->cy_kps, d_kl + last, (size_t)cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToDevice, cs));
+    PCHK(hipMemcpyAsync(p->d_carry + p->cy_depth, d_depth + last, (size_t)cap * sizeof(float), hipMemcpyDeviceToDevice, cs));
+    PCHK(hipMemcpyAsync(p->d_carry + p->cy_cam, d_cams + (n - 1), sizeof(orbfe_unproject_cam), hipMemcpyDeviceToDevice, cs));
+    PCHK(hipMemcpyAsync(p->d_carry + p->cy_n, d_nl + (n - 1), sizeof(int32_t), hipMemcpyDeviceToDevice, cs));
   }
   PCHK(hipEventRecord(s.ev_done, cs));
   // ---- copy out: the whole block in one copy, or the blocks the configuration asks for (the counts always: they lead the block)

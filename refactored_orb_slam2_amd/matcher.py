@@ -291,6 +291,18 @@ def track_queries_batch(poses, points, n_points, frame_shift, queries, nq, strea
                "orbfe_track_queries_device")
 
 
+def track_queries_stereo_batch(kps, desc, n, depth, cams, observed, poses, frame_shift, queries, nq, stream, carry=None):
+    """unproject_stereo_batch + track_queries_batch in one pass (orbfe_track_queries_stereo_device): the queries of frame f from the
+    keypoints / stereo depth of frame f - frame_shift, no point records through memory.  `carry` = (kps (cap,28), desc (cap,32),
+    n (1), depth (cap), cam (64)) of the frame in front of the batch, or None: the batch's own tail (index mod F)."""
+    F, cap = desc.shape[0], desc.shape[1]
+    c = [_lib.ptr(t) for t in carry] if carry is not None else [None] * 5
+    _lib.check(_lib.lib().orbfe_track_queries_stereo_device(F, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n), _lib.ptr(depth), cap,
+                                                            _lib.ptr(cams), int(observed), c[0], c[1], c[2], c[3], c[4], _lib.ptr(poses),
+                                                            int(frame_shift), _lib.ptr(queries), _lib.ptr(nq), _lib.stream_handle(stream)),
+               "orbfe_track_queries_stereo_device")
+
+
 def featvec_arrays(groups: dict):
     """{node_id: [indices]} -> (ctypes array of orbfe_featvec_node sorted by id, count, flat int32 index array)."""
     ids = sorted(groups)

@@ -373,6 +373,27 @@ def test_unproject_and_track_queries_device(mode):
         assert int(t_nm[j]) == onm
         np.testing.assert_array_equal(t_assigned[j].cpu().numpy()[: len(kj)], oassigned)
     assert tot_valid > 0.4 * int(n.sum())
+    # ---- the same queries in ONE pass (orbfe_track_queries_stereo_device: no point records in between): every byte of the query array,
+    #      rows behind a frame's count included.  Frame 0's source: the batch's tail (as above), or a carry frame holding the same data.
+    from refactored_orb_slam2_amd.matcher import track_queries_stereo_batch
+    for carry in (None, (t_kps[F - 1].clone(), t_desc[F - 1].clone(), t_n[F - 1:].clone(), t_depth[F - 1].clone(), t_cams[F - 1].clone())):
+        t_q2 = torch.full((F, cap, 68), 0xAB, dtype=torch.uint8, device="cuda")
+        t_nq2 = torch.full((F,), -5, dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(s):
+            track_queries_stereo_batch(t_kps, t_desc, t_n, t_depth, t_cams, 1, t_poses, 1, t_q2, t_nq2, s, carry=carry)
+        s.synchronize()
+        assert torch.equal(t_q2, t_q) and torch.equal(t_nq2, t_nq)
+        for i, (k1, d1, _) in enumerate(frames):   # ... and against the oracle directly
+            j = (i + 1) % F
+            oq = ol.track_queries(poses[j:j + 1], ol.unproject_stereo(cams[i:i + 1], k1, d1, depth[i]))
+            assert t_q2[j].cpu().numpy().reshape(cap * 68).view(QUERY_DTYPE)[:len(k1)].tobytes() == oq.tobytes()
+    # frame_shift 0: every frame's own keypoints with its own pose
+    with torch.cuda.stream(s):
+        track_queries_batch(t_poses, t_pts, t_n, 0, t_q, t_nq, s)
+        t_q2.fill_(0xCD); t_nq2.fill_(-7)
+        track_queries_stereo_batch(t_kps, t_desc, t_n, t_depth, t_cams, 1, t_poses, 0, t_q2, t_nq2, s)
+    s.synchronize()
+    assert torch.equal(t_q2, t_q) and torch.equal(t_nq2, t_nq)
     m.close()
 
 
