@@ -1303,6 +1303,9 @@ struct SmLevel {
 #define SM_ROUNDS 2
 #endif
 // SM_ROUNDS: bucket entries requested up front per keypoint: SM_ROUNDS * SM_G
+#ifndef SM_SAD_T
+#define SM_SAD_T 8   // rounds of 16 window pixels (timing experiments only: fewer = wrong sums)
+#endif
 #define SAD_LP 32   // LDS pitch of the staged left window: 11 pixels at byte offset <= 15 of two aligned 16-byte pieces
 #define SAD_RP 48   // LDS pitch of the staged right window: 21 pixels at byte offset <= 15 of three aligned 16-byte pieces
 #define SAD_WIN (11 * SAD_LP + 11 * SAD_RP + 16)   // a multiple of 16: every keypoint's slice starts 16-byte aligned
@@ -1493,7 +1496,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(StereoParams P) {
 #pragma unroll
   for (int k = 0; k < 11; k++) acc[k] = 0;
 #pragma unroll
-  for (int t = 0; t < 8; t++) {
+  for (int t = 0; t < SM_SAD_T; t++) {
     const int p = sub + SM_G * t;
     if (t < 7 || p < 121) {
       const unsigned a = (unsigned)((int)WL[s_offL[p]] - cLm);
