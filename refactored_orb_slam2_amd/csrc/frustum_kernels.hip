@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
 #pragma unroll
   for (int j = 0; j < Q_DW; j++) qw[j] = 0u;
   if (tid < have) {
-    const orbfe_track_pose P = poses[f];
+    const orbfe_track_pose& P = poses[f];   // (by reference: see track_queries_stereo_kernel)
     orbfe_last_point lp;
     uint32_t* lw = reinterpret_cast<uint32_t*>(&lp);
 #pragma unroll
@@ -273,14 +273,20 @@ __global__ __launch_bounds__(256) void track_queries_kernel(const orbfe_track_po
 // expressions in the same order, so the queries are byte-equal to unproject_stereo_kernel -> track_queries_kernel.  Source of frame f:
 // frame f - frame_shift of the batch; in front of the batch the carry frame (`carry` != 0: the last frame of the batch before) or, without
 // one, the batch's own tail (mod n_frames: what track_queries_kernel does).
+#ifndef TQS_DIRECT
+#define TQS_DIRECT 0
+#endif
+#ifndef TQS_T
+#define TQS_T 256   // keypoints (threads) per workgroup
+#endif
 struct TqsFrame {   // one source frame's arrays
   const orbfe_keypoint* kps; const uint8_t* desc; const int32_t* n; const float* depth; const orbfe_unproject_cam* cam;
 };
-__global__ __launch_bounds__(256) void track_queries_stereo_kernel(TqsFrame B, TqsFrame Cy, int carry, int cap, int n_frames, int frame_shift,
+__global__ __launch_bounds__(TQS_T) void track_queries_stereo_kernel(TqsFrame B, TqsFrame Cy, int carry, int cap, int n_frames, int frame_shift,
                                                                    int observed, const orbfe_track_pose* __restrict__ poses,
                                                                    orbfe_query* __restrict__ queries, int32_t* __restrict__ nq) {
-  __shared__ uint32_t rec[256 * Q_DW];   // the block's queries leave as coalesced dwords instead of 68-byte strided stores
-  const int f = blockIdx.y, tid = threadIdx.x, p0 = blockIdx.x * 256;
+  __shared__ uint32_t rec[TQS_T * Q_DW];   // the block's queries leave as coalesced dwords instead of 68-byte strided stores
+  const int f = blockIdx.y, tid = threadIdx.x, p0 = blockIdx.x * TQS_T;
   int fs = f - frame_shift;
   const bool from_carry = fs < 0 && carry;
   if (!from_carry) { fs %= n_frames; if (fs < 0) fs += n_frames; }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256) void track_queries_stereo_kernel(TqsFrame B, T
   if (from_carry) fs = 0;
   const int np = S.n[fs];
   if (p0 == 0 && tid == 0) nq[f] = np;
-  const int cnt = min(256, cap - p0);          // query slots this block owns
+  const int cnt = min(TQS_T, cap - p0);          // query slots this block owns
   const int have = max(0, min(cnt, np - p0));  // of which backed by a keypoint
   orbfe_query q;
   uint32_t* qw = reinterpret_cast<uint32_t*>(&q);
@@ -302,7 +308,9 @@ __global__ __launch_bounds__(256) void track_queries_stereo_kernel(TqsFrame B, T
     const uint4 d0 = d[0], d1 = d[1];
     if (z > 0) {
       const orbfe_unproject_cam c = S.cam[fs];
-      const orbfe_track_pose P = poses[f];
+      // (read through the pointer: a by-value copy indexed with the per-lane octave below lives in scratch memory -- 164 bytes written
+      //  and read back per thread, the kernel's whole time in rounds 3-5)
+      const orbfe_track_pose& P = poses[f];
       const float x = (kp.x - c.cx) * z * c.invfx;
       const float y = (kp.y - c.cy) * z * c.invfy;
       float pos[3], xc3[3];
@@ -337,11 +345,19 @@ __global__ __launch_bounds__(256) void track_queries_stereo_kernel(TqsFrame B, T
       }
     }
   }
+#if TQS_DIRECT   // 68-byte strided stores straight from the registers
+  if (tid < cnt) {
+    uint32_t* out = reinterpret_cast<uint32_t*>(queries + (size_t)f * cap + p0 + tid);
+#pragma unroll
+    for (int j = 0; j < Q_DW; j++) out[j] = qw[j];
+  }
+#else
 #pragma unroll
   for (int j = 0; j < Q_DW; j++) rec[tid * Q_DW + j] = qw[j];
   __syncthreads();
   uint32_t* out = reinterpret_cast<uint32_t*>(queries + (size_t)f * cap + p0);
-  for (int i = tid; i < cnt * Q_DW; i += 256) out[i] = rec[i];
+  for (int i = tid; i < cnt * Q_DW; i += TQS_T) out[i] = rec[i];
+#endif
 }
 
 // ---- projection prologue of Fuse / Fuse(Sim3) / SearchBySim3 / SearchByProjection(KF,Scw) / SearchByProjection(Frame,KF,...)
@@ -460,7 +476,7 @@ void orbfe_launch_track_queries_stereo(const orbfe_keypoint* kps, const uint8_t*
                                        const orbfe_track_pose* poses, int frame_shift, orbfe_query* queries, int32_t* nq, int n_frames,
                                        hipStream_t s) {
   const TqsFrame B{kps, desc, n, depth, cams}, Cy{c_kps, c_desc, c_n, c_depth, c_cam};
-  hipLaunchKernelGGL(track_queries_stereo_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, s, B, Cy, c_kps ? 1 : 0, cap, n_frames,
+  hipLaunchKernelGGL(track_queries_stereo_kernel, dim3((cap + TQS_T - 1) / TQS_T, n_frames), dim3(TQS_T), 0, s, B, Cy, c_kps ? 1 : 0, cap, n_frames,
                      frame_shift, observed, poses, queries, nq);
 }
 
