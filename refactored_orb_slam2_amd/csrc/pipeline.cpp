@@ -10,6 +10,22 @@
 //   -> Tracking::TrackWithMotionModel: UpdateLastFrame / UnprojectStereo (:668-679), SearchByProjection(cur, last, th)
 //      (L/src/ORBmatcher.cc:1247-1383)
 #include <hip/hip_runtime.h>
+#ifndef PIPE_CARRY_COPIES
+#define PIPE_CARRY_COPIES 0
+#endif
+#ifndef PIPE_OUT_KERNEL
+#define PIPE_OUT_KERNEL 4   // the output blocks leave by a copy kernel of at least that many workgroups (pipeline_kernels.hip); 0: hipMemcpyAsync (A/B)
+#endif
+#ifndef PIPE_OUT_KERNEL_MAX
+#define PIPE_OUT_KERNEL_MAX 8
+#endif
+// Workgroups of a copy-out.  A workgroup moves ~5.5 GB/s over the link (posted 16-byte stores), and the FEWER of them the better for the
+// kernels beside them -- 37 MB per 2.3 ms chunk (KITTI, every block): 1 / 2 / 3 / 4 / 8 / 16 / 64 workgroups = 53 / 92 / 108 / 109 / 105 /
+// 97 / 89 k frames/s (one and two cannot keep up; from eight on the stores in flight slow the chip's other traffic); 2.5 MB: any count.
+static inline int out_workgroups(size_t bytes) {
+  const size_t w = bytes >> 23;   // one per 8 MB
+  return (int)(w < PIPE_OUT_KERNEL ? PIPE_OUT_KERNEL : w > PIPE_OUT_KERNEL_MAX ? PIPE_OUT_KERNEL_MAX : w);
+}
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,6 +35,7 @@
 #include <vector>
 
 #include "../../include/orbfe.h"
+#include "pipeline_internal.h"
 
 void orbfe_set_error(const char* fmt, ...);
 
@@ -475,20 +492,33 @@ static int submit_chunk(orbfe_pipeline* p, int slot, int n, int has_predecessor,
       PCHK(hipMemsetAsync(d_ntr, 0, sizeof(int32_t), cs));
       PCHK(hipMemsetAsync(d_assigned, 0xff, sizeof(int32_t) * (size_t)cap, cs));
     }
-    // carry: the last frame's keypoints, descriptors, depth, camera and count for the first frame of the next chunk
+    // carry: the last frame's keypoints, descriptors, depth, camera and count for the first frame of the next chunk (one launch)
     const size_t last = (size_t)(n - 1) * cap;
+#if PIPE_CARRY_COPIES   // five device-to-device copies (A/B)
     PCHK(hipMemcpyAsync(p->d_carry, d_dl + last * 32, (size_t)cap * 32, hipMemcpyDeviceToDevice, cs));
     PCHK(hipMemcpyAsync(p->d_carry + p->cy_kps, d_kl + last, (size_t)cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToDevice, cs));
     PCHK(hipMemcpyAsync(p->d_carry + p->cy_depth, d_depth + last, (size_t)cap * sizeof(float), hipMemcpyDeviceToDevice, cs));
     PCHK(hipMemcpyAsync(p->d_carry + p->cy_cam, d_cams + (n - 1), sizeof(orbfe_unproject_cam), hipMemcpyDeviceToDevice, cs));
     PCHK(hipMemcpyAsync(p->d_carry + p->cy_n, d_nl + (n - 1), sizeof(int32_t), hipMemcpyDeviceToDevice, cs));
+#else
+    orbfe_launch_carry_frame(d_dl + last * 32, d_kl + last, d_depth + last, d_cams + (n - 1), d_nl + (n - 1), cap, p->d_carry,
+                             reinterpret_cast<orbfe_keypoint*>(p->d_carry + p->cy_kps), reinterpret_cast<float*>(p->d_carry + p->cy_depth),
+                             reinterpret_cast<orbfe_unproject_cam*>(p->d_carry + p->cy_cam),
+                             reinterpret_cast<int32_t*>(p->d_carry + p->cy_n), cs);
+    PCHK(hipGetLastError());
+#endif
   }
   PCHK(hipEventRecord(s.ev_done, cs));
   // ---- copy out: the whole block in one copy, or the blocks the configuration asks for (the counts always: they lead the block)
   PCHK(hipStreamWaitEvent(p->s_out, s.ev_done, 0));
   const int om = c.output_mask;
   if (om == 0) {
+#if PIPE_OUT_KERNEL
+    orbfe_launch_copy_block(s.d_out, s.h_out, L.bytes, out_workgroups(L.bytes), p->s_out);
+    PCHK(hipGetLastError());
+#else
     PCHK(hipMemcpyAsync(s.h_out, s.d_out, L.bytes, hipMemcpyDeviceToHost, p->s_out));
+#endif
   } else {
     // block boundaries in layout order: counts | assigned | u_right, depth | keypoints | descriptors; adjacent wanted blocks go in one copy
     const size_t edge[6] = {0, L.assigned, L.u_right, L.kps, L.desc, L.bytes};
@@ -498,7 +528,12 @@ static int submit_chunk(orbfe_pipeline* p, int slot, int n, int has_predecessor,
       if (!want[b]) { b++; continue; }
       int e = b;
       while (e + 1 < 5 && want[e + 1]) e++;
+#if PIPE_OUT_KERNEL   // (block boundaries are multiples of 256 bytes)
+      orbfe_launch_copy_block(s.d_out + edge[b], s.h_out + edge[b], edge[e + 1] - edge[b], out_workgroups(edge[e + 1] - edge[b]), p->s_out);
+      PCHK(hipGetLastError());
+#else
       PCHK(hipMemcpyAsync(s.h_out + edge[b], s.d_out + edge[b], edge[e + 1] - edge[b], hipMemcpyDeviceToHost, p->s_out));
+#endif
       b = e + 1;
     }
   }

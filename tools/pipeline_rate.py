@@ -5,6 +5,8 @@ ring of slots.  SLOTS (default 3), F (256), K chunks (60), MASK (orbfe_pipeline_
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
+from refactored_orb_slam2_amd import _lib
+if os.environ.get("ORBFE_AB_LIB"): _lib.LIB_PATH = os.path.join(_lib.CSRC, "_ab", "liborbfe_%s.so" % os.environ["ORBFE_AB_LIB"])
 from refactored_orb_slam2_amd import synth
 from refactored_orb_slam2_amd.pipeline import StereoPipeline
 W, H, NF = 1241, 376, 2000
@@ -12,7 +14,6 @@ F, S, K = int(os.environ.get("F", "256")), int(os.environ.get("SLOTS", "3")), in
 MASK, LAYOUT = int(os.environ.get("MASK", "0")), int(os.environ.get("LAYOUT", "-1"))
 pairs = synth.sequence(W, H, 16, seq=0, stereo=True)
 if LAYOUT >= 0:
-    from refactored_orb_slam2_amd import _lib
     assert _lib.lib().orbfe_debug_pipeline_streams(LAYOUT) == 0
 with StereoPipeline(W, H, F, 718.856, 718.856, 607.1928, 185.2157, 386.1448, 7.0, n_features=NF, slots=S, output_mask=MASK) as p:
     for s in range(S):
