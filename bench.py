@@ -247,10 +247,10 @@ def per_frame_latency(cfg, n_frames: int):
         rb = subprocess.run(base + ["--decode-threads", str(bthreads), "--batch", "256", "--repeat", "4"], capture_output=True, text=True, timeout=600)
         rp = subprocess.run(base + ["--decode-threads", str(bthreads), "--batch", "256", "--preload", "1", "--repeat", "16"], capture_output=True, text=True, timeout=600)
         rq = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "2", "--repeat", "24"], capture_output=True, text=True, timeout=600)
-        rd = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "144"], capture_output=True, text=True, timeout=600)
+        rd = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "288"], capture_output=True, text=True, timeout=600)
         # the same with orbfe_pipeline_config.output_mask: only the tracked assignments (+ the counts), only the counts copied to the host
-        rdm = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "144", "--outputs", "matches"], capture_output=True, text=True, timeout=600)
-        rdc = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "144", "--outputs", "counts"], capture_output=True, text=True, timeout=600)
+        rdm = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "288", "--outputs", "matches"], capture_output=True, text=True, timeout=600)
+        rdc = subprocess.run(base + ["--decode-threads", str(threads), "--batch", "256", "--preload", "3", "--repeat", "288", "--outputs", "counts"], capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         return {"error": f"stereo_kitti exited with {r.returncode}: " + (r.stderr or r.stdout)[-300:]}
     med = re.search(r"median tracking time: ([0-9.eE+-]+)", r.stdout)
@@ -283,7 +283,7 @@ def per_frame_latency(cfg, n_frames: int):
                     "frames_per_s_batched_pinned_resident": float(sqq.group(3)) if sqq else None,
                     "batched_pinned_resident_note": "--preload 2: the slots keep their frames after the first chunks, no host work per frame: the C++ pipeline's own rate with PCIe both ways (what e2e_frames_per_s measures from Python)",
                     "frames_per_s_batched_device_resident": float(sqd.group(3)) if sqd else None,
-                    "batched_device_resident_note": "--preload 3 --repeat 144 (432 chunks, the first three uploaded inside the clock): after the first chunks the frames stay in the slots' DEVICE input blocks (orbfe_pipeline_submit_resident): the C++ "
+                    "batched_device_resident_note": "--preload 3 --repeat 288 (864 chunks; the first three are filled by the host pool and uploaded inside the clock: ~50 ms): after the first chunks the frames stay in the slots' DEVICE input blocks (orbfe_pipeline_submit_resident): the C++ "
                                                     "pipeline handle at its kernels' rate, every result block still copied to the host (37 MB per chunk) -- what a device-side producer of frames gets",
                     "frames_per_s_batched_device_resident_matches": float(sqdm.group(3)) if sqdm else None,
                     "frames_per_s_batched_device_resident_counts": float(sqdc.group(3)) if sqdc else None,
