@@ -104,3 +104,37 @@ def test_pipeline_handle_validates_and_has_no_cpu_fallback(L):
         assert L.orbfe_pipeline_create(C.byref(good), -1, C.byref(h)) == _lib.ERR_NO_DEVICE and not h.value
         with pytest.raises(_lib.OrbfeError):
             StereoPipeline(1241, 376, 8, 718.856, 718.856, 607.19, 185.21, 386.14)
+
+
+def test_no_hot_kernel_uses_scratch_memory():
+    """The compiler's own resource report (tools/scratch_check.sh as a test): no kernel spills registers, and none keeps anything in
+    scratch (private) memory except the three rare-path resolvers.  A by-value struct indexed with a per-lane value lives there -- 164
+    bytes per thread of it were the whole time of the track-query kernels in rounds 3-5 (DESIGN lesson 58); this keeps it from coming back."""
+    import glob, re, shutil, subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("no hipcc")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "refactored_orb_slam2_amd", "csrc")
+    allowed = {"proj_resolve_kernel": 20, "bow_finish_kernel": 16, "init_resolve_kernel": 16}   # bytes per lane, rare paths only
+    seen = 0
+    for src in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+                            "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-rdc", "--cuda-device-only", "-c", "-o", os.devnull,
+                            "-Rpass-analysis=kernel-resource-usage", src], capture_output=True, text=True, cwd=csrc, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        name = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"remark:\s+Function Name: (\S+)", line)
+            if m:
+                name = m.group(1); seen += 1
+                continue
+            m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill): (\d+)", line)
+            if not m or name is None:
+                continue
+            what, val = m.group(1), int(m.group(2))
+            if what.startswith("Scratch"):
+                limit = max([v for k, v in allowed.items() if k in name] + [0])
+                assert val <= limit, f"{os.path.basename(src)}: {name} keeps {val} bytes per lane in scratch memory"
+            elif what.startswith("VGPRs"):
+                assert val == 0, f"{os.path.basename(src)}: {name} spills {val} vector registers"
+    assert seen >= 30   # every kernel of the library was looked at
